@@ -1,0 +1,263 @@
+"""Time-step driver behind the problem-file API: the ``turtleFSI -p <problem>`` replacement.
+
+Host-side counterpart of turtleFSI's ``monolithic.py`` + ``utils/argpar.py`` as VaSP drives them
+[REF docs/simulation.md:9-31; tests/test_simulations.py:22-24; SURVEY.md §3.1]: parse the same CLI,
+run the seven problem hooks in the same order with the whole namespace as keyword arguments, keep the
+same loop (``while t <= T + dt/10``), the same log lines [REF src/vasp/postprocessing/log_plotter.py:71-82]
+and the same output tree.  The per-step Newton solve itself is not here: it is one call through the
+C-ABI (``include/vaspfsi.h``) into the HIP time-step kernel.
+"""
+from __future__ import annotations
+
+import argparse
+import ast
+import importlib
+import importlib.util
+import json
+import sys
+import time as _time
+from pathlib import Path
+from pprint import pprint
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+
+from . import problems as _defaults
+from .fem import (DirichletBC, FormTerms, MixedFunction, MixedSpace, RobinTerm, SurfacePressureTerm,
+                  resolve_bcs)
+from .mesh import FsiMesh
+
+MATERIAL_IDS = {"StVenantKirchoff": 0, "MooneyRivlin": 1}
+
+
+# ------------------------------------------------------------------------------------------------
+# CLI (turtleFSI/utils/argpar.py as used by VaSP)
+# ------------------------------------------------------------------------------------------------
+
+def _coerce(text: str):
+    try:
+        return ast.literal_eval(text)
+    except (ValueError, SyntaxError):
+        return text
+
+
+def parse(argv: Optional[List[str]] = None) -> Dict[str, object]:
+    ap = argparse.ArgumentParser(prog="vaspfsi", description="MI355X-native monolithic ALE-FSI solver "
+                                 "behind the turtleFSI problem-file API")
+    ap.add_argument("-p", "--problem", default="offset_stenosis")
+    ap.add_argument("-dt", "--time-step", dest="dt", type=float, default=None)
+    ap.add_argument("-T", "--end-time", dest="T", type=float, default=None)
+    ap.add_argument("-t", "--theta", dest="theta", type=float, default=None)
+    ap.add_argument("--atol", type=float, default=None)
+    ap.add_argument("--rtol", type=float, default=None)
+    ap.add_argument("--max-it", dest="max_it", type=int, default=None)
+    ap.add_argument("--lmbda", type=float, default=None)
+    ap.add_argument("--recompute", type=int, default=None)
+    ap.add_argument("--recompute-tstep", dest="recompute_tstep", type=int, default=None)
+    ap.add_argument("--verbose", type=_coerce, default=None)
+    ap.add_argument("--folder", default=None)
+    ap.add_argument("--sub-folder", dest="sub_folder", default=None)
+    ap.add_argument("--restart-folder", dest="restart_folder", default=None)
+    ap.add_argument("--save-step", dest="save_step", type=int, default=None)
+    ap.add_argument("--save-deg", dest="save_deg", type=int, default=None)
+    ap.add_argument("--checkpoint-step", dest="checkpoint_step", type=int, default=None)
+    ap.add_argument("--killtime", type=float, default=None)
+    ap.add_argument("--new-arguments", dest="new_arguments", nargs="*", default=[])
+    ns = ap.parse_args(argv)
+    out = {k: v for k, v in vars(ns).items() if v is not None and k != "new_arguments"}
+    for kv in ns.new_arguments:
+        if "=" not in kv:
+            raise SystemExit(f"--new-arguments expects key=value, got {kv!r}")
+        k, v = kv.split("=", 1)
+        out[k] = _coerce(v)
+    return out
+
+
+def load_problem(name: str):
+    """Problem lookup, current directory first (as the reference's ``exec("from <problem> import *")``)."""
+    local = Path.cwd() / (name if name.endswith(".py") else name + ".py")
+    if local.exists():
+        spec = importlib.util.spec_from_file_location(local.stem, local)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    return importlib.import_module(f"vasp_amd.problems.{name}")
+
+
+# ------------------------------------------------------------------------------------------------
+# description handed to the time-step kernel
+# ------------------------------------------------------------------------------------------------
+
+def _as_list(x):
+    return list(x) if isinstance(x, (list, tuple)) else [x]
+
+
+def build_properties(v: dict):
+    """``fluid_properties`` / ``solid_properties`` lists from scalar-or-list parameters."""
+    dx_f = _as_list(v["dx_f_id"])
+    if not v.get("fluid_properties"):
+        rho, mu = _as_list(v["rho_f"]), _as_list(v["mu_f"])
+        v["fluid_properties"] = [dict(dx_f_id=dx_f[i], rho_f=rho[i if len(rho) > 1 else 0],
+                                      mu_f=mu[i if len(mu) > 1 else 0]) for i in range(len(dx_f))]
+    elif isinstance(v["fluid_properties"], dict):
+        v["fluid_properties"] = [v["fluid_properties"]]
+    dx_s = _as_list(v["dx_s_id"])
+    if not v.get("solid_properties"):
+        pick = lambda key, i: _as_list(v[key])[i if len(_as_list(v[key])) > 1 else 0]
+        v["solid_properties"] = [dict(dx_s_id=dx_s[i], material_model=pick("material_model", i),
+                                      rho_s=pick("rho_s", i), mu_s=pick("mu_s", i), lambda_s=pick("lambda_s", i))
+                                 for i in range(len(dx_s))]
+    elif isinstance(v["solid_properties"], dict):
+        v["solid_properties"] = [v["solid_properties"]]
+    return v["fluid_properties"], v["solid_properties"]
+
+
+def build_description(mesh: FsiMesh, v: dict, bcs, F_solid_linear) -> dict:
+    """Plain-array description of the discrete problem (what ``fsi_create`` receives)."""
+    fluid_properties, solid_properties = v["fluid_properties"], v["solid_properties"]
+    kind = -np.ones(mesh.num_cells, dtype=np.int32)
+    region = np.zeros(mesh.num_cells, dtype=np.int32)
+    for r, fp in enumerate(fluid_properties):
+        sel = mesh.cell_markers == fp["dx_f_id"]
+        kind[sel], region[sel] = 0, r
+    for r, spp in enumerate(solid_properties):
+        sel = mesh.cell_markers == spp["dx_s_id"]
+        kind[sel], region[sel] = 1, r
+    if (kind < 0).any():
+        bad = np.unique(mesh.cell_markers[kind < 0])
+        raise ValueError(f"cells with domain markers {bad.tolist()} belong to neither dx_f_id nor dx_s_id")
+    solid_rows = []
+    for spp in solid_properties:
+        model = spp.get("material_model", "StVenantKirchoff")
+        if model not in MATERIAL_IDS:
+            raise NotImplementedError(f"material_model {model!r}")
+        solid_rows.append((float(spp["rho_s"]), float(spp.get("mu_s", 0.0)), float(spp.get("lambda_s", 0.0))))
+    desc = dict(
+        coords=mesh.coords, tets=mesh.tets, tet_nodes=mesh.tet_nodes, num_nodes=mesh.num_nodes,
+        cell_kind=kind, cell_region=region,
+        fluid_props=[(float(fp["rho_f"]), float(fp["mu_f"])) for fp in fluid_properties],
+        solid_props=solid_rows,
+        solid_models=[MATERIAL_IDS[spp.get("material_model", "StVenantKirchoff")] for spp in solid_properties],
+        dt=float(v["dt"]), theta=float(v["theta"]),
+    )
+    pterms = [tm for tm in F_solid_linear if isinstance(tm, SurfacePressureTerm)]
+    if len(pterms) > 1:
+        raise NotImplementedError("more than one surface-pressure term")
+    if pterms:
+        fids, plus = pterms[0].facets(mesh)
+        desc["pressure_facets"] = mesh.facet_nodes[fids]
+        desc["pressure_facet_cell"] = plus
+    rterms = [tm for tm in F_solid_linear if isinstance(tm, RobinTerm)]
+    if rterms:
+        rf, rk, rc = [], [], []
+        for tm in rterms:
+            fids = np.nonzero(np.asarray(tm.boundaries) == tm.marker)[0]
+            rf.append(mesh.facet_nodes[fids])
+            rk.append(np.full(len(fids), tm.k_s))
+            rc.append(np.full(len(fids), tm.c_s))
+        desc["robin_facets"] = np.concatenate(rf)
+        desc["robin_k"] = np.concatenate(rk)
+        desc["robin_c"] = np.concatenate(rc)
+    bc_dofs, bc_values = resolve_bcs(bcs, mesh.num_dofs)
+    desc["bc_dofs"] = bc_dofs
+    return desc, bc_values, (pterms[0].pressure if pterms else None)
+
+
+# ------------------------------------------------------------------------------------------------
+# the driver
+# ------------------------------------------------------------------------------------------------
+
+def default_backend(desc):
+    from .capi import HipBackend   # raises loudly if libvaspfsi.so or the GPU is missing
+    return HipBackend(desc)
+
+
+def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_backend, out=print):
+    """Run one simulation; returns the final namespace (for tests).  ``out`` receives solver log lines."""
+    args = parse(argv)
+    problem = load_problem(args.pop("problem"))
+    hook = lambda name: getattr(problem, name, getattr(_defaults, name))
+
+    v = {k: (list(x) if isinstance(x, list) else x) for k, x in _defaults.default_variables.items()}
+    v = hook("set_problem_parameters")(default_variables=v, **args)
+    v.update(args)
+    build_properties(v)
+    ns: Dict[str, object] = dict(v)
+    ns["default_variables"] = v
+    if ns["verbose"]:
+        pprint(v)
+
+    # folders ---------------------------------------------------------------------------------
+    folder = Path(str(ns["folder"]))
+    if ns.get("sub_folder") is not None:
+        results = folder / str(ns["sub_folder"])
+    else:
+        existing = [int(p.name) for p in folder.glob("*") if p.name.isdigit()] if folder.exists() else []
+        results = folder / str(max(existing) + 1 if existing else 1)
+    for sub in ("Checkpoint", "Mesh", "Visualization"):
+        (results / sub).mkdir(parents=True, exist_ok=True)
+    ns.update(results_folder=results, visualization_folder=results / "Visualization",
+              checkpoint_folder=results / "Checkpoint")
+
+    # mesh + space -------------------------------------------------------------------------------
+    mesh, domains, boundaries = hook("get_mesh_domain_and_boundaries")(**ns)
+    mesh.cell_markers, mesh.facet_markers = domains, boundaries
+    mesh.write(results / "Mesh" / "mesh.h5")
+    DVP = MixedSpace(mesh)
+    n_dof = mesh.num_dofs
+    state = {k: np.zeros(n_dof) for k in ("n", "n-1")}
+    dvp_ = {k: MixedFunction(mesh, x) for k, x in state.items()}
+    ns.update(mesh=mesh, domains=domains, boundaries=boundaries, DVP=DVP, dvp_=dvp_, psi="psi", phi="phi",
+              gamma="gamma", F_solid_linear=FormTerms(), F_fluid_linear=FormTerms(),
+              t=float(ns["t"]), counter=int(ns["counter"]))
+    if ns.get("robin_bc"):
+        ds_ids, k_s, c_s = _as_list(ns["ds_s_id"]), _as_list(ns["k_s"]), _as_list(ns["c_s"])
+        for i, marker in enumerate(ds_ids):
+            ns["F_solid_linear"] += RobinTerm(boundaries, marker, k_s[i], c_s[i])
+
+    upd = hook("initiate")(**ns)
+    ns.update(upd or {})
+    upd = hook("create_bcs")(**ns)
+    ns.update(upd or {})
+
+    desc, bc_values, pressure = build_description(mesh, v, ns["bcs"], ns["F_solid_linear"])
+    backend = backend_factory(desc)
+    ns["backend"] = backend
+    first_step_num = ns["counter"]
+    newton_keys = ("atol", "rtol", "max_it", "lmbda", "recompute", "recompute_tstep")
+
+    t, dt, T = ns["t"], float(ns["dt"]), float(ns["T"])
+    total_newton = 0
+    t_loop = _time.perf_counter()
+    while t <= T + dt / 10:
+        t0 = _time.perf_counter()
+        t += dt
+        ns["t"] = t
+        upd = hook("pre_solve")(**ns)
+        ns.update(upd or {})
+
+        backend.set_dirichlet_values(bc_values())
+        backend.set_interface_pressure(float(pressure.P) if pressure is not None else 0.0)
+        hist = backend.newton_solve(counter=ns["counter"], first_step_num=first_step_num,
+                                    log=out if ns["verbose"] else None, **{k: ns[k] for k in newton_keys})
+        total_newton += len(hist)
+        backend.shift()                       # dvp_["n-1"] <- dvp_["n"]
+        backend.get_state("n", state["n"])
+        state["n-1"][:] = state["n"]
+
+        hook("post_solve")(**ns)
+        ns["counter"] += 1
+        out("Solved for timestep %d, t = %.4f in %.1f s" % (ns["counter"], t, _time.perf_counter() - t0))
+    ns["time_loop_seconds"] = _time.perf_counter() - t_loop
+    ns["newton_iterations"] = total_newton
+    hook("finished")(**ns)
+    return ns
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    run(argv)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
