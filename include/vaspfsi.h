@@ -1,0 +1,146 @@
+/*
+ * vaspfsi.h — C-ABI of the MI355X-native monolithic ALE-FSI time-step kernel (libvaspfsi.so).
+ *
+ * Drop-in boundary.  VaSP's simulation stage hands its problem files to turtleFSI, whose
+ * hot loop is, per Newton iteration, `assemble(J_nonlinear)` (+ `A_pre`, `ident_zeros`, `bc.apply(A)`),
+ * `assemble(-F)`, `bc.apply(b, u)`, `LUSolver.solve`, `axpy`, `bc.apply(u)` and two norms
+ * (turtleFSI/modules/newtonsolver.py `solver_setup` / `newtonsolver`; call sites in the reference:
+ * src/vasp/simulations/offset_stenosis.py:9 `from turtleFSI.problems import *`, the hooks at :27,:85,:143,
+ * :151,:199,:216 and the solver keys at :44-48).  Each entry point below names the reference-side call it
+ * replaces.  All buffers are caller-owned host memory unless stated otherwise; every function returns an
+ * `int` status (FSI_OK == 0) and never throws across the ABI.  One host thread per context; contexts are
+ * independent (one per GPU).
+ *
+ * Global dof layout at this boundary ("user layout", vasp_amd/mesh.py): [ d: 3*N2 | v: 3*N2 | p: V ],
+ * component-minor, N2 = #P2 nodes (vertices first, then edges), V = #vertices.
+ */
+#ifndef VASPFSI_H
+#define VASPFSI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSI_OK 0
+#define FSI_ERR_INVALID 1      /* bad argument / inconsistent mesh arrays                                   */
+#define FSI_ERR_DEVICE 2       /* HIP runtime error (no device, out of memory, launch failure)              */
+#define FSI_ERR_DIVERGED 3     /* residual or update > 1e20 or NaN: the reference raises RuntimeError here   */
+#define FSI_ERR_LINEAR 4       /* Krylov breakdown / no convergence within max iterations                    */
+#define FSI_ERR_PIVOT 5        /* zero or non-finite pivot in the incomplete factorisation                   */
+
+typedef struct FsiCtx FsiCtx;
+
+/* Mesh + discrete-problem description.  Replaces: Mesh/MeshFunction reads and
+ * FunctionSpace(mesh, MixedElement([P2^3, P2^3, P1])) in turtleFSI monolithic.py, driven by
+ * get_mesh_domain_and_boundaries [REF src/vasp/simulations/offset_stenosis.py:85-140]. */
+typedef struct FsiMeshDesc {
+  int64_t num_vertices;        /* V                                                                         */
+  int64_t num_nodes;           /* N2 = V + #edges                                                           */
+  int64_t num_cells;           /* C                                                                         */
+  const double* coords;        /* [V][3] vertex coordinates                                                 */
+  const int32_t* tet_nodes;    /* [C][10] P2 node ids, UFC local order (4 vertices, 6 edges), rows of the   */
+                               /*         vertex part ascending                                             */
+  const int32_t* cell_kind;    /* [C] 0 = fluid, 1 = solid                                                  */
+  const int32_t* cell_region;  /* [C] index into fluid_props / solid_props                                  */
+} FsiMeshDesc;
+
+/* Material / scheme parameters.  Replaces: fluid_properties / solid_properties lists, dt, theta handed to
+ * fluid_setup / solid_setup / extrapolate_setup [REF offset_stenosis.py:36-80; SURVEY.md §8a a4-a6]. */
+typedef struct FsiParams {
+  double dt;
+  double theta;
+  int32_t num_fluid_regions;
+  const double* fluid_props;   /* [nf][2]  rho_f, mu_f                                                      */
+  int32_t num_solid_regions;
+  const double* solid_props;   /* [ns][3]  rho_s, mu_s, lambda_s  (StVenantKirchoff)                        */
+  const int32_t* solid_models; /* [ns]     0 = StVenantKirchoff                                             */
+  double delta;                /* d_t = v penalty in the solid (turtleFSI solid.py: 1e7)                    */
+  double laplace_alpha;        /* mesh-lifting coefficient ("constant": 1.0)                                */
+} FsiParams;
+
+typedef struct FsiNewtonOpts {
+  double atol, rtol;           /* newtonsolver(): loop while rel_res > rtol and residual > atol             */
+  int32_t max_it;
+  double lmbda;                /* relaxation of the update                                                  */
+  int32_t recompute;           /* re-assemble the Jacobian every `recompute` Newton iterations              */
+  int32_t recompute_tstep;     /* ... and every `recompute_tstep` time steps                                */
+  int32_t counter;             /* time-step counter of this call                                            */
+  int32_t first_step_num;      /* counter value of the first step of this run (forces a Jacobian)           */
+  double lin_rtol;             /* Krylov stop: ||r|| <= lin_rtol * ||b||   (row-equilibrated norms)         */
+  int32_t lin_max_it;          /* Krylov iteration cap per linear solve                                     */
+  int32_t lin_solver;          /* 0 = GCR with recycled directions, 1 = BiCGStab                            */
+} FsiNewtonOpts;
+
+typedef struct FsiNewtonIter {
+  double residual;             /* ||b||_2   ("r (atol)")                                                    */
+  double rel_res;              /* ||du||_2  ("r (rel)")                                                     */
+  int32_t recomputed;          /* 1 if "Compute Jacobian matrix" happened before this iteration             */
+  int32_t lin_iters;           /* Krylov iterations (new directions) of this iteration's linear solve       */
+  double lin_relres;           /* achieved ||r||/||b||                                                      */
+} FsiNewtonIter;
+
+/* ---- lifetime ------------------------------------------------------------------------------------ */
+/* Replaces: space / form set-up up to solver_setup() (A_pre assembled at the zero state). `device` is the
+ * HIP device ordinal. */
+int fsi_create(const FsiMeshDesc* mesh, const FsiParams* params, int device, FsiCtx** out);
+int fsi_destroy(FsiCtx* ctx);
+const char* fsi_last_error(const FsiCtx* ctx);
+
+/* ---- boundary data ------------------------------------------------------------------------------- */
+/* Replaces: bcs = [DirichletBC(...), ...] [REF offset_stenosis.py:170-179].  `dofs` are unique user-layout
+ * dofs with list-order precedence already resolved. */
+int fsi_set_dirichlet(FsiCtx* ctx, int64_t n, const int64_t* dofs);
+/* Replaces: per-step expression updates in pre_solve [REF offset_stenosis.py:199-208]; values[i] belongs to dofs[i]. */
+int fsi_set_dirichlet_values(FsiCtx* ctx, int64_t n, const double* values);
+/* Replaces: F_solid_linear += P * inner(n('+'), psi('+')) * dS(fsi_id) [REF offset_stenosis.py:184-190].
+ * `facet_nodes` [nf][6] P2 nodes (3 vertices, 3 edges (b,c),(a,c),(a,b)); `plus_cell` [nf] the '+' cell. */
+int fsi_set_pressure_facets(FsiCtx* ctx, int64_t nf, const int32_t* facet_nodes, const int32_t* plus_cell);
+/* Replaces: InterfacePressure.update(t) -> P [REF src/vasp/simulations/simulation_common.py:371-395]. */
+int fsi_set_interface_pressure(FsiCtx* ctx, double P);
+/* Replaces: robin_bc terms of solid_setup [REF src/vasp/simulations/aneurysm.py:73-76]. */
+int fsi_set_robin_facets(FsiCtx* ctx, int64_t nf, const int32_t* facet_nodes, const double* k_s, const double* c_s);
+/* Finishes set-up: assembles A_pre = assemble(J_linear) at the current state (solver_setup()). */
+int fsi_solver_setup(FsiCtx* ctx);
+
+/* ---- the hot path --------------------------------------------------------------------------------- */
+/* b = assemble(-F); [bc.apply(b, u)]; writes ||b||_2 */
+int fsi_assemble_residual(FsiCtx* ctx, double* norm);
+/* A = assemble(J_nonlinear) + A_pre; ident_zeros; [bc.apply(A)]; refreshes the preconditioner */
+int fsi_assemble_jacobian(FsiCtx* ctx);
+/* One linear solve A du = b with the current factorisation (up_sol.solve). */
+int fsi_solve(FsiCtx* ctx, double lin_rtol, int32_t lin_max_it, int32_t lin_solver, int32_t* iters, double* relres);
+/* newtonsolver(): one time step.  `iters` has room for opts->max_it entries; *n_iters receives the count. */
+int fsi_newton_solve(FsiCtx* ctx, const FsiNewtonOpts* opts, FsiNewtonIter* iters, int32_t* n_iters);
+/* dvp_["n-1"] <- dvp_["n"] (the reference's vector shift after each step). */
+int fsi_shift(FsiCtx* ctx);
+
+/* ---- state / introspection (checkpoint, restart, parity dumps) --------------------------------------- */
+/* which: 0 = dvp_["n"], 1 = dvp_["n-1"], 2 = last rhs b, 3 = last update du.  User layout, length ndof. */
+int fsi_get_state(FsiCtx* ctx, int which, double* out);
+int fsi_set_state(FsiCtx* ctx, int which, const double* in);
+int64_t fsi_num_dofs(const FsiCtx* ctx);
+int64_t fsi_matrix_nnz(const FsiCtx* ctx);
+/* Copies the assembled matrix out in user-layout row/column numbering (CSR, rows sorted).  rowptr [ndof+1],
+ * cols/vals [nnz].  Values are the un-equilibrated Jacobian after ident_zeros and bc.apply. */
+int fsi_get_matrix(FsiCtx* ctx, int64_t* rowptr, int64_t* cols, double* vals);
+/* y = A x with the device SpMV (user layout in/out). */
+int fsi_spmv(FsiCtx* ctx, const double* x, double* y);
+
+/* ---- timing of the device kernels (HIP events on the solver stream) ---------------------------------- */
+typedef struct FsiTimers {
+  double residual_ms;  int64_t residual_calls;
+  double jacobian_ms;  int64_t jacobian_calls;
+  double factor_ms;    int64_t factor_calls;
+  double spmv_ms;      int64_t spmv_calls;
+  double precond_ms;   int64_t precond_calls;
+  double ortho_ms;     int64_t ortho_calls;
+  double krylov_ms;    int64_t krylov_solves;   int64_t krylov_iters;
+} FsiTimers;
+int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VASPFSI_H */

@@ -1,0 +1,260 @@
+"""ctypes binding of ``libvaspfsi.so`` (``include/vaspfsi.h``) and the backend the time-step driver uses.
+
+There is no CPU fallback: if the HIP library has not been built, or no GPU is visible, constructing a
+``HipBackend`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import List, Optional
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "libvaspfsi.so"
+
+FSI_OK = 0
+ERROR_NAMES = {1: "FSI_ERR_INVALID", 2: "FSI_ERR_DEVICE", 3: "FSI_ERR_DIVERGED", 4: "FSI_ERR_LINEAR", 5: "FSI_ERR_PIVOT"}
+
+EXPORTED_SYMBOLS = (
+    "fsi_create", "fsi_destroy", "fsi_last_error", "fsi_set_dirichlet", "fsi_set_dirichlet_values",
+    "fsi_set_pressure_facets", "fsi_set_interface_pressure", "fsi_set_robin_facets", "fsi_solver_setup",
+    "fsi_assemble_residual", "fsi_assemble_jacobian", "fsi_solve", "fsi_newton_solve", "fsi_shift",
+    "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_get_matrix", "fsi_spmv",
+    "fsi_get_timers",
+)
+
+
+class FsiMeshDesc(C.Structure):
+    _fields_ = [("num_vertices", C.c_int64), ("num_nodes", C.c_int64), ("num_cells", C.c_int64),
+                ("coords", C.c_void_p), ("tet_nodes", C.c_void_p), ("cell_kind", C.c_void_p),
+                ("cell_region", C.c_void_p)]
+
+
+class FsiParams(C.Structure):
+    _fields_ = [("dt", C.c_double), ("theta", C.c_double), ("num_fluid_regions", C.c_int32),
+                ("fluid_props", C.c_void_p), ("num_solid_regions", C.c_int32), ("solid_props", C.c_void_p),
+                ("solid_models", C.c_void_p), ("delta", C.c_double), ("laplace_alpha", C.c_double)]
+
+
+class FsiNewtonOpts(C.Structure):
+    _fields_ = [("atol", C.c_double), ("rtol", C.c_double), ("max_it", C.c_int32), ("lmbda", C.c_double),
+                ("recompute", C.c_int32), ("recompute_tstep", C.c_int32), ("counter", C.c_int32),
+                ("first_step_num", C.c_int32), ("lin_rtol", C.c_double), ("lin_max_it", C.c_int32),
+                ("lin_solver", C.c_int32)]
+
+
+class FsiNewtonIter(C.Structure):
+    _fields_ = [("residual", C.c_double), ("rel_res", C.c_double), ("recomputed", C.c_int32),
+                ("lin_iters", C.c_int32), ("lin_relres", C.c_double)]
+
+
+class FsiTimers(C.Structure):
+    _fields_ = [("residual_ms", C.c_double), ("residual_calls", C.c_int64), ("jacobian_ms", C.c_double),
+                ("jacobian_calls", C.c_int64), ("factor_ms", C.c_double), ("factor_calls", C.c_int64),
+                ("spmv_ms", C.c_double), ("spmv_calls", C.c_int64), ("precond_ms", C.c_double),
+                ("precond_calls", C.c_int64), ("ortho_ms", C.c_double), ("ortho_calls", C.c_int64),
+                ("krylov_ms", C.c_double), ("krylov_solves", C.c_int64), ("krylov_iters", C.c_int64)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class FsiError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{ERROR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path: Optional[Path] = None):
+    """Load libvaspfsi.so and declare the prototypes. Raises if the library has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise RuntimeError(f"{p} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
+                           f"or make -C vasp_amd/csrc). There is no CPU fallback.")
+    lib = C.CDLL(str(p))
+    vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
+    lib.fsi_create.argtypes = [C.POINTER(FsiMeshDesc), C.POINTER(FsiParams), C.c_int, C.POINTER(vp)]
+    lib.fsi_destroy.argtypes = [vp]
+    lib.fsi_last_error.argtypes = [vp]
+    lib.fsi_last_error.restype = C.c_char_p
+    lib.fsi_set_dirichlet.argtypes = [vp, i64, vp]
+    lib.fsi_set_dirichlet_values.argtypes = [vp, i64, vp]
+    lib.fsi_set_pressure_facets.argtypes = [vp, i64, vp, vp]
+    lib.fsi_set_interface_pressure.argtypes = [vp, dbl]
+    lib.fsi_set_robin_facets.argtypes = [vp, i64, vp, vp, vp]
+    lib.fsi_solver_setup.argtypes = [vp]
+    lib.fsi_assemble_residual.argtypes = [vp, C.POINTER(dbl)]
+    lib.fsi_assemble_jacobian.argtypes = [vp]
+    lib.fsi_solve.argtypes = [vp, dbl, i32, i32, C.POINTER(i32), C.POINTER(dbl)]
+    lib.fsi_newton_solve.argtypes = [vp, C.POINTER(FsiNewtonOpts), C.POINTER(FsiNewtonIter), C.POINTER(i32)]
+    lib.fsi_shift.argtypes = [vp]
+    lib.fsi_get_state.argtypes = [vp, C.c_int, vp]
+    lib.fsi_set_state.argtypes = [vp, C.c_int, vp]
+    lib.fsi_num_dofs.argtypes = [vp]
+    lib.fsi_num_dofs.restype = i64
+    lib.fsi_matrix_nnz.argtypes = [vp]
+    lib.fsi_matrix_nnz.restype = i64
+    lib.fsi_get_matrix.argtypes = [vp, vp, vp, vp]
+    lib.fsi_spmv.argtypes = [vp, vp, vp]
+    lib.fsi_get_timers.argtypes = [vp, C.POINTER(FsiTimers), C.c_int]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("fsi_last_error", "fsi_num_dofs", "fsi_matrix_nnz"):
+            fn.restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+STATE = {"n": 0, "n-1": 1, "b": 2, "du": 3}
+
+
+class HipBackend:
+    """One problem instance resident on one GPU; the methods are what ``monolithic.run`` calls per time step."""
+
+    def __init__(self, desc: dict, device: int = 0, lin_rtol: float = 1e-10, lin_max_it: int = 4000,
+                 lin_solver: int = 0):
+        self.lib = load_library()
+        self.ctx = C.c_void_p()
+        self.lin_rtol, self.lin_max_it, self.lin_solver = lin_rtol, lin_max_it, lin_solver
+        coords = np.ascontiguousarray(desc["coords"], dtype=np.float64)
+        tet_nodes = np.ascontiguousarray(desc["tet_nodes"], dtype=np.int32)
+        kind = np.ascontiguousarray(desc["cell_kind"], dtype=np.int32)
+        region = np.ascontiguousarray(desc["cell_region"], dtype=np.int32)
+        fprops = np.ascontiguousarray(np.asarray(desc["fluid_props"], dtype=np.float64).reshape(-1, 2))
+        sprops = np.ascontiguousarray(np.asarray(desc["solid_props"], dtype=np.float64).reshape(-1, 3))
+        smodels = np.ascontiguousarray(desc.get("solid_models", [0] * len(sprops)), dtype=np.int32)
+        md = FsiMeshDesc(len(coords), int(desc["num_nodes"]), len(tet_nodes), _ptr(coords), _ptr(tet_nodes),
+                         _ptr(kind), _ptr(region))
+        pr = FsiParams(float(desc["dt"]), float(desc["theta"]), len(fprops), _ptr(fprops), len(sprops), _ptr(sprops),
+                       _ptr(smodels), float(desc.get("delta", 1.0e7)), float(desc.get("laplace_alpha", 1.0)))
+        rc = self.lib.fsi_create(C.byref(md), C.byref(pr), device, C.byref(self.ctx))
+        if rc != FSI_OK:
+            msg = self.lib.fsi_last_error(self.ctx).decode() if self.ctx else "fsi_create failed"
+            if self.ctx:
+                self.lib.fsi_destroy(self.ctx)
+                self.ctx = C.c_void_p()
+            raise FsiError(rc, msg)
+        self.ndof = int(self.lib.fsi_num_dofs(self.ctx))
+        bc = np.ascontiguousarray(desc.get("bc_dofs", np.zeros(0)), dtype=np.int64)
+        self._check(self.lib.fsi_set_dirichlet(self.ctx, len(bc), _ptr(bc)))
+        self.nbc = len(bc)
+        pf = desc.get("pressure_facets")
+        if pf is not None and len(pf):
+            pf = np.ascontiguousarray(pf, dtype=np.int32)
+            pc = np.ascontiguousarray(desc["pressure_facet_cell"], dtype=np.int32)
+            self._check(self.lib.fsi_set_pressure_facets(self.ctx, len(pf), _ptr(pf), _ptr(pc)))
+        rf = desc.get("robin_facets")
+        if rf is not None and len(rf):
+            rf = np.ascontiguousarray(rf, dtype=np.int32)
+            rk = np.ascontiguousarray(desc["robin_k"], dtype=np.float64)
+            rcoef = np.ascontiguousarray(desc["robin_c"], dtype=np.float64)
+            self._check(self.lib.fsi_set_robin_facets(self.ctx, len(rf), _ptr(rf), _ptr(rk), _ptr(rcoef)))
+        self._check(self.lib.fsi_solver_setup(self.ctx))
+        self.history: List[list] = []
+
+    # ---- plumbing ---------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != FSI_OK:
+            raise FsiError(rc, self.lib.fsi_last_error(self.ctx).decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.fsi_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- backend protocol of monolithic.run -----------------------------------------------------------
+    def set_dirichlet_values(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self._check(self.lib.fsi_set_dirichlet_values(self.ctx, len(v), _ptr(v)))
+
+    def set_interface_pressure(self, P: float):
+        self._check(self.lib.fsi_set_interface_pressure(self.ctx, float(P)))
+
+    def newton_solve(self, *, counter, first_step_num, atol, rtol, max_it, lmbda, recompute, recompute_tstep, log=None):
+        opts = FsiNewtonOpts(atol, rtol, int(max_it), lmbda, int(recompute), int(recompute_tstep), int(counter),
+                             int(first_step_num), self.lin_rtol, self.lin_max_it, self.lin_solver)
+        iters = (FsiNewtonIter * int(max_it))()
+        n = C.c_int32(0)
+        rc = self.lib.fsi_newton_solve(self.ctx, C.byref(opts), iters, C.byref(n))
+        hist = []
+        for i in range(n.value):
+            it = iters[i]
+            if log:
+                if it.recomputed:
+                    log("Compute Jacobian matrix")
+                log("Newton iteration %d: r (atol) = %.3e (tol = %.3e), r (rel) = %.3e (tol = %.3e) "
+                    % (i, it.residual, atol, it.rel_res, rtol))
+            hist.append((it.residual, it.rel_res, bool(it.recomputed), it.lin_iters, it.lin_relres))
+        self.history.append(hist)
+        if rc == 3:
+            raise RuntimeError("Error: The simulation has diverged during the Newton solve.")
+        self._check(rc)
+        return hist
+
+    def shift(self):
+        self._check(self.lib.fsi_shift(self.ctx))
+
+    def get_state(self, which, out=None):
+        out = np.empty(self.ndof) if out is None else out
+        self._check(self.lib.fsi_get_state(self.ctx, STATE[which], _ptr(out)))
+        return out
+
+    def set_state(self, which, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.shape == (self.ndof,)
+        self._check(self.lib.fsi_set_state(self.ctx, STATE[which], _ptr(x)))
+
+    # ---- pieces of the hot path (tests, benchmarks) ----------------------------------------------------
+    def assemble_residual(self) -> float:
+        nrm = C.c_double(0.0)
+        self._check(self.lib.fsi_assemble_residual(self.ctx, C.byref(nrm)))
+        return nrm.value
+
+    def assemble_jacobian(self):
+        self._check(self.lib.fsi_assemble_jacobian(self.ctx))
+
+    def solve(self, lin_rtol=None, lin_max_it=None, lin_solver=None):
+        it, rr = C.c_int32(0), C.c_double(0.0)
+        self._check(self.lib.fsi_solve(self.ctx, self.lin_rtol if lin_rtol is None else lin_rtol,
+                                       self.lin_max_it if lin_max_it is None else lin_max_it,
+                                       self.lin_solver if lin_solver is None else lin_solver, C.byref(it), C.byref(rr)))
+        return it.value, rr.value
+
+    def matrix(self):
+        """The assembled Jacobian (after ident_zeros and bc.apply) as scipy CSR in the user dof layout."""
+        import scipy.sparse as sp
+        nnz = int(self.lib.fsi_matrix_nnz(self.ctx))
+        rp = np.empty(self.ndof + 1, dtype=np.int64)
+        ci = np.empty(nnz, dtype=np.int64)
+        va = np.empty(nnz, dtype=np.float64)
+        self._check(self.lib.fsi_get_matrix(self.ctx, _ptr(rp), _ptr(ci), _ptr(va)))
+        return sp.csr_matrix((va, ci, rp), shape=(self.ndof, self.ndof))
+
+    def spmv(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty(self.ndof)
+        self._check(self.lib.fsi_spmv(self.ctx, _ptr(x), _ptr(y)))
+        return y
+
+    def timers(self, reset=False) -> dict:
+        t = FsiTimers()
+        self._check(self.lib.fsi_get_timers(self.ctx, C.byref(t), int(reset)))
+        return t.as_dict()

@@ -1,0 +1,302 @@
+// Element-loop kernels of the monolithic ALE-FSI step (gfx950): geometry, residual, Jacobian, boundary terms.
+//
+// Replaces `assemble(-F)` and `assemble(J_nonlinear)` / `assemble(J_linear)` of turtleFSI's newtonsolver as VaSP
+// drives it.  One wavefront (64 lanes) owns one tetrahedron:
+//   residual : lanes 0..23 evaluate the 24 quadrature points (interpolation + pointwise flux), results go through
+//              LDS, then all 64 lanes contract against the P2/P1 test tables (one local dof per lane) and
+//              scatter-add into the global vector;
+//   Jacobian : lane j carries the forward-mode derivative along local trial dof j (fsi::Dual), accumulates its
+//              64-entry column in registers and scatter-adds it into the CSR values through the per-element
+//              neighbour-index tables (no search in the hot loop).
+// HBM traffic per tet (algorithmic): residual 10*4 + 2*64*8 + 80 (geometry) + 64*8 write; Jacobian + 64*64*8 write.
+#include "fsi_kernels.hpp"
+
+namespace fsi {
+
+__constant__ double c_qw[NQ];
+__constant__ double c_N[NQ][10];
+__constant__ double c_dN[NQ][10][3];
+__constant__ double c_L[NQ][4];
+
+static const int H_TET_EDGES[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
+
+// FIAT default degree-6 scheme on the tetrahedron: Keast 24 points.
+hipError_t upload_tables() {
+  double qp[NQ][3], qw[NQ];
+  int n = 0;
+  const double a4[3] = {0.214602871259151684, 0.040673958534611353, 0.322337890142275646};
+  const double w4[3] = {0.039922750258167949, 0.010077211055320643, 0.055357181543654720};
+  for (int o = 0; o < 3; ++o) {
+    double a = a4[o], b = 1.0 - 3.0 * a;
+    double pts[4][3] = {{b, a, a}, {a, a, a}, {a, a, b}, {a, b, a}};
+    for (int i = 0; i < 4; ++i) {
+      for (int k = 0; k < 3; ++k) qp[n][k] = pts[i][k];
+      qw[n++] = w4[o] / 6.0;
+    }
+  }
+  {
+    double a = 0.063661001875017525, b = 0.269672331458315867, c = 0.603005664791649076;
+    double pts[12][3] = {{b, a, a}, {a, b, a}, {a, a, b}, {c, a, a}, {a, c, a}, {a, a, c},
+                         {a, b, c}, {b, c, a}, {c, a, b}, {a, c, b}, {b, a, c}, {c, b, a}};
+    for (int i = 0; i < 12; ++i) {
+      for (int k = 0; k < 3; ++k) qp[n][k] = pts[i][k];
+      qw[n++] = 0.048214285714285714 / 6.0;
+    }
+  }
+  double N[NQ][10], dN[NQ][10][3], L[NQ][4];
+  const double dL[4][3] = {{-1, -1, -1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int q = 0; q < NQ; ++q) {
+    double l[4] = {1.0 - qp[q][0] - qp[q][1] - qp[q][2], qp[q][0], qp[q][1], qp[q][2]};
+    for (int a = 0; a < 4; ++a) {
+      L[q][a] = l[a];
+      N[q][a] = l[a] * (2.0 * l[a] - 1.0);
+      for (int k = 0; k < 3; ++k) dN[q][a][k] = (4.0 * l[a] - 1.0) * dL[a][k];
+    }
+    for (int e = 0; e < 6; ++e) {
+      int i = H_TET_EDGES[e][0], j = H_TET_EDGES[e][1];
+      N[q][4 + e] = 4.0 * l[i] * l[j];
+      for (int k = 0; k < 3; ++k) dN[q][4 + e][k] = 4.0 * (l[i] * dL[j][k] + l[j] * dL[i][k]);
+    }
+  }
+  hipError_t e;
+  if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_qw), qw, sizeof(qw))) != hipSuccess) return e;
+  if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_N), N, sizeof(N))) != hipSuccess) return e;
+  if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_dN), dN, sizeof(dN))) != hipSuccess) return e;
+  return hipMemcpyToSymbol(HIP_SYMBOL(c_L), L, sizeof(L));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// geometry: per cell Jinv[k][j] = d xi_k / d x_j (9 doubles) and |det| (1 double)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_geometry(int64_t C, const double* __restrict__ coords, const int32_t* __restrict__ tet_vertices,
+                           double* __restrict__ geom) {
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int32_t* t = tet_vertices + 4 * c;
+  double x0[3], J[3][3];
+  for (int i = 0; i < 3; ++i) x0[i] = coords[3 * (int64_t)t[0] + i];
+  for (int k = 0; k < 3; ++k)
+    for (int i = 0; i < 3; ++i) J[i][k] = coords[3 * (int64_t)t[k + 1] + i] - x0[i];   // dx_i / dxi_k
+  double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+  double c01 = J[0][2] * J[2][1] - J[0][1] * J[2][2];
+  double c02 = J[0][1] * J[1][2] - J[0][2] * J[1][1];
+  double c10 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+  double c11 = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+  double c12 = J[0][2] * J[1][0] - J[0][0] * J[1][2];
+  double c20 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  double c21 = J[0][1] * J[2][0] - J[0][0] * J[2][1];
+  double c22 = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+  double det = J[0][0] * c00 + J[0][1] * c10 + J[0][2] * c20;
+  double r = 1.0 / det;
+  double* g = geom + 10 * c;
+  g[0] = c00 * r; g[1] = c01 * r; g[2] = c02 * r;
+  g[3] = c10 * r; g[4] = c11 * r; g[5] = c12 * r;
+  g[6] = c20 * r; g[7] = c21 * r; g[8] = c22 * r;
+  g[9] = fabs(det);
+}
+
+__device__ inline void load_props(const ElemParams& ep, int kind, int region, FluidProps& fp, SolidProps& sp) {
+  if (kind == 0) fp = ep.fluid[region];
+  else sp = ep.solid[region];
+}
+
+// Interpolate the local dofs (LDS, layout [d_x(10) d_y d_z v_x v_y v_z p(4)]) at quadrature point q.
+__device__ inline void interpolate(const double* __restrict__ sU, const double* __restrict__ Jinv, int q,
+                                   Kin<double>& s) {
+  for (int i = 0; i < 3; ++i) {
+    s.d[i] = 0.0; s.v[i] = 0.0;
+    for (int j = 0; j < 3; ++j) { s.gd[i][j] = 0.0; s.gv[i][j] = 0.0; }
+  }
+  s.p = 0.0;
+  for (int a = 0; a < 10; ++a) {
+    const double N = c_N[q][a];
+    const double r0 = c_dN[q][a][0], r1 = c_dN[q][a][1], r2 = c_dN[q][a][2];
+    double G[3];
+    for (int j = 0; j < 3; ++j) G[j] = r0 * Jinv[j] + r1 * Jinv[3 + j] + r2 * Jinv[6 + j];
+    for (int i = 0; i < 3; ++i) {
+      const double dv = sU[i * 10 + a], vv = sU[30 + i * 10 + a];
+      s.d[i] += N * dv;
+      s.v[i] += N * vv;
+      for (int j = 0; j < 3; ++j) { s.gd[i][j] += dv * G[j]; s.gv[i][j] += vv * G[j]; }
+    }
+  }
+  for (int a = 0; a < 4; ++a) s.p += c_L[q][a] * sU[60 + a];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// residual: F += sum over cells of the element vector (un-negated, no boundary conditions)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_residual(ElemArrays ea, ElemParams ep, const double* __restrict__ U,
+                                                 const double* __restrict__ U1, double* __restrict__ F) {
+  const int64_t c = blockIdx.x;
+  const int lane = threadIdx.x;
+  __shared__ double sU[NLOC], sU1[NLOC], sJ[10];
+  __shared__ double sS[NQ][25];
+  const int32_t dof = ea.cell_dofs[c * NLOC + lane];
+  sU[lane] = U[dof];
+  sU1[lane] = U1[dof];
+  if (lane < 10) sJ[lane] = ea.geom[c * 10 + lane];
+  __syncthreads();
+  const int kind = ea.cell_kind[c], region = ea.cell_region[c];
+  if (lane < NQ) {
+    const int q = lane;
+    Kin<double> s, o;
+    interpolate(sU, sJ, q, s);
+    interpolate(sU1, sJ, q, o);
+    Slots<double> out;
+    if (kind == 0) fluid_flux<double, PART_BOTH>(ep.fluid[region], ep.sc, s, o, out);
+    else solid_flux<double, PART_BOTH>(ep.solid[region], ep.sc, s, o, out);
+    const double w = sJ[9] * c_qw[q];
+    double* S = sS[q];
+    for (int i = 0; i < 3; ++i) {
+      S[i] = w * out.dval[i];
+      S[12 + i] = w * out.vval[i];
+      for (int k = 0; k < 3; ++k) {     // gradient slots pulled back to reference coordinates
+        S[3 + 3 * i + k] = w * (out.dgrd[i][0] * sJ[3 * k] + out.dgrd[i][1] * sJ[3 * k + 1] + out.dgrd[i][2] * sJ[3 * k + 2]);
+        S[15 + 3 * i + k] = w * (out.vgrd[i][0] * sJ[3 * k] + out.vgrd[i][1] * sJ[3 * k + 1] + out.vgrd[i][2] * sJ[3 * k + 2]);
+      }
+    }
+    S[24] = w * out.pval;
+  }
+  __syncthreads();
+  double r = 0.0;
+  if (lane < 60) {
+    const int fld = lane / 30, comp = (lane % 30) / 10, a = lane % 10;
+    const int vo = fld * 12 + comp, go = fld * 12 + 3 + 3 * comp;
+    for (int q = 0; q < NQ; ++q)
+      r += sS[q][vo] * c_N[q][a] + sS[q][go] * c_dN[q][a][0] + sS[q][go + 1] * c_dN[q][a][1] + sS[q][go + 2] * c_dN[q][a][2];
+  } else {
+    const int a = lane - 60;
+    for (int q = 0; q < NQ; ++q) r += sS[q][24] * c_L[q][a];
+  }
+  unsafeAtomicAdd(&F[dof], r);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Jacobian: vals += d(element vector)/d(local dofs), PART selects F_linear (A_pre) or F_nonlinear
+// ---------------------------------------------------------------------------------------------------------
+template <int PART>
+__global__ __launch_bounds__(64) void k_jacobian(ElemArrays ea, ElemParams ep, const double* __restrict__ U,
+                                                 const double* __restrict__ U1, const int64_t* __restrict__ rowptr,
+                                                 const int64_t* __restrict__ nadj_ptr, double* __restrict__ vals) {
+  const int64_t c = blockIdx.x;
+  const int lane = threadIdx.x;
+  __shared__ double sU[NLOC], sU1[NLOC], sJ[10];
+  __shared__ double sG[NQ][10][3];       // physical gradients of the P2 basis at the quadrature points
+  __shared__ double sB[NQ][25];          // base state at n: gd(9) gv(9) d(3) v(3) p
+  __shared__ double sO[NQ][25];          // state at n-1
+  __shared__ int64_t sRow[NLOC];
+  __shared__ int32_t sDeg6[10];
+  const int32_t dof = ea.cell_dofs[c * NLOC + lane];
+  sU[lane] = U[dof];
+  sU1[lane] = U1[dof];
+  sRow[lane] = rowptr[dof];
+  if (lane < 10) {
+    sJ[lane] = ea.geom[c * 10 + lane];
+    const int32_t rk = ea.cell_rank[c * 10 + lane];
+    sDeg6[lane] = 6 * (int32_t)(nadj_ptr[rk + 1] - nadj_ptr[rk]);
+  }
+  __syncthreads();
+  for (int t = lane; t < NQ * 10; t += 64) {
+    const int q = t / 10, a = t % 10;
+    for (int j = 0; j < 3; ++j)
+      sG[q][a][j] = c_dN[q][a][0] * sJ[j] + c_dN[q][a][1] * sJ[3 + j] + c_dN[q][a][2] * sJ[6 + j];
+  }
+  if (lane < NQ) {
+    Kin<double> s, o;
+    interpolate(sU, sJ, lane, s);
+    interpolate(sU1, sJ, lane, o);
+    double* B = sB[lane];
+    double* O = sO[lane];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        B[3 * i + j] = s.gd[i][j]; B[9 + 3 * i + j] = s.gv[i][j];
+        O[3 * i + j] = o.gd[i][j]; O[9 + 3 * i + j] = o.gv[i][j];
+      }
+    for (int i = 0; i < 3; ++i) { B[18 + i] = s.d[i]; B[21 + i] = s.v[i]; O[18 + i] = o.d[i]; O[21 + i] = o.v[i]; }
+    B[24] = s.p; O[24] = o.p;
+  }
+  __syncthreads();
+  const int kind = ea.cell_kind[c], region = ea.cell_region[c];
+  // trial dof of this lane
+  const int jf = lane < 60 ? lane / 30 : 2;          // 0 d, 1 v, 2 p
+  const int jc = lane < 60 ? (lane % 30) / 10 : 0;
+  const int jb = lane < 60 ? lane % 10 : lane - 60;
+  double acc[NLOC];
+#pragma unroll
+  for (int i = 0; i < NLOC; ++i) acc[i] = 0.0;
+  for (int q = 0; q < NQ; ++q) {
+    Kin<Dual> s;
+    Kin<double> o;
+    const double* B = sB[q];
+    const double* O = sO[q];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        s.gd[i][j] = Dual(B[3 * i + j], (jf == 0 && jc == i) ? sG[q][jb][j] : 0.0);
+        s.gv[i][j] = Dual(B[9 + 3 * i + j], (jf == 1 && jc == i) ? sG[q][jb][j] : 0.0);
+        o.gd[i][j] = O[3 * i + j];
+        o.gv[i][j] = O[9 + 3 * i + j];
+      }
+    for (int i = 0; i < 3; ++i) {
+      s.d[i] = Dual(B[18 + i], (jf == 0 && jc == i) ? c_N[q][jb] : 0.0);
+      s.v[i] = Dual(B[21 + i], (jf == 1 && jc == i) ? c_N[q][jb] : 0.0);
+      o.d[i] = O[18 + i];
+      o.v[i] = O[21 + i];
+    }
+    s.p = Dual(B[24], jf == 2 ? c_L[q][jb] : 0.0);
+    o.p = O[24];
+    Slots<Dual> out;
+    if (kind == 0) fluid_flux<Dual, PART>(ep.fluid[region], ep.sc, s, o, out);
+    else solid_flux<Dual, PART>(ep.solid[region], ep.sc, s, o, out);
+    const double w = sJ[9] * c_qw[q];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double dv = w * out.dval[i].e, vv = w * out.vval[i].e;
+      const double d0 = w * out.dgrd[i][0].e, d1 = w * out.dgrd[i][1].e, d2 = w * out.dgrd[i][2].e;
+      const double v0 = w * out.vgrd[i][0].e, v1 = w * out.vgrd[i][1].e, v2 = w * out.vgrd[i][2].e;
+#pragma unroll
+      for (int a = 0; a < 10; ++a) {
+        const double N = c_N[q][a], g0 = sG[q][a][0], g1 = sG[q][a][1], g2 = sG[q][a][2];
+        acc[i * 10 + a] += dv * N + d0 * g0 + d1 * g1 + d2 * g2;
+        acc[30 + i * 10 + a] += vv * N + v0 * g0 + v1 * g1 + v2 * g2;
+      }
+    }
+    const double pv = w * out.pval.e;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[60 + a] += pv * c_L[q][a];
+  }
+  // scatter column `lane` of the element matrix
+  const uint16_t* nb = ea.enbr + c * 100;
+  const uint16_t* pb = ea.epnbr + c * 40;
+#pragma unroll
+  for (int i = 0; i < NLOC; ++i) {
+    const int ra = i < 60 ? i % 10 : i - 60;
+    int64_t pos;
+    if (jf < 2) pos = sRow[i] + 6 * (int64_t)nb[ra * 10 + jb] + 3 * jf + jc;
+    else pos = sRow[i] + sDeg6[ra] + pb[ra * 4 + jb];
+    if (acc[i] != 0.0) unsafeAtomicAdd(&vals[pos], acc[i]);
+  }
+}
+
+template __global__ void k_jacobian<PART_LINEAR>(ElemArrays, ElemParams, const double*, const double*, const int64_t*,
+                                                 const int64_t*, double*);
+template __global__ void k_jacobian<PART_NONLINEAR>(ElemArrays, ElemParams, const double*, const double*,
+                                                    const int64_t*, const int64_t*, double*);
+
+void launch_geometry(hipStream_t st, int64_t C, const double* coords, const int32_t* tet_vertices, double* geom) {
+  const int bs = 256;
+  hipLaunchKernelGGL(k_geometry, dim3((unsigned)((C + bs - 1) / bs)), dim3(bs), 0, st, C, coords, tet_vertices, geom);
+}
+void launch_residual(hipStream_t st, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
+                     const double* U1, double* F) {
+  hipLaunchKernelGGL(k_residual, dim3((unsigned)C), dim3(64), 0, st, ea, ep, U, U1, F);
+}
+void launch_jacobian(hipStream_t st, int part, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
+                     const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals) {
+  if (part == PART_LINEAR)
+    hipLaunchKernelGGL(k_jacobian<PART_LINEAR>, dim3((unsigned)C), dim3(64), 0, st, ea, ep, U, U1, rowptr, nadj_ptr, vals);
+  else
+    hipLaunchKernelGGL(k_jacobian<PART_NONLINEAR>, dim3((unsigned)C), dim3(64), 0, st, ea, ep, U, U1, rowptr, nadj_ptr, vals);
+}
+
+}  // namespace fsi

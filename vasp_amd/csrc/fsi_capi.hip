@@ -1,0 +1,836 @@
+// C-ABI of libvaspfsi.so (include/vaspfsi.h): problem set-up, Newton driver, Krylov methods.
+//
+// Host-side logic follows turtleFSI's monolithic.py / newtonsolver.py as VaSP uses them; the
+// arithmetic runs in the HIP kernels of fsi_assembly.hip / fsi_solver.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+#include "fsi_kernels.hpp"
+
+using namespace fsi;
+
+#define HIPCHK(call)                                                                               \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                                \
+      return FSI_ERR_DEVICE;                                                                       \
+    }                                                                                              \
+  } while (0)
+#define FSICHK(call)                 \
+  do {                               \
+    int r_ = (call);                 \
+    if (r_ != FSI_OK) return r_;     \
+  } while (0)
+
+namespace {
+
+const int TET_EDGES[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
+
+struct Phase {   // HIP-event bracket on the solver stream (each timer owns its pair of events: phases nest)
+  FsiCtx* c;
+  PhaseTimer* t;
+  Phase(FsiCtx* ctx, PhaseTimer* tm) : c(ctx), t(tm) {
+    if (!t->e0) { (void)hipEventCreate(&t->e0); (void)hipEventCreate(&t->e1); }
+    (void)hipEventRecord(t->e0, c->stream);
+  }
+  ~Phase() {
+    (void)hipEventRecord(t->e1, c->stream);
+    (void)hipEventSynchronize(t->e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, t->e0, t->e1);
+    t->ms += ms;
+    t->calls += 1;
+  }
+};
+
+template <class T>
+int upload(FsiCtx* ctx, DevBuf<T>& buf, const std::vector<T>& h) {
+  HIPCHK(buf.alloc(h.size()));
+  if (!h.empty()) HIPCHK(hipMemcpy(buf.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return FSI_OK;
+}
+
+ElemArrays elem_arrays(FsiCtx* c) {
+  return ElemArrays{c->geom.p, c->cell_dofs.p, c->cell_kind.p, c->cell_region.p, c->cell_rank.p, c->enbr.p, c->epnbr.p};
+}
+ElemParams elem_params(FsiCtx* c) {
+  ElemParams ep;
+  ep.sc = c->scheme;
+  for (int i = 0; i < MAX_REGIONS; ++i) { ep.fluid[i] = c->fluid[i]; ep.solid[i] = c->solid[i]; }
+  return ep;
+}
+
+int host_scalar(FsiCtx* ctx, const double* dptr, double* out) {
+  HIPCHK(hipMemcpyAsync(out, dptr, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return FSI_OK;
+}
+int dot(FsiCtx* ctx, const double* x, const double* y, double* out) {
+  launch_dot(ctx->stream, x, y, ctx->ndof, ctx->scratch.p, ctx->scratch.p + 4096);
+  return host_scalar(ctx, ctx->scratch.p + 4096, out);
+}
+int norm2(FsiCtx* ctx, const double* x, double* out) {
+  FSICHK(dot(ctx, x, x, out));
+  *out = std::sqrt(*out);
+  return FSI_OK;
+}
+
+int precondition(FsiCtx* ctx, const double* r, double* z) {
+  Phase ph(ctx, &ctx->t_prec);
+  launch_sptrsv_levels(ctx->stream, ctx->levels, ctx->rowptr.p, ctx->cols.p, ctx->diagpos.p, ctx->LU.p, r, ctx->tmp7.p, z);
+  return FSI_OK;
+}
+int spmv(FsiCtx* ctx, const double* x, double* y) {
+  Phase ph(ctx, &ctx->t_spmv);
+  launch_spmv(ctx->stream, ctx->ndof, ctx->rowptr.p, ctx->cols.p, ctx->A.p, x, y);
+  return FSI_OK;
+}
+
+// ---- GCR with directions kept across solves while the matrix is unchanged ----------------------------------
+// (right-preconditioned; Q = A P orthonormal; x = P (Q^T b) + new directions)
+int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it, int* iters, double* relres) {
+  const int64_t n = ctx->ndof;
+  hipStream_t st = ctx->stream;
+  double* r = ctx->tmp1.p;
+  double* z = ctx->tmp2.p;
+  double* w = ctx->tmp3.p;
+  launch_copy(st, r, rhs, n);
+  launch_fill(st, x, n, 0.0);
+  double bnorm = 0.0, rnorm = 0.0;
+  FSICHK(norm2(ctx, r, &bnorm));
+  *iters = 0;
+  if (bnorm == 0.0) { *relres = 0.0; return FSI_OK; }
+  if (!std::isfinite(bnorm)) { ctx->err = "non-finite right-hand side"; return FSI_ERR_LINEAR; }
+  int m = (int)std::min<int64_t>(ctx->kry_m, ctx->kry_cap);
+  if (m > 0) {   // projection on the recycled space
+    Phase ph(ctx, &ctx->t_ortho);
+    launch_multi_dot(st, ctx->KQ.p, n, m, r, ctx->scratch.p, ctx->hcoef.p);
+    launch_multi_axpy(st, ctx->KP.p, n, m, ctx->hcoef.p, +1.0, x);
+    launch_multi_axpy(st, ctx->KQ.p, n, m, ctx->hcoef.p, -1.0, r);
+  }
+  FSICHK(norm2(ctx, r, &rnorm));
+  while (rnorm > rtol * bnorm && *iters < max_it) {
+    FSICHK(precondition(ctx, r, z));
+    FSICHK(spmv(ctx, z, w));
+    m = (int)std::min<int64_t>(ctx->kry_m, ctx->kry_cap);
+    if (m > 0) {
+      Phase ph(ctx, &ctx->t_ortho);
+      for (int pass = 0; pass < 2; ++pass) {   // classical Gram-Schmidt, twice
+        launch_multi_dot(st, ctx->KQ.p, n, m, w, ctx->scratch.p, ctx->hcoef.p);
+        launch_multi_axpy(st, ctx->KQ.p, n, m, ctx->hcoef.p, -1.0, w);
+        launch_multi_axpy(st, ctx->KP.p, n, m, ctx->hcoef.p, -1.0, z);
+      }
+    }
+    double wn = 0.0;
+    FSICHK(norm2(ctx, w, &wn));
+    if (!(wn > 0.0) || !std::isfinite(wn)) { ctx->err = "GCR breakdown (A M^-1 r vanished or is not finite)"; return FSI_ERR_LINEAR; }
+    launch_scale(st, w, 1.0 / wn, n);
+    launch_scale(st, z, 1.0 / wn, n);
+    const int slot = (int)(ctx->kry_m % ctx->kry_cap);   // space full: overwrite the oldest direction
+    launch_copy(st, ctx->KP.p + (int64_t)slot * n, z, n);
+    launch_copy(st, ctx->KQ.p + (int64_t)slot * n, w, n);
+    ctx->kry_m += 1;
+    double alpha = 0.0;
+    FSICHK(dot(ctx, w, r, &alpha));
+    launch_axpy(st, x, alpha, z, n);
+    launch_axpy(st, r, -alpha, w, n);
+    FSICHK(norm2(ctx, r, &rnorm));
+    *iters += 1;
+    ctx->kry_iters += 1;
+  }
+  *relres = rnorm / bnorm;
+  if (!(rnorm <= rtol * bnorm)) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "GCR: no convergence in %d iterations (relres %.3e, tol %.1e)", *iters, *relres, rtol);
+    ctx->err = buf;
+    return FSI_ERR_LINEAR;
+  }
+  return FSI_OK;
+}
+
+// ---- BiCGStab, right-preconditioned ---------------------------------------------------------------------------
+int solve_bicgstab(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it, int* iters, double* relres) {
+  const int64_t n = ctx->ndof;
+  hipStream_t st = ctx->stream;
+  double *r = ctx->tmp1.p, *r0 = ctx->tmp2.p, *p = ctx->tmp3.p, *v = ctx->tmp4.p, *s = ctx->tmp5.p, *t = ctx->tmp6.p;
+  double *ph = ctx->bs.p;   // preconditioned vector (bs is free once rhs was copied)
+  launch_copy(st, r, rhs, n);
+  launch_copy(st, r0, rhs, n);
+  launch_fill(st, x, n, 0.0);
+  launch_fill(st, p, n, 0.0);
+  launch_fill(st, v, n, 0.0);
+  double bnorm = 0.0, rnorm = 0.0;
+  FSICHK(norm2(ctx, r, &bnorm));
+  *iters = 0;
+  if (bnorm == 0.0) { *relres = 0.0; return FSI_OK; }
+  rnorm = bnorm;
+  double rho = 1.0, alpha = 1.0, omega = 1.0;
+  while (rnorm > rtol * bnorm && *iters < max_it) {
+    double rho1 = 0.0;
+    FSICHK(dot(ctx, r0, r, &rho1));
+    if (rho1 == 0.0 || !std::isfinite(rho1)) { ctx->err = "BiCGStab breakdown (rho = 0)"; return FSI_ERR_LINEAR; }
+    const double beta = (rho1 / rho) * (alpha / omega);
+    launch_axpy(st, p, -omega, v, n);             // p = r + beta (p - omega v)
+    launch_axpby(st, p, 1.0, r, beta, p, n);
+    FSICHK(precondition(ctx, p, ph));
+    FSICHK(spmv(ctx, ph, v));
+    double r0v = 0.0;
+    FSICHK(dot(ctx, r0, v, &r0v));
+    if (r0v == 0.0 || !std::isfinite(r0v)) { ctx->err = "BiCGStab breakdown (r0.v = 0)"; return FSI_ERR_LINEAR; }
+    alpha = rho1 / r0v;
+    launch_axpby(st, s, 1.0, r, -alpha, v, n);
+    launch_axpy(st, x, alpha, ph, n);
+    FSICHK(precondition(ctx, s, ph));
+    FSICHK(spmv(ctx, ph, t));
+    double ts = 0.0, tt = 0.0;
+    FSICHK(dot(ctx, t, s, &ts));
+    FSICHK(dot(ctx, t, t, &tt));
+    omega = tt > 0.0 ? ts / tt : 0.0;
+    launch_axpy(st, x, omega, ph, n);
+    launch_axpby(st, r, 1.0, s, -omega, t, n);
+    FSICHK(norm2(ctx, r, &rnorm));
+    rho = rho1;
+    *iters += 1;
+    ctx->kry_iters += 1;
+    if (omega == 0.0 && rnorm > rtol * bnorm) { ctx->err = "BiCGStab breakdown (omega = 0)"; return FSI_ERR_LINEAR; }
+    if (!std::isfinite(rnorm)) { ctx->err = "BiCGStab diverged"; return FSI_ERR_LINEAR; }
+  }
+  *relres = rnorm / bnorm;
+  if (!(rnorm <= rtol * bnorm)) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "BiCGStab: no convergence in %d iterations (relres %.3e, tol %.1e)", *iters, *relres, rtol);
+    ctx->err = buf;
+    return FSI_ERR_LINEAR;
+  }
+  return FSI_OK;
+}
+
+}  // namespace
+
+// =========================================================================================================
+extern "C" {
+
+const char* fsi_last_error(const FsiCtx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int64_t fsi_num_dofs(const FsiCtx* ctx) { return ctx ? ctx->ndof : 0; }
+int64_t fsi_matrix_nnz(const FsiCtx* ctx) { return ctx ? ctx->nnz : 0; }
+
+int fsi_destroy(FsiCtx* ctx) {
+  if (!ctx) return FSI_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  DevBuf<double>* dbl[] = {&ctx->geom, &ctx->A_pre, &ctx->A, &ctx->LU, &ctx->rowscale, &ctx->U, &ctx->U1, &ctx->F, &ctx->b,
+                           &ctx->du, &ctx->bs, &ctx->tmp1, &ctx->tmp2, &ctx->tmp3, &ctx->tmp4, &ctx->tmp5, &ctx->tmp6,
+                           &ctx->tmp7, &ctx->scratch, &ctx->bc_vals, &ctx->pf_coef, &ctx->rb_val, &ctx->KP, &ctx->KQ,
+                           &ctx->hcoef};
+  for (auto* b : dbl) b->release();
+  DevBuf<int32_t>* i32[] = {&ctx->user2solver, &ctx->solver2user, &ctx->cell_dofs, &ctx->cell_kind, &ctx->cell_region,
+                            &ctx->cell_rank, &ctx->nadj, &ctx->padj, &ctx->cols, &ctx->iflags, &ctx->bc_dofs,
+                            &ctx->pf_dofs, &ctx->rb_row, &ctx->rb_col};
+  for (auto* b : i32) b->release();
+  DevBuf<int64_t>* i64[] = {&ctx->nadj_ptr, &ctx->padj_ptr, &ctx->rowptr, &ctx->diagpos, &ctx->rb_pos};
+  for (auto* b : i64) b->release();
+  ctx->enbr.release();
+  ctx->epnbr.release();
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return FSI_OK;
+}
+
+int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx** out) {
+  if (!mesh || !prm || !out) return FSI_ERR_INVALID;
+  *out = nullptr;
+  FsiCtx* ctx = new FsiCtx();
+  *out = ctx;   // returned even on failure so that fsi_last_error() can be read; caller destroys it
+  ctx->device = device;
+  const int64_t V = mesh->num_vertices, N2 = mesh->num_nodes, C = mesh->num_cells;
+  if (V <= 0 || N2 < V || C <= 0 || !mesh->coords || !mesh->tet_nodes || !mesh->cell_kind || !mesh->cell_region) {
+    ctx->err = "fsi_create: empty or inconsistent mesh description";
+    return FSI_ERR_INVALID;
+  }
+  if (prm->num_fluid_regions > MAX_REGIONS || prm->num_solid_regions > MAX_REGIONS || !(prm->dt > 0.0)) {
+    ctx->err = "fsi_create: bad parameters (dt <= 0 or too many regions)";
+    return FSI_ERR_INVALID;
+  }
+  if (6 * N2 + V >= (int64_t)2147483647) { ctx->err = "fsi_create: more than 2^31 dofs"; return FSI_ERR_INVALID; }
+  for (int64_t c = 0; c < C; ++c) {
+    const int kind = mesh->cell_kind[c], reg = mesh->cell_region[c];
+    if (kind < 0 || kind > 1 || reg < 0 || reg >= (kind == 0 ? prm->num_fluid_regions : prm->num_solid_regions)) {
+      ctx->err = "fsi_create: cell with a bad kind/region marker";
+      return FSI_ERR_INVALID;
+    }
+    for (int a = 0; a < 10; ++a) {
+      const int32_t nd = mesh->tet_nodes[10 * c + a];
+      if (nd < 0 || nd >= N2 || (a < 4 && nd >= V)) { ctx->err = "fsi_create: node id out of range"; return FSI_ERR_INVALID; }
+    }
+  }
+  for (int r = 0; r < prm->num_solid_regions; ++r)
+    if (prm->solid_models && prm->solid_models[r] != 0) { ctx->err = "fsi_create: only StVenantKirchoff (0) is implemented"; return FSI_ERR_INVALID; }
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) { ctx->err = "fsi_create: no such HIP device"; return FSI_ERR_DEVICE; }
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipStreamCreate(&ctx->stream));
+  HIPCHK(hipEventCreate(&ctx->ev0));
+  HIPCHK(hipEventCreate(&ctx->ev1));
+  HIPCHK(upload_tables());
+
+  ctx->V = V; ctx->N2 = N2; ctx->C = C; ctx->ndof = 6 * N2 + V;
+  ctx->scheme = Scheme{prm->dt, prm->theta, 1.0 - prm->theta, prm->delta, prm->laplace_alpha};
+  ctx->nfluid = prm->num_fluid_regions;
+  ctx->nsolid = prm->num_solid_regions;
+  for (int r = 0; r < MAX_REGIONS; ++r) { ctx->fluid[r] = FluidProps{1.0, 1.0}; ctx->solid[r] = SolidProps{1.0, 1.0, 1.0}; }
+  for (int r = 0; r < ctx->nfluid; ++r) ctx->fluid[r] = FluidProps{prm->fluid_props[2 * r], prm->fluid_props[2 * r + 1]};
+  for (int r = 0; r < ctx->nsolid; ++r)
+    ctx->solid[r] = SolidProps{prm->solid_props[3 * r], prm->solid_props[3 * r + 1], prm->solid_props[3 * r + 2]};
+  ctx->h_coords.assign(mesh->coords, mesh->coords + 3 * V);
+  ctx->h_tet_nodes.assign(mesh->tet_nodes, mesh->tet_nodes + 10 * C);
+  const int32_t* tn = ctx->h_tet_nodes.data();
+
+  // ---- base ordering: every vertex followed by the edge nodes it owns (= edges whose lower vertex it is) ------
+  std::vector<int32_t> owner(N2, -1), other(N2, 0);
+  for (int32_t v = 0; v < V; ++v) owner[v] = v;
+  for (int64_t c = 0; c < C; ++c)
+    for (int e = 0; e < 6; ++e) {
+      const int32_t a = tn[10 * c + TET_EDGES[e][0]], b = tn[10 * c + TET_EDGES[e][1]], nd = tn[10 * c + 4 + e];
+      owner[nd] = std::min(a, b);
+      other[nd] = std::max(a, b);
+    }
+  for (int64_t i = 0; i < N2; ++i)
+    if (owner[i] < 0) { ctx->err = "fsi_create: P2 node that belongs to no cell"; return FSI_ERR_INVALID; }
+  std::vector<int32_t> base(N2), base_rank(N2);
+  std::iota(base.begin(), base.end(), 0);
+  std::sort(base.begin(), base.end(), [&](int32_t x, int32_t y) {
+    if (owner[x] != owner[y]) return owner[x] < owner[y];
+    const bool ex = x >= V, ey = y >= V;
+    if (ex != ey) return !ex;
+    if (other[x] != other[y]) return other[x] < other[y];
+    return x < y;
+  });
+  for (int64_t r = 0; r < N2; ++r) base_rank[base[r]] = (int32_t)r;
+
+  // ---- node graph (node ids), sorted unique pairs ---------------------------------------------------------------
+  std::vector<uint64_t> pairs;
+  pairs.reserve((size_t)C * 100);
+  for (int64_t c = 0; c < C; ++c)
+    for (int a = 0; a < 10; ++a)
+      for (int b = 0; b < 10; ++b)
+        pairs.push_back(((uint64_t)(uint32_t)tn[10 * c + a] << 32) | (uint32_t)tn[10 * c + b]);
+  std::sort(pairs.begin(), pairs.end());
+  pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());
+  std::vector<int64_t> gptr(N2 + 1, 0);
+  std::vector<int32_t> gadj(pairs.size());
+  for (size_t i = 0; i < pairs.size(); ++i) {
+    gptr[(pairs[i] >> 32) + 1] += 1;
+    gadj[i] = (int32_t)(pairs[i] & 0xffffffffu);
+  }
+  for (int64_t r = 0; r < N2; ++r) gptr[r + 1] += gptr[r];
+  std::vector<uint64_t>().swap(pairs);
+
+  // ---- greedy multicolouring of the node graph (base order): nodes of one colour share no element -----------------
+  std::vector<int32_t> color(N2, -1);
+  {
+    std::vector<int32_t> mark(1024, -1);
+    for (int64_t r = 0; r < N2; ++r) {
+      const int32_t nd = base[r];
+      for (int64_t k = gptr[nd]; k < gptr[nd + 1]; ++k) {
+        const int32_t c = color[gadj[k]];
+        if (c >= 0) {
+          if ((size_t)c >= mark.size()) mark.resize(2 * c + 2, -1);
+          mark[c] = nd;
+        }
+      }
+      int32_t c = 0;
+      while ((size_t)c < mark.size() && mark[c] == nd) ++c;
+      if ((size_t)c >= mark.size()) mark.resize(2 * c + 2, -1);
+      color[nd] = c;
+      ctx->ncolors = std::max(ctx->ncolors, c + 1);
+    }
+  }
+  ctx->h_rank2node = base;
+  std::stable_sort(ctx->h_rank2node.begin(), ctx->h_rank2node.end(), [&](int32_t x, int32_t y) { return color[x] < color[y]; });
+  ctx->h_node2rank.resize(N2);
+  for (int64_t r = 0; r < N2; ++r) ctx->h_node2rank[ctx->h_rank2node[r]] = (int32_t)r;
+  const std::vector<int32_t>& rk = ctx->h_node2rank;
+  // pressure block: vertices in the same (colour, base) order
+  ctx->h_prank.assign(V, 0);
+  std::vector<int32_t> prow_rank(V);
+  {
+    int32_t q = 0;
+    for (int64_t r = 0; r < N2; ++r) {
+      const int32_t nd = ctx->h_rank2node[r];
+      if (nd < V) { ctx->h_prank[nd] = q; prow_rank[q] = (int32_t)r; ++q; }
+    }
+  }
+  // levels: one per colour for the d/v rows (6 rows per node), then one per colour for the pressure rows
+  {
+    std::vector<int64_t> ncount(ctx->ncolors, 0), vcount(ctx->ncolors, 0);
+    for (int64_t nd = 0; nd < N2; ++nd) { ncount[color[nd]] += 1; if (nd < V) vcount[color[nd]] += 1; }
+    int64_t r0 = 0;
+    for (int c = 0; c < ctx->ncolors; ++c) { ctx->levels.push_back(Level{6 * r0, ncount[c], 6}); r0 += ncount[c]; }
+    int64_t q0 = 0;
+    for (int c = 0; c < ctx->ncolors; ++c) { ctx->levels.push_back(Level{6 * N2 + q0, vcount[c], 1}); q0 += vcount[c]; }
+  }
+  // adjacency in final ranks (ascending) and pressure neighbours as positions in the pressure block (ascending)
+  ctx->h_nadj_ptr.assign(N2 + 1, 0);
+  ctx->h_nadj.resize(gadj.size());
+  ctx->h_padj_ptr.assign(N2 + 1, 0);
+  ctx->h_padj.clear();
+  {
+    int64_t o = 0;
+    std::vector<int32_t> tmpv;
+    for (int64_t r = 0; r < N2; ++r) {
+      const int32_t nd = ctx->h_rank2node[r];
+      const int64_t o0 = o;
+      tmpv.clear();
+      for (int64_t k = gptr[nd]; k < gptr[nd + 1]; ++k) {
+        ctx->h_nadj[o++] = rk[gadj[k]];
+        if (gadj[k] < V) tmpv.push_back(ctx->h_prank[gadj[k]]);
+      }
+      std::sort(ctx->h_nadj.begin() + o0, ctx->h_nadj.begin() + o);
+      std::sort(tmpv.begin(), tmpv.end());
+      ctx->h_padj.insert(ctx->h_padj.end(), tmpv.begin(), tmpv.end());
+      ctx->h_nadj_ptr[r + 1] = o;
+      ctx->h_padj_ptr[r + 1] = (int64_t)ctx->h_padj.size();
+    }
+  }
+  std::vector<int64_t>().swap(gptr);
+  std::vector<int32_t>().swap(gadj);
+  for (int64_t r = 0; r < N2; ++r) {
+    const int64_t deg = ctx->h_nadj_ptr[r + 1] - ctx->h_nadj_ptr[r];
+    if (deg >= 65536 / 6 || 6 * deg + (ctx->h_padj_ptr[r + 1] - ctx->h_padj_ptr[r]) > 1024) {
+      ctx->err = "fsi_create: node with too many neighbours for the row buffers (max 1024 entries per row)";
+      return FSI_ERR_INVALID;
+    }
+  }
+
+  // ---- CSR row pointers ------------------------------------------------------------------------------------
+  std::vector<int64_t> rowptr(ctx->ndof + 1, 0);
+  for (int64_t r = 0; r < N2; ++r) {
+    const int64_t len = 6 * (ctx->h_nadj_ptr[r + 1] - ctx->h_nadj_ptr[r]) + (ctx->h_padj_ptr[r + 1] - ctx->h_padj_ptr[r]);
+    for (int t = 0; t < 6; ++t) rowptr[6 * r + t + 1] = len;
+  }
+  for (int64_t q = 0; q < V; ++q) {
+    const int32_t r = prow_rank[q];
+    rowptr[6 * N2 + q + 1] = 6 * (ctx->h_nadj_ptr[r + 1] - ctx->h_nadj_ptr[r]) + (ctx->h_padj_ptr[r + 1] - ctx->h_padj_ptr[r]);
+  }
+  for (int64_t i = 0; i < ctx->ndof; ++i) rowptr[i + 1] += rowptr[i];
+  ctx->nnz = rowptr[ctx->ndof];
+
+  // ---- element tables --------------------------------------------------------------------------------------
+  std::vector<int32_t> cell_dofs((size_t)C * NLOC), cell_rank((size_t)C * 10), tet_vertices((size_t)C * 4);
+  std::vector<uint16_t> enbr((size_t)C * 100), epnbr((size_t)C * 40);
+  for (int64_t c = 0; c < C; ++c) {
+    for (int a = 0; a < 10; ++a) {
+      const int32_t ra = rk[tn[10 * c + a]];
+      cell_rank[10 * c + a] = ra;
+      for (int cmp = 0; cmp < 3; ++cmp) {
+        cell_dofs[c * NLOC + cmp * 10 + a] = 6 * ra + cmp;
+        cell_dofs[c * NLOC + 30 + cmp * 10 + a] = 6 * ra + 3 + cmp;
+      }
+      const int32_t* lo = ctx->h_nadj.data() + ctx->h_nadj_ptr[ra];
+      const int32_t* hi = ctx->h_nadj.data() + ctx->h_nadj_ptr[ra + 1];
+      for (int b = 0; b < 10; ++b)
+        enbr[c * 100 + a * 10 + b] = (uint16_t)(std::lower_bound(lo, hi, rk[tn[10 * c + b]]) - lo);
+      const int32_t* plo = ctx->h_padj.data() + ctx->h_padj_ptr[ra];
+      const int32_t* phi = ctx->h_padj.data() + ctx->h_padj_ptr[ra + 1];
+      for (int b = 0; b < 4; ++b)
+        epnbr[c * 40 + a * 4 + b] = (uint16_t)(std::lower_bound(plo, phi, ctx->h_prank[tn[10 * c + b]]) - plo);
+    }
+    for (int a = 0; a < 4; ++a) {
+      cell_dofs[c * NLOC + 60 + a] = (int32_t)(6 * N2 + ctx->h_prank[tn[10 * c + a]]);
+      tet_vertices[4 * c + a] = tn[10 * c + a];
+    }
+  }
+  ctx->h_user2solver.resize(ctx->ndof);
+  std::vector<int32_t> solver2user(ctx->ndof);
+  for (int64_t nd = 0; nd < N2; ++nd)
+    for (int cmp = 0; cmp < 3; ++cmp) {
+      ctx->h_user2solver[3 * nd + cmp] = 6 * rk[nd] + cmp;
+      ctx->h_user2solver[3 * N2 + 3 * nd + cmp] = 6 * rk[nd] + 3 + cmp;
+    }
+  for (int64_t v = 0; v < V; ++v) ctx->h_user2solver[6 * N2 + v] = (int32_t)(6 * N2 + ctx->h_prank[v]);
+  for (int64_t i = 0; i < ctx->ndof; ++i) solver2user[ctx->h_user2solver[i]] = (int32_t)i;
+
+  // ---- upload ------------------------------------------------------------------------------------------------
+  FSICHK(upload(ctx, ctx->user2solver, ctx->h_user2solver));
+  FSICHK(upload(ctx, ctx->solver2user, solver2user));
+  FSICHK(upload(ctx, ctx->cell_dofs, cell_dofs));
+  FSICHK(upload(ctx, ctx->cell_rank, cell_rank));
+  FSICHK(upload(ctx, ctx->enbr, enbr));
+  FSICHK(upload(ctx, ctx->epnbr, epnbr));
+  FSICHK(upload(ctx, ctx->cell_kind, std::vector<int32_t>(mesh->cell_kind, mesh->cell_kind + C)));
+  FSICHK(upload(ctx, ctx->cell_region, std::vector<int32_t>(mesh->cell_region, mesh->cell_region + C)));
+  FSICHK(upload(ctx, ctx->nadj_ptr, ctx->h_nadj_ptr));
+  FSICHK(upload(ctx, ctx->nadj, ctx->h_nadj));
+  FSICHK(upload(ctx, ctx->padj_ptr, ctx->h_padj_ptr));
+  FSICHK(upload(ctx, ctx->padj, ctx->h_padj));
+  FSICHK(upload(ctx, ctx->rowptr, rowptr));
+  HIPCHK(ctx->cols.alloc(ctx->nnz));
+  HIPCHK(ctx->diagpos.alloc(ctx->ndof));
+  {
+    DevBuf<int32_t> d_vrank, d_tv;
+    DevBuf<double> d_coords;
+    FSICHK(upload(ctx, d_vrank, prow_rank));
+    FSICHK(upload(ctx, d_tv, tet_vertices));
+    FSICHK(upload(ctx, d_coords, ctx->h_coords));
+    HIPCHK(ctx->geom.alloc((size_t)C * 10));
+    launch_expand_cols(ctx->stream, N2, V, ctx->nadj_ptr.p, ctx->nadj.p, ctx->padj_ptr.p, ctx->padj.p, d_vrank.p,
+                       ctx->rowptr.p, ctx->cols.p, ctx->diagpos.p);
+    launch_geometry(ctx->stream, C, d_coords.p, d_tv.p, ctx->geom.p);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    d_vrank.release(); d_tv.release(); d_coords.release();
+  }
+  const int64_t n = ctx->ndof;
+  DevBuf<double>* vecs[] = {&ctx->U, &ctx->U1, &ctx->F, &ctx->b, &ctx->du, &ctx->bs, &ctx->tmp1, &ctx->tmp2, &ctx->tmp3,
+                            &ctx->tmp4, &ctx->tmp5, &ctx->tmp6, &ctx->tmp7, &ctx->rowscale};
+  for (auto* v : vecs) {
+    HIPCHK(v->alloc(n));
+    HIPCHK(hipMemsetAsync(v->p, 0, n * sizeof(double), ctx->stream));
+  }
+  HIPCHK(ctx->A_pre.alloc(ctx->nnz));
+  HIPCHK(ctx->A.alloc(ctx->nnz));
+  HIPCHK(ctx->LU.alloc(ctx->nnz));
+  HIPCHK(hipMemsetAsync(ctx->A_pre.p, 0, ctx->nnz * sizeof(double), ctx->stream));
+  HIPCHK(ctx->iflags.alloc(n + 16));
+  // Krylov space: sized from free memory (the recycled directions are what 288 GB of HBM are used for)
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  int64_t cap = (int64_t)((double)free_b * 0.5 / (16.0 * (double)n));
+  cap = std::max<int64_t>(8, std::min<int64_t>(cap, 1000));
+  ctx->kry_cap = cap;
+  HIPCHK(ctx->KP.alloc((size_t)cap * n));
+  HIPCHK(ctx->KQ.alloc((size_t)cap * n));
+  HIPCHK(ctx->hcoef.alloc(cap));
+  HIPCHK(ctx->scratch.alloc(std::max<size_t>(8192, (size_t)cap * 64 + 16)));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return FSI_OK;
+}
+
+int fsi_set_dirichlet(FsiCtx* ctx, int64_t n, const int64_t* dofs) {
+  if (!ctx || n < 0 || (n > 0 && !dofs)) return FSI_ERR_INVALID;
+  std::vector<int32_t> s(n);
+  for (int64_t i = 0; i < n; ++i) {
+    if (dofs[i] < 0 || dofs[i] >= ctx->ndof) { ctx->err = "fsi_set_dirichlet: dof out of range"; return FSI_ERR_INVALID; }
+    s[i] = ctx->h_user2solver[dofs[i]];
+  }
+  ctx->nbc = n;
+  FSICHK(upload(ctx, ctx->bc_dofs, s));
+  HIPCHK(ctx->bc_vals.alloc(n));
+  if (n) HIPCHK(hipMemset(ctx->bc_vals.p, 0, n * sizeof(double)));
+  return FSI_OK;
+}
+
+int fsi_set_dirichlet_values(FsiCtx* ctx, int64_t n, const double* values) {
+  if (!ctx || n != ctx->nbc || (n > 0 && !values)) { if (ctx) ctx->err = "fsi_set_dirichlet_values: size mismatch"; return FSI_ERR_INVALID; }
+  if (n) HIPCHK(hipMemcpy(ctx->bc_vals.p, values, n * sizeof(double), hipMemcpyHostToDevice));
+  return FSI_OK;
+}
+
+int fsi_set_pressure_facets(FsiCtx* ctx, int64_t nf, const int32_t* facet_nodes, const int32_t* plus_cell) {
+  if (!ctx || nf < 0 || (nf > 0 && (!facet_nodes || !plus_cell))) return FSI_ERR_INVALID;
+  std::vector<int32_t> dofs;
+  std::vector<double> coef;
+  const double* X = ctx->h_coords.data();
+  for (int64_t f = 0; f < nf; ++f) {
+    const int32_t* fn = facet_nodes + 6 * f;
+    const int32_t cell = plus_cell[f];
+    if (cell < 0 || cell >= ctx->C) { ctx->err = "fsi_set_pressure_facets: bad cell"; return FSI_ERR_INVALID; }
+    for (int a = 0; a < 6; ++a)
+      if (fn[a] < 0 || fn[a] >= ctx->N2 || (a < 3 && fn[a] >= ctx->V)) { ctx->err = "fsi_set_pressure_facets: bad node"; return FSI_ERR_INVALID; }
+    const double *a = X + 3 * fn[0], *b = X + 3 * fn[1], *c = X + 3 * fn[2];
+    double e1[3], e2[3], nv[3], fc[3], cc[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i) { e1[i] = b[i] - a[i]; e2[i] = c[i] - a[i]; fc[i] = (a[i] + b[i] + c[i]) / 3.0; }
+    nv[0] = e1[1] * e2[2] - e1[2] * e2[1];
+    nv[1] = e1[2] * e2[0] - e1[0] * e2[2];
+    nv[2] = e1[0] * e2[1] - e1[1] * e2[0];       // |nv| = 2 area
+    for (int v = 0; v < 4; ++v)
+      for (int i = 0; i < 3; ++i) cc[i] += 0.25 * X[3 * ctx->h_tet_nodes[10 * (int64_t)cell + v] + i];
+    const double sgn = (nv[0] * (fc[0] - cc[0]) + nv[1] * (fc[1] - cc[1]) + nv[2] * (fc[2] - cc[2])) < 0 ? -1.0 : 1.0;
+    // int N_a ds = 0 for the vertex functions, area/3 for the edge functions (P2 triangle)
+    for (int e = 3; e < 6; ++e)
+      for (int i = 0; i < 3; ++i) {
+        dofs.push_back(6 * ctx->h_node2rank[fn[e]] + 3 + i);
+        coef.push_back(sgn * 0.5 * nv[i] / 3.0);
+      }
+  }
+  ctx->npf = (int64_t)dofs.size();
+  FSICHK(upload(ctx, ctx->pf_dofs, dofs));
+  FSICHK(upload(ctx, ctx->pf_coef, coef));
+  return FSI_OK;
+}
+
+int fsi_set_interface_pressure(FsiCtx* ctx, double P) {
+  if (!ctx) return FSI_ERR_INVALID;
+  ctx->P = P;
+  return FSI_OK;
+}
+
+int fsi_set_robin_facets(FsiCtx* ctx, int64_t nf, const int32_t* facet_nodes, const double* k_s, const double* c_s) {
+  if (!ctx || nf < 0 || (nf > 0 && (!facet_nodes || !k_s || !c_s))) return FSI_ERR_INVALID;
+  // reference P2 triangle mass matrix / area: (1/180) [[6,-1,-1,-4,0,0],[-1,6,-1,0,-4,0],[-1,-1,6,0,0,-4],
+  //                                                  [-4,0,0,32,16,16],[0,-4,0,16,32,16],[0,0,-4,16,16,32]]
+  static const double M[6][6] = {{6, -1, -1, -4, 0, 0},  {-1, 6, -1, 0, -4, 0},  {-1, -1, 6, 0, 0, -4},
+                                 {-4, 0, 0, 32, 16, 16}, {0, -4, 0, 16, 32, 16}, {0, 0, -4, 16, 16, 32}};
+  std::vector<int32_t> row, col;
+  std::vector<double> val;
+  std::vector<int64_t> pos;
+  const double* X = ctx->h_coords.data();
+  std::vector<int64_t> h_rowptr(ctx->ndof + 1);
+  HIPCHK(hipMemcpy(h_rowptr.data(), ctx->rowptr.p, (ctx->ndof + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+  for (int64_t f = 0; f < nf; ++f) {
+    const int32_t* fn = facet_nodes + 6 * f;
+    for (int a = 0; a < 6; ++a)
+      if (fn[a] < 0 || fn[a] >= ctx->N2 || (a < 3 && fn[a] >= ctx->V)) { ctx->err = "fsi_set_robin_facets: bad node"; return FSI_ERR_INVALID; }
+    const double *a = X + 3 * fn[0], *b = X + 3 * fn[1], *c = X + 3 * fn[2];
+    double e1[3], e2[3];
+    for (int i = 0; i < 3; ++i) { e1[i] = b[i] - a[i]; e2[i] = c[i] - a[i]; }
+    const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+    const double area = 0.5 * std::sqrt(nx * nx + ny * ny + nz * nz);
+    for (int p = 0; p < 6; ++p)
+      for (int q = 0; q < 6; ++q) {
+        const double m = area * M[p][q] / 180.0;
+        if (m == 0.0) continue;
+        const int32_t rp = ctx->h_node2rank[fn[p]], rq = ctx->h_node2rank[fn[q]];
+        const int32_t* lo = ctx->h_nadj.data() + ctx->h_nadj_ptr[rp];
+        const int32_t* hi = ctx->h_nadj.data() + ctx->h_nadj_ptr[rp + 1];
+        const int64_t k = std::lower_bound(lo, hi, rq) - lo;
+        for (int i = 0; i < 3; ++i) {
+          const int32_t r = 6 * rp + 3 + i;
+          row.push_back(r); col.push_back(6 * rq + i);     val.push_back(k_s[f] * m); pos.push_back(h_rowptr[r] + 6 * k + i);
+          row.push_back(r); col.push_back(6 * rq + 3 + i); val.push_back(c_s[f] * m); pos.push_back(h_rowptr[r] + 6 * k + 3 + i);
+        }
+      }
+  }
+  ctx->nrobin = (int64_t)row.size();
+  FSICHK(upload(ctx, ctx->rb_row, row));
+  FSICHK(upload(ctx, ctx->rb_col, col));
+  FSICHK(upload(ctx, ctx->rb_val, val));
+  FSICHK(upload(ctx, ctx->rb_pos, pos));
+  return FSI_OK;
+}
+
+int fsi_solver_setup(FsiCtx* ctx) {
+  if (!ctx) return FSI_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  Phase ph(ctx, &ctx->t_jac);
+  HIPCHK(hipMemsetAsync(ctx->A_pre.p, 0, ctx->nnz * sizeof(double), ctx->stream));
+  launch_jacobian(ctx->stream, PART_LINEAR, ctx->C, elem_arrays(ctx), elem_params(ctx), ctx->U.p, ctx->U1.p,
+                  ctx->rowptr.p, ctx->nadj_ptr.p, ctx->A_pre.p);
+  launch_add_at(ctx->stream, ctx->A_pre.p, ctx->rb_pos.p, ctx->rb_val.p, ctx->scheme.th0, ctx->nrobin);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->have_jacobian = false;
+  return FSI_OK;
+}
+
+int fsi_assemble_residual(FsiCtx* ctx, double* norm) {
+  if (!ctx) return FSI_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  {
+    Phase ph(ctx, &ctx->t_res);
+    HIPCHK(hipMemsetAsync(ctx->F.p, 0, ctx->ndof * sizeof(double), ctx->stream));
+    launch_residual(ctx->stream, ctx->C, elem_arrays(ctx), elem_params(ctx), ctx->U.p, ctx->U1.p, ctx->F.p);
+    launch_add_indexed(ctx->stream, ctx->F.p, ctx->pf_dofs.p, ctx->pf_coef.p, ctx->P, ctx->npf);
+    launch_robin_residual(ctx->stream, ctx->nrobin, ctx->rb_row.p, ctx->rb_col.p, ctx->rb_val.p, ctx->scheme.th0,
+                          ctx->scheme.th1, ctx->U.p, ctx->U1.p, ctx->F.p);
+    launch_negate(ctx->stream, ctx->b.p, ctx->F.p, ctx->ndof);
+    launch_bc_rhs(ctx->stream, ctx->b.p, ctx->U.p, ctx->bc_dofs.p, ctx->bc_vals.p, ctx->nbc);
+    HIPCHK(hipGetLastError());
+  }
+  double nrm = 0.0;
+  FSICHK(norm2(ctx, ctx->b.p, &nrm));
+  if (norm) *norm = nrm;
+  return FSI_OK;
+}
+
+int fsi_assemble_jacobian(FsiCtx* ctx) {
+  if (!ctx) return FSI_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  {
+    Phase ph(ctx, &ctx->t_jac);
+    HIPCHK(hipMemsetAsync(ctx->A.p, 0, ctx->nnz * sizeof(double), ctx->stream));
+    launch_jacobian(ctx->stream, PART_NONLINEAR, ctx->C, elem_arrays(ctx), elem_params(ctx), ctx->U.p, ctx->U1.p,
+                    ctx->rowptr.p, ctx->nadj_ptr.p, ctx->A.p);
+    if (getenv("FSI_DEBUG")) { HIPCHK(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[fsi] jacobian kernel done\n"); fflush(stderr); }
+    launch_matrix_finish(ctx->stream, ctx->ndof, ctx->rowptr.p, ctx->diagpos.p, ctx->A.p, ctx->A_pre.p, ctx->bc_dofs.p,
+                         ctx->nbc, ctx->rowscale.p, ctx->iflags.p + 16);
+    HIPCHK(hipGetLastError());
+    if (getenv("FSI_DEBUG")) { HIPCHK(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[fsi] matrix finish done\n"); fflush(stderr); }
+  }
+  {
+    Phase ph(ctx, &ctx->t_fac);
+    HIPCHK(hipMemcpyAsync(ctx->LU.p, ctx->A.p, ctx->nnz * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    launch_ilu0_levels(ctx->stream, ctx->levels, ctx->rowptr.p, ctx->cols.p, ctx->diagpos.p, ctx->LU.p, ctx->iflags.p);
+    HIPCHK(hipGetLastError());
+  }
+  int32_t flags[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
+  ctx->kry_m = 0;          // the recycled directions belong to the previous matrix
+  ctx->have_jacobian = true;
+  if (flags[1] & 1) { ctx->err = "ILU(0): a row has more than 1024 entries"; return FSI_ERR_INVALID; }
+  if (flags[1] & 2) { ctx->err = "ILU(0): zero or non-finite pivot"; return FSI_ERR_PIVOT; }
+  return FSI_OK;
+}
+
+int fsi_solve(FsiCtx* ctx, double lin_rtol, int32_t lin_max_it, int32_t lin_solver, int32_t* iters, double* relres) {
+  if (!ctx) return FSI_ERR_INVALID;
+  if (!ctx->have_jacobian) { ctx->err = "fsi_solve: no Jacobian assembled"; return FSI_ERR_INVALID; }
+  HIPCHK(hipSetDevice(ctx->device));
+  launch_mul(ctx->stream, ctx->bs.p, ctx->rowscale.p, ctx->b.p, ctx->ndof);
+  int it = 0;
+  double rr = 0.0;
+  int rc;
+  {
+    Phase ph(ctx, &ctx->t_kry);
+    if (lin_solver == 1) {
+      launch_copy(ctx->stream, ctx->F.p, ctx->bs.p, ctx->ndof);     // F is free between residual assemblies
+      rc = solve_bicgstab(ctx, ctx->F.p, ctx->du.p, lin_rtol, lin_max_it, &it, &rr);
+    } else {
+      rc = solve_gcr(ctx, ctx->bs.p, ctx->du.p, lin_rtol, lin_max_it, &it, &rr);
+    }
+  }
+  if (iters) *iters = it;
+  if (relres) *relres = rr;
+  return rc;
+}
+
+int fsi_newton_solve(FsiCtx* ctx, const FsiNewtonOpts* o, FsiNewtonIter* iters, int32_t* n_iters) {
+  if (!ctx || !o || !iters || !n_iters) return FSI_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  int it = 0;
+  double residual = 1e8, rel_res = 1e8, last_residual = 1e8;
+  *n_iters = 0;
+  while (rel_res > o->rtol && residual > o->atol && it < o->max_it) {
+    const bool rec = (it == 0 && o->recompute_tstep > 0 && o->counter % o->recompute_tstep == 0) ||
+                     (it > 0 && o->recompute > 0 && it % o->recompute == 0) || (it > 0 && last_residual < residual) ||
+                     (it == 0 && o->counter == o->first_step_num) || !ctx->have_jacobian;
+    if (rec) FSICHK(fsi_assemble_jacobian(ctx));
+    double bnorm = 0.0;
+    FSICHK(fsi_assemble_residual(ctx, &bnorm));
+    last_residual = residual;
+    int32_t lit = 0;
+    double lrr = 0.0;
+    FSICHK(fsi_solve(ctx, o->lin_rtol, o->lin_max_it, o->lin_solver, &lit, &lrr));
+    launch_axpy(ctx->stream, ctx->U.p, o->lmbda, ctx->du.p, ctx->ndof);
+    launch_bc_set(ctx->stream, ctx->U.p, ctx->bc_dofs.p, ctx->bc_vals.p, ctx->nbc);
+    residual = bnorm;
+    FSICHK(norm2(ctx, ctx->du.p, &rel_res));
+    iters[it] = FsiNewtonIter{residual, rel_res, rec ? 1 : 0, lit, lrr};
+    it += 1;
+    *n_iters = it;
+    if (!(residual <= 1e20) || !(rel_res <= 1e20)) {
+      ctx->err = "Error: The simulation has diverged during the Newton solve.";
+      return FSI_ERR_DIVERGED;
+    }
+  }
+  return FSI_OK;
+}
+
+int fsi_shift(FsiCtx* ctx) {
+  if (!ctx) return FSI_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  launch_copy(ctx->stream, ctx->U1.p, ctx->U.p, ctx->ndof);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return FSI_OK;
+}
+
+static double* state_ptr(FsiCtx* ctx, int which) {
+  switch (which) {
+    case 0: return ctx->U.p;
+    case 1: return ctx->U1.p;
+    case 2: return ctx->b.p;
+    case 3: return ctx->du.p;
+    default: return nullptr;
+  }
+}
+
+int fsi_get_state(FsiCtx* ctx, int which, double* out) {
+  if (!ctx || !out || !state_ptr(ctx, which)) return FSI_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  launch_gather(ctx->stream, ctx->tmp7.p, state_ptr(ctx, which), ctx->user2solver.p, ctx->ndof);   // tmp7[user] = x[solver]
+  HIPCHK(hipMemcpyAsync(out, ctx->tmp7.p, ctx->ndof * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return FSI_OK;
+}
+
+int fsi_set_state(FsiCtx* ctx, int which, const double* in) {
+  if (!ctx || !in || !state_ptr(ctx, which)) return FSI_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(ctx->tmp7.p, in, ctx->ndof * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  launch_scatter(ctx->stream, state_ptr(ctx, which), ctx->tmp7.p, ctx->user2solver.p, ctx->ndof);  // x[solver] = in[user]
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return FSI_OK;
+}
+
+int fsi_get_matrix(FsiCtx* ctx, int64_t* rowptr, int64_t* cols, double* vals) {
+  if (!ctx || !rowptr || !cols || !vals) return FSI_ERR_INVALID;
+  if (!ctx->have_jacobian) { ctx->err = "fsi_get_matrix: no Jacobian assembled"; return FSI_ERR_INVALID; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t n = ctx->ndof, nnz = ctx->nnz;
+  std::vector<int64_t> rp(n + 1);
+  std::vector<int32_t> cs(nnz), s2u(n);
+  std::vector<double> vs(nnz), sc(n);
+  HIPCHK(hipMemcpy(rp.data(), ctx->rowptr.p, (n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(cs.data(), ctx->cols.p, nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(vs.data(), ctx->A.p, nnz * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(sc.data(), ctx->rowscale.p, n * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(s2u.data(), ctx->solver2user.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  rowptr[0] = 0;
+  for (int64_t u = 0; u < n; ++u) {
+    const int64_t s = ctx->h_user2solver[u];
+    rowptr[u + 1] = rowptr[u] + (rp[s + 1] - rp[s]);
+  }
+  std::vector<std::pair<int64_t, double>> rowbuf;
+  for (int64_t u = 0; u < n; ++u) {
+    const int64_t s = ctx->h_user2solver[u];
+    rowbuf.clear();
+    for (int64_t t = rp[s]; t < rp[s + 1]; ++t) rowbuf.emplace_back((int64_t)s2u[cs[t]], vs[t] / sc[s]);
+    std::sort(rowbuf.begin(), rowbuf.end());
+    int64_t o = rowptr[u];
+    for (auto& e : rowbuf) { cols[o] = e.first; vals[o] = e.second; ++o; }
+  }
+  return FSI_OK;
+}
+
+int fsi_spmv(FsiCtx* ctx, const double* x, double* y) {
+  if (!ctx || !x || !y) return FSI_ERR_INVALID;
+  if (!ctx->have_jacobian) { ctx->err = "fsi_spmv: no Jacobian assembled"; return FSI_ERR_INVALID; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t n = ctx->ndof;
+  HIPCHK(hipMemcpyAsync(ctx->tmp7.p, x, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  launch_scatter(ctx->stream, ctx->tmp1.p, ctx->tmp7.p, ctx->user2solver.p, n);
+  launch_spmv(ctx->stream, n, ctx->rowptr.p, ctx->cols.p, ctx->A.p, ctx->tmp1.p, ctx->tmp2.p);
+  // undo the row equilibration: y = D^-1 (D A) x
+  launch_gather(ctx->stream, ctx->tmp7.p, ctx->tmp2.p, ctx->user2solver.p, n);
+  std::vector<double> ys(n), sc(n);
+  HIPCHK(hipMemcpyAsync(ys.data(), ctx->tmp7.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  launch_gather(ctx->stream, ctx->tmp3.p, ctx->rowscale.p, ctx->user2solver.p, n);
+  HIPCHK(hipMemcpyAsync(sc.data(), ctx->tmp3.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (int64_t i = 0; i < n; ++i) y[i] = ys[i] / sc[i];
+  return FSI_OK;
+}
+
+int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
+  if (!ctx || !out) return FSI_ERR_INVALID;
+  *out = FsiTimers{ctx->t_res.ms,  ctx->t_res.calls,  ctx->t_jac.ms,   ctx->t_jac.calls,   ctx->t_fac.ms, ctx->t_fac.calls,
+                   ctx->t_spmv.ms, ctx->t_spmv.calls, ctx->t_prec.ms,  ctx->t_prec.calls,  ctx->t_ortho.ms,
+                   ctx->t_ortho.calls, ctx->t_kry.ms, ctx->t_kry.calls, ctx->kry_iters};
+  if (reset) {
+    for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_kry}) {
+      t->ms = 0.0;
+      t->calls = 0;
+    }
+    ctx->kry_iters = 0;
+  }
+  return FSI_OK;
+}
+
+}  // extern "C"

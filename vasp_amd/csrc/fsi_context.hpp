@@ -1,0 +1,124 @@
+// Device-resident context of one monolithic FSI problem (one per GPU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/vaspfsi.h"
+#include "fsi_element.hpp"
+
+namespace fsi {
+
+constexpr int NQ = 24;        // Keast degree-6 rule
+constexpr int NLOC = 64;      // local dofs per tet: 30 (d) + 30 (v) + 4 (p)
+constexpr int MAX_REGIONS = 8;
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+// One colour of the multicolour ordering: `ngroups` groups of `group_rows` consecutive rows starting at `first_row`
+// (6 rows per P2 node for the d/v block, 1 row per vertex for the pressure block).
+struct Level {
+  int64_t first_row, ngroups;
+  int group_rows;
+};
+
+struct PhaseTimer {
+  double ms = 0.0;
+  int64_t calls = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
+}  // namespace fsi
+
+struct FsiCtx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // sizes
+  int64_t V = 0, N2 = 0, C = 0, ndof = 0, nnz = 0;
+  fsi::Scheme scheme{};
+  int nfluid = 0, nsolid = 0;
+  fsi::FluidProps fluid[fsi::MAX_REGIONS];
+  fsi::SolidProps solid[fsi::MAX_REGIONS];
+
+  // numbering: solver index <-> user index
+  std::vector<int32_t> h_user2solver;        // [ndof]
+  fsi::DevBuf<int32_t> user2solver, solver2user;
+
+  // mesh / element data (device)
+  fsi::DevBuf<double> geom;                  // [C][10]: Jinv (row-major dxi_k/dx_j) 9 + |det|
+  fsi::DevBuf<int32_t> cell_dofs;            // [C][64] solver indices
+  fsi::DevBuf<int32_t> cell_kind, cell_region;
+  fsi::DevBuf<uint16_t> enbr;                // [C][10][10] index of node b in adj(node a)
+  fsi::DevBuf<uint16_t> epnbr;               // [C][10][4]  index of vertex b among vertex-neighbours of node a
+  fsi::DevBuf<int32_t> cell_rank;            // [C][10] rank of the local nodes
+
+  // node graph + CSR structure
+  std::vector<int64_t> h_nadj_ptr;           // [N2+1]
+  std::vector<int32_t> h_nadj;               // neighbour ranks, ascending
+  std::vector<int64_t> h_padj_ptr;           // [N2+1] vertex-neighbours (as vertex ids), ascending
+  std::vector<int32_t> h_padj;
+  std::vector<int32_t> h_rank2node, h_node2rank;
+  std::vector<int32_t> h_prank;               // vertex -> position in the pressure block
+  std::vector<fsi::Level> levels;
+  int ncolors = 0;
+  fsi::DevBuf<int64_t> nadj_ptr, padj_ptr;
+  fsi::DevBuf<int32_t> nadj, padj;
+  fsi::DevBuf<int64_t> rowptr;               // [ndof+1]
+  fsi::DevBuf<int32_t> cols;                 // [nnz]
+  fsi::DevBuf<int64_t> diagpos;              // [ndof]
+
+  // matrices
+  fsi::DevBuf<double> A_pre, A, LU;          // [nnz] each; A holds the row-equilibrated Jacobian after setup
+  fsi::DevBuf<double> rowscale;              // [ndof]
+  bool have_jacobian = false;
+
+  // vectors (solver ordering)
+  fsi::DevBuf<double> U, U1, F, b, du, bs, tmp1, tmp2, tmp3, tmp4, tmp5, tmp6, tmp7;
+  fsi::DevBuf<double> scratch;               // reductions
+  fsi::DevBuf<int32_t> iflags;               // device-side error / counters
+
+  // boundary data
+  int64_t nbc = 0;
+  fsi::DevBuf<int32_t> bc_dofs;              // solver indices
+  fsi::DevBuf<double> bc_vals;
+  int64_t npf = 0;                           // interface-pressure load: F[dof] += P * coef
+  fsi::DevBuf<int32_t> pf_dofs;
+  fsi::DevBuf<double> pf_coef;
+  double P = 0.0;
+  int64_t nrobin = 0;                        // Robin COO: rows (v dofs), cols (d or v dofs), values
+  fsi::DevBuf<int32_t> rb_row, rb_col;
+  fsi::DevBuf<double> rb_val;
+  fsi::DevBuf<int64_t> rb_pos;               // position in the CSR values
+
+  // Krylov recycling space (GCR): P (search directions) and Q = A P (orthonormal)
+  int64_t kry_cap = 0, kry_m = 0;
+  fsi::DevBuf<double> KP, KQ;
+  fsi::DevBuf<double> hcoef;                 // [kry_cap] coefficients on device
+
+  // timers
+  fsi::PhaseTimer t_res, t_jac, t_fac, t_spmv, t_prec, t_ortho, t_kry;
+  int64_t kry_iters = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  // host copy of the mesh needed after create
+  std::vector<double> h_coords;
+  std::vector<int32_t> h_tet_nodes;
+};

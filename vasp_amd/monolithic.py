@@ -172,8 +172,13 @@ def default_backend(desc):
     return HipBackend(desc)
 
 
-def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_backend, out=print):
-    """Run one simulation; returns the final namespace (for tests).  ``out`` receives solver log lines."""
+def prepare(argv: Optional[List[str]] = None):
+    """Everything ``run`` does before the time loop: parameters, folders, mesh, hooks up to ``create_bcs``.
+
+    Returns (ns, desc, bc_values, pressure, hook): the namespace, the plain-array problem description the kernel
+    library consumes, a callable giving the current Dirichlet values, the interface-pressure object (or None) and the
+    hook lookup.
+    """
     args = parse(argv)
     problem = load_problem(args.pop("problem"))
     hook = lambda name: getattr(problem, name, getattr(_defaults, name))
@@ -209,7 +214,7 @@ def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_ba
     dvp_ = {k: MixedFunction(mesh, x) for k, x in state.items()}
     ns.update(mesh=mesh, domains=domains, boundaries=boundaries, DVP=DVP, dvp_=dvp_, psi="psi", phi="phi",
               gamma="gamma", F_solid_linear=FormTerms(), F_fluid_linear=FormTerms(),
-              t=float(ns["t"]), counter=int(ns["counter"]))
+              t=float(ns["t"]), counter=int(ns["counter"]), _state=state)
     if ns.get("robin_bc"):
         ds_ids, k_s, c_s = _as_list(ns["ds_s_id"]), _as_list(ns["k_s"]), _as_list(ns["c_s"])
         for i, marker in enumerate(ds_ids):
@@ -221,6 +226,13 @@ def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_ba
     ns.update(upd or {})
 
     desc, bc_values, pressure = build_description(mesh, v, ns["bcs"], ns["F_solid_linear"])
+    return ns, desc, bc_values, pressure, hook
+
+
+def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_backend, out=print):
+    """Run one simulation; returns the final namespace (for tests).  ``out`` receives solver log lines."""
+    ns, desc, bc_values, pressure, hook = prepare(argv)
+    state = ns["_state"]
     backend = backend_factory(desc)
     ns["backend"] = backend
     first_step_num = ns["counter"]
