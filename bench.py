@@ -1,0 +1,192 @@
+"""Benchmark of the hot path: Newton iterations per second of the monolithic ALE-FSI time step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--tets T]
+
+One "step" = one time step of the offset-stenosis problem (pre_solve data, quasi-Newton solve through the C-ABI, state
+shift) on a synthetic offset-stenosis mesh of about T tetrahedra (default 1 M = BASELINE.json configs[1]; the mesh comes
+from vasp_amd.meshgen because the reference tree has no mesh of that size).  All inputs are resident in HBM before the
+timed region; the only host<->device traffic inside it is the per-step Dirichlet values and a few scalars.
+
+N > 1: the path partitions by elements; this round every rank runs the whole problem on its own GPU on
+an independent mesh replica ("replicas only" until the element-partitioned solver lands), so the aggregate is N x the
+per-rank rate and `scaling` is "weak".
+
+Output: ONE JSON line on rank 0 (metric, value, roofline of the dominant kernel, cpu_baseline of the oracle).
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(budget_s: float = 25.0):
+    """The oracle (numpy restatement, exact sparse LU) timed on the host cores on a bounded sample: the cylinder
+    fixture (1 647 tets, 15 352 dofs), quasi-Newton iterations with one Jacobian, until ~budget_s is spent."""
+    from oracle.backend import OracleBackend
+    from vasp_amd.monolithic import prepare
+    with contextlib.redirect_stdout(io.StringIO()):
+        ns, desc, bc_values, pressure, hook = prepare(
+            ["-p", "cylinder", "-dt", "0.001", "-T", "0.1", "--theta", "0.501", "--verbose", "False", "--folder",
+             tempfile.mkdtemp(), "--sub-folder", "1", "--new-arguments",
+             f"mesh_path={ROOT / 'tests' / 'golden' / 'cylinder' / 'cylinder.h5'}"])
+    t0 = time.perf_counter()
+    ob = OracleBackend(desc)            # includes A_pre = assemble(J_linear), as the reference's solver_setup
+    its, step, t = 0, 0, 0.0
+    while time.perf_counter() - t0 < budget_s or its == 0:
+        t += 0.001
+        with contextlib.redirect_stdout(io.StringIO()):
+            ns["t"] = t
+            hook("pre_solve")(**ns)
+        ob.set_dirichlet_values(bc_values())
+        ob.set_interface_pressure(float(pressure.P))
+        hist = ob.newton_solve(counter=step, first_step_num=0, atol=1e-6, rtol=1e-6, max_it=50, lmbda=1.0, recompute=20,
+                               recompute_tstep=20)
+        ob.shift()
+        its += len(hist)
+        step += 1
+    dt = time.perf_counter() - t0
+    ndof = ob.o.ndof
+    return {"value": its / dt, "unit": "Newton-iterations/s", "cores": 1, "kind": "port",
+            "sample": f"oracle (numpy + SuperLU) on the cylinder fixture: 1647 tets, {ndof} dofs, {step} time steps, "
+                      f"{its} Newton iterations in {dt:.1f} s incl. one Jacobian + LU",
+            "dof_updates_per_s": its * ndof / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tets", type=int, default=int(os.environ.get("VASPFSI_BENCH_TETS", 1000000)))
+    ap.add_argument("--dt", type=float, default=1e-3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    from vasp_amd.capi import HipBackend
+    from vasp_amd.meshgen import write_mesh
+    from vasp_amd.monolithic import prepare
+
+    tmp = Path(tempfile.mkdtemp(prefix=f"vaspfsi_bench_r{rank}_"))
+    mesh_path = tmp / "stenosis.h5"
+    t_setup = time.perf_counter()
+    write_mesh(mesh_path, args.tets, seed=0)
+    T_end = args.dt * (args.steps + args.warmup)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ns, desc, bc_values, pressure, hook = prepare(
+            ["-p", "offset_stenosis", "-dt", str(args.dt), "-T", str(T_end), "--theta", "0.501", "--verbose", "False",
+             "--folder", str(tmp / "results"), "--sub-folder", "1", "--new-arguments", f"mesh_path={mesh_path}"])
+    hb = HipBackend(desc, device=local_rank)
+    mesh = ns["mesh"]
+    setup_s = time.perf_counter() - t_setup
+    newton = dict(atol=ns["atol"], rtol=ns["rtol"], max_it=ns["max_it"], lmbda=ns["lmbda"], recompute=ns["recompute"],
+                  recompute_tstep=ns["recompute_tstep"])
+
+    def one_step(counter, t):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ns["t"] = t
+            hook("pre_solve")(**ns)
+        hb.set_dirichlet_values(bc_values())
+        hb.set_interface_pressure(float(pressure.P))
+        hist = hb.newton_solve(counter=counter, first_step_num=0, **newton)
+        hb.shift()
+        return hist
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t, counter = 0.0, 0
+    for _ in range(args.warmup):
+        t += args.dt
+        one_step(counter, t)
+        counter += 1
+    hb.timers(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    n_newton, n_krylov = 0, 0
+    for _ in range(args.steps):
+        t += args.dt
+        hist = one_step(counter, t)
+        counter += 1
+        n_newton += len(hist)
+        n_krylov += sum(h[3] for h in hist)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tm = hb.timers()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        nn = torch.tensor([n_newton], dtype=torch.float64, device="cuda")
+        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
+        total_newton = float(nn.item())
+    else:
+        total_newton = float(n_newton)
+
+    if rank == 0:
+        ndof, nnz = hb.ndof, int(hb.lib.fsi_matrix_nnz(hb.ctx))
+        C = mesh.num_cells
+        # algorithmic bytes per launch of each timed kernel
+        kernels = {
+            "k_spmv (monolithic Jacobian, CSR f64 + i32)": (tm["spmv_ms"], tm["spmv_calls"], nnz * 12.0 + ndof * 16.0 + (ndof + 1) * 8.0),
+            "k_residual (element residual + scatter-add)": (tm["residual_ms"], tm["residual_calls"], C * 1676.0),
+            "k_jacobian<nonlinear> (element Jacobian + scatter-add)": (tm["jacobian_ms"], tm["jacobian_calls"], C * 33420.0),
+        }
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        ms, calls, nbytes = kernels[dom]
+        achieved = nbytes / (ms / max(calls, 1) * 1e-3) / 1e9 if ms > 0 else 0.0
+        out = {
+            "metric": "Newton-iterations/sec (offset_stenosis, monolithic ALE-FSI step)",
+            "value": total_newton / elapsed, "unit": "Newton-iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"offset_stenosis synthetic mesh, {C} tets, {ndof} dofs, dt={args.dt}, theta=0.501, "
+                                   f"quasi-Newton atol=rtol=1e-6 recompute_tstep={ns['recompute_tstep']}",
+                       "tets": C, "dofs": ndof, "matrix_nnz": nnz, "parallelism": "replicas" if world > 1 else "1 GPU"},
+            "dof_updates_per_s": total_newton * ndof / elapsed,
+            "newton_iterations": n_newton, "krylov_iterations": n_krylov,
+            "phase_ms": {k: tm[k] for k in ("residual_ms", "jacobian_ms", "factor_ms", "spmv_ms", "precond_ms", "ortho_ms", "krylov_ms")},
+            "phase_calls": {k: tm[k] for k in ("residual_calls", "jacobian_calls", "factor_calls", "spmv_calls", "precond_calls",
+                                               "krylov_solves", "krylov_iters", "inner_vv_iters", "inner_schur_iters", "inner_dd_iters")},
+            "setup_s": setup_s,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": calls,
+                         "avg_launch_ms": ms / max(calls, 1), "algorithmic_bytes_per_launch": nbytes},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    hb.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,6 +101,11 @@ int fsi_set_pressure_facets(FsiCtx* ctx, int64_t nf, const int32_t* facet_nodes,
 int fsi_set_interface_pressure(FsiCtx* ctx, double P);
 /* Replaces: robin_bc terms of solid_setup [REF src/vasp/simulations/aneurysm.py:73-76]. */
 int fsi_set_robin_facets(FsiCtx* ctx, int64_t nf, const int32_t* facet_nodes, const double* k_s, const double* c_s);
+/* Replaces: `linear_solver="mumps"` [REF offset_stenosis.py:45].  precond 0 = field-split block preconditioner
+ * (velocity/pressure SIMPLE split with the solid displacement eliminated, then the displacement block; inner ILU(0)
+ * BiCGStab solves to `inner_rtol` within `inner_max_it` iterations), 1 = multicolour ILU(0) of the monolithic matrix.
+ * Non-positive inner_rtol / inner_max_it keep the current values. */
+int fsi_set_linear_solver(FsiCtx* ctx, int32_t precond, double inner_rtol, int32_t inner_max_it);
 /* Finishes set-up: assembles A_pre = assemble(J_linear) at the current state (solver_setup()). */
 int fsi_solver_setup(FsiCtx* ctx);
 
@@ -137,6 +142,10 @@ typedef struct FsiTimers {
   double precond_ms;   int64_t precond_calls;
   double ortho_ms;     int64_t ortho_calls;
   double krylov_ms;    int64_t krylov_solves;   int64_t krylov_iters;
+  int64_t inner_vv_iters;                    /* inner BiCGStab iterations of the block preconditioner: velocity block */
+  int64_t inner_schur_iters;                 /* ... pressure Schur complement                                          */
+  int64_t inner_dd_iters;                    /* ... displacement block                                                 */
+  int64_t precond_applies;
 } FsiTimers;
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
 

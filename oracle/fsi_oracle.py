@@ -382,6 +382,22 @@ class FsiOracle:
         Rl, Rn = self.element_residuals(U, U1)
         return self.assemble_vector(Rl + Rn) + self.facet_residual(U, U1, P)
 
+    def function_norm(self, X):
+        """``norm(dvp_res, 'l2')`` of the reference's newtonsolver.  ``dolfin.norm`` of a *Function* (not a vector)
+        assembles sqrt(int_Omega |f|^2 dx) whatever the case of the norm name, so "r (rel)" in the log is the
+        L2(Omega) norm of the mixed update (d, v, p), not the l2 norm of its dof vector.  Cross-check: the tutorial
+        log [REF docs/offset_stenosis.md:200-202] shows r (rel) = 2e-2 at iteration 0 where the dof-vector norm of a
+        pressure update of O(10 Pa) over O(10^3) vertices would be O(10^2)."""
+        d, v, p = self.unpack(self.gather(X))
+        w, N, L = self.wdet, self.N, self.L
+        tot = 0.0
+        for fld in (d, v):
+            fq = np.einsum("qa,cai->cqi", N, fld)
+            tot += np.einsum("cq,cqi,cqi->", w, fq, fq)
+        pq = np.einsum("qa,ca->cq", L, p)
+        tot += np.einsum("cq,cq,cq->", w, pq, pq)
+        return float(np.sqrt(tot))
+
     # ---- turtleFSI newtonsolver.py ----------------------------------------------------------------
     def solver_setup(self, U, U1):
         """``A_pre = assemble(J_linear)`` once, at the state the solver is created with."""
@@ -442,7 +458,7 @@ class FsiOracle:
             U += lmbda * dU
             U[self.bc_dofs] = bc_values
             residual = float(np.linalg.norm(b))
-            rel_res = float(np.linalg.norm(dU))
+            rel_res = self.function_norm(dU)
             if not np.isfinite(residual) or not np.isfinite(rel_res) or residual > 1e20 or rel_res > 1e20:
                 raise RuntimeError("Error: The simulation has diverged during the Newton solve.")
             if log:

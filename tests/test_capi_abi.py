@@ -1,0 +1,72 @@
+"""The drop-in boundary: libvaspfsi.so loads and exports every entry point include/vaspfsi.h declares; the ctypes
+structs match the header; without a GPU the product path fails loudly (no CPU fallback)."""
+import ctypes
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from vasp_amd import capi
+
+HEADER = (ROOT / "include" / "vaspfsi.h").read_text()
+
+
+def declared_functions():
+    return sorted(set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(fsi_\w+)\s*\(", HEADER, flags=re.M)))
+
+
+def test_every_declared_symbol_is_exported():
+    lib = capi.load_library()
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vaspfsi.h but not exported"
+    assert set(names) == set(capi.EXPORTED_SYMBOLS)
+
+
+def test_struct_layouts_match_header():
+    # field counts and sizes (all members are 8-byte aligned or explicitly int32 pairs)
+    def fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), HEADER, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        return [part.strip().split()[-1].lstrip("*") for f in body.split(";") if f.strip() for part in f.split(",")]
+    for name, cls in (("FsiMeshDesc", capi.FsiMeshDesc), ("FsiParams", capi.FsiParams),
+                      ("FsiNewtonOpts", capi.FsiNewtonOpts), ("FsiNewtonIter", capi.FsiNewtonIter), ("FsiTimers", capi.FsiTimers),
+                      ("FsiStepStats", getattr(capi, "FsiStepStats", None))):
+        if cls is None:
+            continue
+        assert [f for f, _ in cls._fields_] == fields(name), name
+    assert ctypes.sizeof(capi.FsiNewtonIter) == 32
+
+
+def test_error_codes_match_header():
+    for code, name in capi.ERROR_NAMES.items():
+        assert re.search(r"#define %s %d\b" % (name, code), HEADER)
+
+
+def test_no_gpu_means_loud_failure(cylinder_case):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.FsiError) as e:
+        capi.HipBackend(cylinder_case[1])
+    assert e.value.code == 2           # FSI_ERR_DEVICE
+
+
+def test_create_rejects_bad_input():
+    lib = capi.load_library()
+    ctx = ctypes.c_void_p()
+    coords = np.zeros((4, 3))
+    tn = np.arange(10, dtype=np.int32)[None]
+    kind = np.array([5], dtype=np.int32)           # neither fluid (0) nor solid (1)
+    reg = np.zeros(1, dtype=np.int32)
+    md = capi.FsiMeshDesc(4, 10, 1, capi._ptr(coords), capi._ptr(tn), capi._ptr(kind), capi._ptr(reg))
+    fp = np.array([[1.0, 1.0]])
+    sp = np.array([[1.0, 1.0, 1.0]])
+    sm = np.zeros(1, dtype=np.int32)
+    pr = capi.FsiParams(1e-3, 0.5, 1, capi._ptr(fp), 1, capi._ptr(sp), capi._ptr(sm), 1e7, 1.0)
+    rc = lib.fsi_create(ctypes.byref(md), ctypes.byref(pr), 0, ctypes.byref(ctx))
+    assert rc == 1 and b"kind" in lib.fsi_last_error(ctx)
+    lib.fsi_destroy(ctx)
+    assert lib.fsi_create(None, None, 0, ctypes.byref(ctx)) == 1

@@ -1,0 +1,102 @@
+"""The oracle against the reference's own known answers, and against its committed golden runs.
+
+The reference's known-answer values are outputs of turtleFSI/FEniCS/MUMPS runs that stop Newton at atol = rtol = 1e-6
+after one to a dozen quasi-Newton steps with a direct solve of a matrix whose entries span 1e-7 .. 1e+2 per row
+(delta = 1e7 penalty); the last printed digits therefore depend on the factorisation's round-off and on where the
+loop stops, not only on the discrete equations.  What the restatement can and does reproduce is the solution of the
+same discrete equations: the committed runs of the oracle (tests/golden/*.npz, made by tests/golden/make_golden.py)
+agree with every pinned value to a few 1e-5 relative to the field's magnitude - that is the tolerance written below,
+looser than the reference's own np.isclose(rtol=1e-5) / atol=1e-10, and recorded as such in DESIGN.md.
+"""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+# REF tests/test_simulations.py:34-35,43-44,53,57 (offset stenosis, dt 0.01, theta 0.51, 5 steps, probe 5)
+PIN_V = np.array([-0.012555684636129378, 8.084632937234429e-06, -2.3712435710623827e-05])
+PIN_P = 0.43014573081840823
+PIN_D = np.array([-9.431090796213597e-06, -4.33478380630615e-05, -4.655061542874265e-05])
+# REF tests/test_create_hdf5_and_separate_viz.py:40-51,196-206 (cylinder, dt 1e-3, theta 0.51, vertex 0, t = 1,2,3 ms)
+PIN_CYL_VX = np.array([4.38261949610407e-6, 5.244315455211961e-6, 8.137814761280497e-6])
+PIN_CYL_DX = np.array([2.235075700301419e-9, 7.0569699656660426e-9, 1.3776599148439903e-8])
+# REF tests/test_predeform.py:32-33: mesh_predeformed coordinates[0] = x0 - d(vertex 0, t = 3 ms)  (scale factor -1)
+PIN_CYL_PREDEFORMED = np.array([7.382372340085156e-5, -1.1083576098054155e-4, 4.930899508039441e-4])
+
+
+def probe(mesh, state, point, fld):
+    from vasp_amd.fem import MixedFunction
+    return MixedFunction(mesh, state).sub(fld)(point)
+
+
+@pytest.mark.parametrize("run", ["stenosis_ref", "stenosis_tight"])
+def test_offset_stenosis_known_answer(stenosis_case, run):
+    path = GOLDEN / f"{run}.npz"
+    if not path.exists():
+        pytest.skip(f"{path.name} not generated")
+    ns = stenosis_case[0]
+    mesh = ns["mesh"]
+    U = np.load(path)["states"][4]                      # after step 5 (t = 0.05)
+    v = probe(mesh, U, ns["probe_points"][5], 1)
+    p = probe(mesh, U, ns["probe_points"][5], 2)
+    d = probe(mesh, U, ns["solid_probe_points"][5], 0)
+    vscale, dscale = np.abs(PIN_V).max(), np.abs(PIN_D).max()
+    assert np.abs(v - PIN_V).max() < 5e-5 * vscale, (v, PIN_V)
+    assert np.abs(d - PIN_D).max() < 3e-4 * dscale, (d, PIN_D)
+    assert np.allclose(d, PIN_D, rtol=1e-5, atol=1e-8)              # the reference's own tolerance holds for d
+    # the probe pressure crosses zero during these steps (-1.6 .. +0.43 Pa); compare on that scale
+    assert abs(p - PIN_P) < 5e-4 * 1.6, (p, PIN_P)
+
+
+@pytest.mark.parametrize("run", ["cylinder_ref", "cylinder_tight"])
+def test_cylinder_known_answers(cylinder_case, run):
+    mesh = cylinder_case[0]["mesh"]
+    S = np.load(GOLDEN / f"{run}.npz")["states"]
+    N2 = mesh.num_nodes
+    vx, dx = S[:, 3 * N2], S[:, 0]
+    assert np.abs(vx / PIN_CYL_VX - 1).max() < 3e-4, vx
+    assert np.abs(dx / PIN_CYL_DX - 1).max() < 1e-4, dx
+    assert np.allclose(dx, PIN_CYL_DX, rtol=0, atol=1e-10)          # the reference's own tolerance holds for d_x
+    # d_x(t1) = dt theta v_x(t1) for an interface vertex, zero initial state
+    assert np.isclose(dx[0], 1e-3 * 0.51 * vx[0], rtol=1e-9)
+    d3 = S[2, :3]
+    assert np.allclose(mesh.coords[0] - d3, PIN_CYL_PREDEFORMED, rtol=0, atol=2e-10)
+
+
+def test_golden_states_solve_the_oracle_equations(cylinder_case):
+    """The committed states are solutions of the oracle's own discrete equations: F(U_k; U_{k-1}) = 0 to the tolerance
+    of the run (cheap re-check, no Jacobian), with the boundary data of that step."""
+    import contextlib, io
+    from oracle.fsi_oracle import FsiOracle
+    ns, desc, bc_values, pressure, hook = cylinder_case
+    o = FsiOracle(desc)
+    S = np.load(GOLDEN / "cylinder_tight.npz")["states"]
+    prev = np.zeros(o.ndof)
+    for k, U in enumerate(S):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ns["t"] = 1e-3 * (k + 1)
+            hook("pre_solve")(**ns)
+        b = o.rhs(U, prev, float(pressure.P), bc_values())
+        assert np.linalg.norm(b) < 1e-9, (k, np.linalg.norm(b))
+        prev = U
+
+
+def test_oracle_newton_step_reproduces_golden(cylinder_case):
+    """One full oracle time step (assembly, complex-step Jacobian, LU, quasi-Newton policy, L2 update norm) from zero."""
+    import contextlib, io
+    from oracle.backend import OracleBackend
+    ns, desc, bc_values, pressure, hook = cylinder_case
+    ob = OracleBackend(desc)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ns["t"] = 1e-3
+        hook("pre_solve")(**ns)
+    ob.set_dirichlet_values(bc_values())
+    ob.set_interface_pressure(float(pressure.P))
+    lines = []
+    hist = ob.newton_solve(counter=0, first_step_num=0, atol=1e-6, rtol=1e-6, max_it=50, lmbda=1.0, recompute=20,
+                           recompute_tstep=20, log=lines.append)
+    gold = np.load(GOLDEN / "cylinder_ref.npz")
+    assert len(hist) == int(gold["iterations"][0])
+    assert lines[0] == "Compute Jacobian matrix" and lines[1].startswith("Newton iteration 0: r (atol) = ")
+    U = gold["states"][0]
+    assert np.abs(ob.U - U).max() <= 1e-9 * np.abs(U).max()

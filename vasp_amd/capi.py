@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "fsi_set_pressure_facets", "fsi_set_interface_pressure", "fsi_set_robin_facets", "fsi_solver_setup",
     "fsi_assemble_residual", "fsi_assemble_jacobian", "fsi_solve", "fsi_newton_solve", "fsi_shift",
     "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_get_matrix", "fsi_spmv",
-    "fsi_get_timers",
+    "fsi_get_timers", "fsi_set_linear_solver",
 )
 
 
@@ -54,7 +54,9 @@ class FsiTimers(C.Structure):
                 ("jacobian_calls", C.c_int64), ("factor_ms", C.c_double), ("factor_calls", C.c_int64),
                 ("spmv_ms", C.c_double), ("spmv_calls", C.c_int64), ("precond_ms", C.c_double),
                 ("precond_calls", C.c_int64), ("ortho_ms", C.c_double), ("ortho_calls", C.c_int64),
-                ("krylov_ms", C.c_double), ("krylov_solves", C.c_int64), ("krylov_iters", C.c_int64)]
+                ("krylov_ms", C.c_double), ("krylov_solves", C.c_int64), ("krylov_iters", C.c_int64),
+                ("inner_vv_iters", C.c_int64), ("inner_schur_iters", C.c_int64), ("inner_dd_iters", C.c_int64),
+                ("precond_applies", C.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -104,6 +106,7 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_get_matrix.argtypes = [vp, vp, vp, vp]
     lib.fsi_spmv.argtypes = [vp, vp, vp]
     lib.fsi_get_timers.argtypes = [vp, C.POINTER(FsiTimers), C.c_int]
+    lib.fsi_set_linear_solver.argtypes = [vp, i32, dbl, i32]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("fsi_last_error", "fsi_num_dofs", "fsi_matrix_nnz"):
@@ -124,7 +127,7 @@ class HipBackend:
     """One problem instance resident on one GPU; the methods are what ``monolithic.run`` calls per time step."""
 
     def __init__(self, desc: dict, device: int = 0, lin_rtol: float = 1e-10, lin_max_it: int = 4000,
-                 lin_solver: int = 0):
+                 lin_solver: int = 0, precond: int = 0, inner_rtol: float = 1e-2, inner_max_it: int = 40):
         self.lib = load_library()
         self.ctx = C.c_void_p()
         self.lin_rtol, self.lin_max_it, self.lin_solver = lin_rtol, lin_max_it, lin_solver
@@ -147,6 +150,7 @@ class HipBackend:
                 self.ctx = C.c_void_p()
             raise FsiError(rc, msg)
         self.ndof = int(self.lib.fsi_num_dofs(self.ctx))
+        self._check(self.lib.fsi_set_linear_solver(self.ctx, int(precond), float(inner_rtol), int(inner_max_it)))
         bc = np.ascontiguousarray(desc.get("bc_dofs", np.zeros(0)), dtype=np.int64)
         self._check(self.lib.fsi_set_dirichlet(self.ctx, len(bc), _ptr(bc)))
         self.nbc = len(bc)
@@ -253,6 +257,9 @@ class HipBackend:
         y = np.empty(self.ndof)
         self._check(self.lib.fsi_spmv(self.ctx, _ptr(x), _ptr(y)))
         return y
+
+    def set_linear_solver(self, precond: int = 0, inner_rtol: float = 0.0, inner_max_it: int = 0):
+        self._check(self.lib.fsi_set_linear_solver(self.ctx, int(precond), float(inner_rtol), int(inner_max_it)))
 
     def timers(self, reset=False) -> dict:
         t = FsiTimers()

@@ -1,0 +1,301 @@
+// Field-split pieces of the linear solve (gfx950): structure and values of the sub-matrices of the monolithic Jacobian
+// and the pressure Schur complement used by the block preconditioner (fsi_capi.hip: precondition_block).
+//
+// The reference hands the monolithic matrix to MUMPS (`up_sol.solve`).  Here the Krylov method runs on
+// the monolithic matrix and is preconditioned by an approximate block factorisation in the order (v, p) -> d:
+//   * in the solid the d-equation  delta rho/k (d - d1) = delta rho (theta v + ...)  is a mass-matrix identity, so
+//     dd = k theta dv there; substituting it turns A_vd, A_pd columns of solid nodes into velocity columns:
+//       Avv~ = A_vv + k theta A_vd[:, solid],   Apv~ = A_pv + k theta A_pd[:, solid]
+//   * the (v, p) saddle point is split SIMPLE-style with the explicit Schur complement S = A_pp - Apv~ D^-1 A_vp,
+//     D = diag(Avv~), assembled on its full (two-ring) vertex pattern;
+//   * d follows from A_dd dd = r_d - A_dv dv (solid: mass matrix; fluid: the mesh-lifting Laplacian).
+// All of it is HBM-bound gather/scatter work; bytes are those of the matrices touched (stated at the launchers).
+#include "fsi_kernels.hpp"
+
+namespace fsi {
+
+__device__ inline double wsum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---- structure of the 3x3-blocked node matrices (A_dd, Avv~, A_dv share it) -------------------------------------------
+// row 3r+i: for every neighbour rank s of r (ascending) the columns 3s, 3s+1, 3s+2.
+__global__ void k_b3_structure(int64_t N2, const int64_t* __restrict__ nadj_ptr, const int32_t* __restrict__ nadj,
+                               int64_t* __restrict__ rowptr3, int32_t* __restrict__ cols3, int64_t* __restrict__ diagpos3) {
+  const int64_t R = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (R > 3 * N2) return;
+  if (R == 3 * N2) { rowptr3[R] = 9 * nadj_ptr[N2]; return; }
+  const int64_t r = R / 3;
+  const int i = (int)(R % 3);
+  const int64_t a = nadj_ptr[r], deg = nadj_ptr[r + 1] - a;
+  int64_t pos = 9 * a + 3 * i * deg;
+  rowptr3[R] = pos;
+  for (int64_t k = 0; k < deg; ++k) {
+    const int32_t s = nadj[a + k];
+    if (s == r) diagpos3[R] = pos + i;
+    cols3[pos++] = 3 * s;
+    cols3[pos++] = 3 * s + 1;
+    cols3[pos++] = 3 * s + 2;
+  }
+}
+// rows 3r+i x pressure columns (positions in the pressure block) of the vertex neighbours of node r
+__global__ void k_vp_structure(int64_t N2, const int64_t* __restrict__ padj_ptr, const int32_t* __restrict__ padj,
+                               int64_t* __restrict__ rowptr, int32_t* __restrict__ cols) {
+  const int64_t R = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (R > 3 * N2) return;
+  if (R == 3 * N2) { rowptr[R] = 3 * padj_ptr[N2]; return; }
+  const int64_t r = R / 3;
+  const int i = (int)(R % 3);
+  const int64_t a = padj_ptr[r], deg = padj_ptr[r + 1] - a;
+  int64_t pos = 3 * a + i * deg;
+  rowptr[R] = pos;
+  for (int64_t k = 0; k < deg; ++k) cols[pos++] = padj[a + k];
+}
+// pressure rows q x velocity columns 3s+j of the neighbours of the vertex' node; rowptr_pv given (host prefix sum)
+__global__ void k_pv_structure(int64_t V, const int32_t* __restrict__ vrank, const int64_t* __restrict__ nadj_ptr,
+                               const int32_t* __restrict__ nadj, const int64_t* __restrict__ rowptr,
+                               int32_t* __restrict__ cols) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= V) return;
+  const int32_t r = vrank[q];
+  int64_t pos = rowptr[q];
+  for (int64_t k = nadj_ptr[r]; k < nadj_ptr[r + 1]; ++k) {
+    const int32_t s = nadj[k];
+    cols[pos++] = 3 * s;
+    cols[pos++] = 3 * s + 1;
+    cols[pos++] = 3 * s + 2;
+  }
+}
+
+void launch_block_structure(hipStream_t st, int64_t N2, int64_t V, const int64_t* nadj_ptr, const int32_t* nadj,
+                            const int64_t* padj_ptr, const int32_t* padj, const int32_t* vrank, int64_t* rowptr3,
+                            int32_t* cols3, int64_t* diagpos3, int64_t* rowptr_vp, int32_t* cols_vp,
+                            const int64_t* rowptr_pv, int32_t* cols_pv) {
+  const unsigned g3 = (unsigned)((3 * N2 + 1 + 255) / 256);
+  hipLaunchKernelGGL(k_b3_structure, dim3(g3), dim3(256), 0, st, N2, nadj_ptr, nadj, rowptr3, cols3, diagpos3);
+  hipLaunchKernelGGL(k_vp_structure, dim3(g3), dim3(256), 0, st, N2, padj_ptr, padj, rowptr_vp, cols_vp);
+  hipLaunchKernelGGL(k_pv_structure, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, V, vrank, nadj_ptr, nadj,
+                     rowptr_pv, cols_pv);
+}
+
+// ---- values: split the (row-equilibrated) monolithic matrix into its field blocks -----------------------------------------
+// One wave per monolithic row.  Reads nnz*8 B, writes the same once.
+__global__ __launch_bounds__(256) void k_extract_blocks(
+    int64_t N2, int64_t V, double ktheta, const int64_t* __restrict__ rowptr, const double* __restrict__ A,
+    const int64_t* __restrict__ nadj_ptr, const int32_t* __restrict__ nadj, const int64_t* __restrict__ padj_ptr,
+    const int32_t* __restrict__ vrank, const int32_t* __restrict__ node_solid, const int64_t* __restrict__ rowptr3,
+    const int64_t* __restrict__ rowptr_vp, const int64_t* __restrict__ rowptr_pv, const int64_t* __restrict__ rowptr_pp,
+    double* __restrict__ Add, double* __restrict__ Adv, double* __restrict__ Avv, double* __restrict__ Avp,
+    double* __restrict__ Apv, double* __restrict__ App) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t n = 6 * N2 + V;
+  for (int64_t row = wave; row < n; row += nwaves) {
+    const int64_t s0 = rowptr[row];
+    if (row < 6 * N2) {
+      const int64_t r = row / 6;
+      const int t = (int)(row % 6), f = t / 3, i = t % 3;
+      const int64_t a = nadj_ptr[r], deg = nadj_ptr[r + 1] - a;
+      const int64_t o3 = rowptr3[3 * r + i];
+      for (int64_t k = lane; k < deg; k += 64) {
+        const double* e = A + s0 + 6 * k;
+        const double sol = node_solid[nadj[a + k]] ? ktheta : 0.0;
+        if (f == 0) {
+          for (int j = 0; j < 3; ++j) { Add[o3 + 3 * k + j] = e[j]; Adv[o3 + 3 * k + j] = e[3 + j]; }
+        } else {
+          for (int j = 0; j < 3; ++j) Avv[o3 + 3 * k + j] = e[3 + j] + sol * e[j];
+        }
+      }
+      if (f == 1) {
+        const int64_t pdeg = padj_ptr[r + 1] - padj_ptr[r];
+        const int64_t ov = rowptr_vp[3 * r + i];
+        for (int64_t k = lane; k < pdeg; k += 64) Avp[ov + k] = A[s0 + 6 * deg + k];
+      }
+    } else {
+      const int64_t q = row - 6 * N2;
+      const int32_t r = vrank[q];
+      const int64_t a = nadj_ptr[r], deg = nadj_ptr[r + 1] - a;
+      const int64_t ov = rowptr_pv[q];
+      for (int64_t k = lane; k < deg; k += 64) {
+        const double* e = A + s0 + 6 * k;
+        const double sol = node_solid[nadj[a + k]] ? ktheta : 0.0;
+        for (int j = 0; j < 3; ++j) Apv[ov + 3 * k + j] = e[3 + j] + sol * e[j];
+      }
+      const int64_t pdeg = padj_ptr[r + 1] - padj_ptr[r];
+      const int64_t op = rowptr_pp[q];
+      for (int64_t k = lane; k < pdeg; k += 64) App[op + k] = A[s0 + 6 * deg + k];
+    }
+  }
+}
+void launch_extract_blocks(hipStream_t st, int64_t N2, int64_t V, double ktheta, const int64_t* rowptr, const double* A,
+                           const int64_t* nadj_ptr, const int32_t* nadj, const int64_t* padj_ptr, const int32_t* vrank,
+                           const int32_t* node_solid, const int64_t* rowptr3, const int64_t* rowptr_vp,
+                           const int64_t* rowptr_pv, const int64_t* rowptr_pp, double* Add, double* Adv, double* Avv,
+                           double* Avp, double* Apv, double* App) {
+  const int64_t n = 6 * N2 + V;
+  int64_t blocks = (n + 3) / 4;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_extract_blocks, dim3((unsigned)blocks), dim3(256), 0, st, N2, V, ktheta, rowptr, A, nadj_ptr, nadj,
+                     padj_ptr, vrank, node_solid, rowptr3, rowptr_vp, rowptr_pv, rowptr_pp, Add, Adv, Avv, Avp, Apv, App);
+}
+
+// ---- sparsified Schur complement S1 = (A_pp - Apv~ D^-1 A_vp) restricted to the vertex-neighbour pattern -------------------
+// Only used to build an ILU(0) preconditioner for the pressure solve; the solve itself applies the full operator
+// (launch_schur_apply).  One wave per pressure row q; columns = vertex neighbours of q (ascending pressure positions).
+static constexpr int MAXS = 512;
+__global__ __launch_bounds__(64) void k_schur_p1(int64_t V, const int32_t* __restrict__ vrank,
+                                                 const int64_t* __restrict__ nadj_ptr, const int32_t* __restrict__ nadj,
+                                                 const int64_t* __restrict__ padj_ptr, const int32_t* __restrict__ padj,
+                                                 const int64_t* __restrict__ rowptr_pv, const double* __restrict__ Apv,
+                                                 const int64_t* __restrict__ rowptr_pp, const double* __restrict__ App,
+                                                 const int64_t* __restrict__ rowptr_vp, const double* __restrict__ Avp,
+                                                 const int64_t* __restrict__ diagpos3, const double* __restrict__ Avv,
+                                                 double* __restrict__ S1, int32_t* __restrict__ flags) {
+  __shared__ double acc[MAXS];
+  __shared__ int32_t scol[MAXS];
+  const int lane = threadIdx.x;
+  for (int64_t q = blockIdx.x; q < V; q += gridDim.x) {
+    const int32_t r = vrank[q];
+    const int64_t pa0 = padj_ptr[r];
+    const int len = (int)(padj_ptr[r + 1] - pa0);
+    const int64_t op = rowptr_pp[q];
+    if (len > MAXS) { if (lane == 0) atomicOr(&flags[1], 4); continue; }
+    __syncthreads();
+    for (int t = lane; t < len; t += 64) { acc[t] = App[op + t]; scol[t] = padj[pa0 + t]; }
+    __syncthreads();
+    const int64_t a = nadj_ptr[r], deg = nadj_ptr[r + 1] - a, ov = rowptr_pv[q];
+    for (int64_t e = lane; e < 3 * deg; e += 64) {
+      const int32_t b = nadj[a + e / 3];
+      const int j = (int)(e % 3);
+      const double bq = Apv[ov + e];
+      if (bq == 0.0) continue;
+      const int64_t R = 3 * (int64_t)b + j;
+      const double coef = bq / Avv[diagpos3[R]];
+      const int64_t pa = padj_ptr[b], pdeg = padj_ptr[b + 1] - pa, o = rowptr_vp[R];
+      for (int64_t k = 0; k < pdeg; ++k) {
+        const double v = Avp[o + k];
+        if (v == 0.0) continue;
+        const int32_t c = padj[pa + k];
+        int lo = 0, hi = len - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (scol[mid] < c) lo = mid + 1; else hi = mid; }
+        if (scol[lo] == c) atomicAdd(&acc[lo], -coef * v);
+      }
+    }
+    __syncthreads();
+    for (int t = lane; t < len; t += 64) S1[op + t] = acc[t];
+  }
+}
+void launch_schur_p1(hipStream_t st, int64_t V, const int32_t* vrank, const int64_t* nadj_ptr, const int32_t* nadj,
+                     const int64_t* padj_ptr, const int32_t* padj, const int64_t* rowptr_pv, const double* Apv,
+                     const int64_t* rowptr_pp, const double* App, const int64_t* rowptr_vp, const double* Avp,
+                     const int64_t* diagpos3, const double* Avv, double* S1, int32_t* flags) {
+  const unsigned blocks = (unsigned)(V < 16384 ? V : 16384);
+  hipLaunchKernelGGL(k_schur_p1, dim3(blocks), dim3(64), 0, st, V, vrank, nadj_ptr, nadj, padj_ptr, padj, rowptr_pv, Apv,
+                     rowptr_pp, App, rowptr_vp, Avp, diagpos3, Avv, S1, flags);
+}
+
+// ---- field vectors <-> monolithic vector (solver ordering: 6 per node [d d d v v v], then pressure) ---------------------------
+#define GS(i, n) for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+__global__ void k_split(int64_t N2, int64_t V, const double* __restrict__ r, double* __restrict__ rd,
+                        double* __restrict__ rv, double* __restrict__ rp) {
+  GS(t, 3 * N2) {
+    const int64_t nd = t / 3;
+    const int i = (int)(t % 3);
+    rd[t] = r[6 * nd + i];
+    rv[t] = r[6 * nd + 3 + i];
+  }
+  GS(q, V) rp[q] = r[6 * N2 + q];
+}
+__global__ void k_merge(int64_t N2, int64_t V, const double* __restrict__ zd, const double* __restrict__ zv,
+                        const double* __restrict__ zp, double* __restrict__ z) {
+  GS(t, 3 * N2) {
+    const int64_t nd = t / 3;
+    const int i = (int)(t % 3);
+    z[6 * nd + i] = zd[t];
+    z[6 * nd + 3 + i] = zv[t];
+  }
+  GS(q, V) z[6 * N2 + q] = zp[q];
+}
+static inline unsigned gridn(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 4096) g = 4096;
+  return (unsigned)g;
+}
+void launch_split(hipStream_t st, int64_t N2, int64_t V, const double* r, double* rd, double* rv, double* rp) {
+  hipLaunchKernelGGL(k_split, dim3(gridn(3 * N2)), dim3(256), 0, st, N2, V, r, rd, rv, rp);
+}
+void launch_merge(hipStream_t st, int64_t N2, int64_t V, const double* zd, const double* zv, const double* zp, double* z) {
+  hipLaunchKernelGGL(k_merge, dim3(gridn(3 * N2)), dim3(256), 0, st, N2, V, zd, zv, zp, z);
+}
+
+// dv[R] = vs[R] - (A_vp dp)[R] / D[R]   (SIMPLE velocity correction); also y = D^-1 A_vp x for the Schur operator.
+// One thread per row (rows have 4-30 entries).
+__global__ void k_vel_correct(int64_t n3, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                              const double* __restrict__ vals, const double* __restrict__ dp,
+                              const int64_t* __restrict__ diagpos3, const double* __restrict__ Avv,
+                              const double* __restrict__ vs, double* __restrict__ dv) {
+  GS(R, n3) {
+    double s = 0.0;
+    for (int64_t t = rowptr[R]; t < rowptr[R + 1]; ++t) s += vals[t] * dp[cols[t]];
+    dv[R] = (vs ? vs[R] : 0.0) - s / Avv[diagpos3[R]];
+  }
+}
+void launch_vel_correct(hipStream_t st, int64_t n3, const int64_t* rowptr, const int32_t* cols, const double* vals,
+                        const double* dp, const int64_t* diagpos3, const double* Avv, const double* vs, double* dv) {
+  hipLaunchKernelGGL(k_vel_correct, dim3(gridn(n3)), dim3(256), 0, st, n3, rowptr, cols, vals, dp, diagpos3, Avv, vs, dv);
+}
+// y = alpha * (App x)[q] + beta * (Apv~ w)[q] + gamma * c[q]: pressure-row products (Schur operator, pressure rhs).
+// One wave per pressure row.
+__global__ __launch_bounds__(256) void k_pres_rows(int64_t V, const int64_t* __restrict__ rowptr_pp,
+                                                   const int32_t* __restrict__ cols_pp, const double* __restrict__ App,
+                                                   const double* __restrict__ x, double alpha,
+                                                   const int64_t* __restrict__ rowptr_pv, const int32_t* __restrict__ cols_pv,
+                                                   const double* __restrict__ Apv, const double* __restrict__ w, double beta,
+                                                   const double* __restrict__ c, double gamma, double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t q = wave; q < V; q += nwaves) {
+    double s1 = 0.0, s2 = 0.0;
+    if (alpha != 0.0)
+      for (int64_t t = rowptr_pp[q] + lane; t < rowptr_pp[q + 1]; t += 64) s1 += App[t] * x[cols_pp[t]];
+    if (beta != 0.0)
+      for (int64_t t = rowptr_pv[q] + lane; t < rowptr_pv[q + 1]; t += 64) s2 += Apv[t] * w[cols_pv[t]];
+    const double s = wsum(alpha * s1 + beta * s2);
+    if (lane == 0) y[q] = s + (gamma != 0.0 ? gamma * c[q] : 0.0);
+  }
+}
+void launch_pres_rows(hipStream_t st, int64_t V, const int64_t* rowptr_pp, const int32_t* cols_pp, const double* App,
+                      const double* x, double alpha, const int64_t* rowptr_pv, const int32_t* cols_pv, const double* Apv,
+                      const double* w, double beta, const double* c, double gamma, double* y) {
+  int64_t blocks = (V + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_pres_rows, dim3((unsigned)blocks), dim3(256), 0, st, V, rowptr_pp, cols_pp, App, x, alpha, rowptr_pv,
+                     cols_pv, Apv, w, beta, c, gamma, y);
+}
+// y = b - A x, one wave per row (generic CSR)
+__global__ __launch_bounds__(256) void k_residual_csr(int64_t n, const int64_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ cols, const double* __restrict__ vals,
+                                                      const double* __restrict__ x, const double* __restrict__ b,
+                                                      double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t row = wave; row < n; row += nwaves) {
+    double s = 0.0;
+    for (int64_t t = rowptr[row] + lane; t < rowptr[row + 1]; t += 64) s += vals[t] * x[cols[t]];
+    s = wsum(s);
+    if (lane == 0) y[row] = b[row] - s;
+  }
+}
+void launch_residual_csr(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const double* vals,
+                         const double* x, const double* b, double* y) {
+  int64_t blocks = (n + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_residual_csr, dim3((unsigned)blocks), dim3(256), 0, st, n, rowptr, cols, vals, x, b, y);
+}
+
+}  // namespace fsi

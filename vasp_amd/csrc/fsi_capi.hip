@@ -27,6 +27,8 @@ using namespace fsi;
     if (r_ != FSI_OK) return r_;     \
   } while (0)
 
+int refresh_preconditioner(FsiCtx* ctx);
+
 namespace {
 
 const int TET_EDGES[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
@@ -70,18 +72,112 @@ int host_scalar(FsiCtx* ctx, const double* dptr, double* out) {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return FSI_OK;
 }
-int dot(FsiCtx* ctx, const double* x, const double* y, double* out) {
-  launch_dot(ctx->stream, x, y, ctx->ndof, ctx->scratch.p, ctx->scratch.p + 4096);
+int dot_n(FsiCtx* ctx, const double* x, const double* y, int64_t n, double* out) {
+  launch_dot(ctx->stream, x, y, n, ctx->scratch.p, ctx->scratch.p + 4096);
   return host_scalar(ctx, ctx->scratch.p + 4096, out);
 }
+int dot(FsiCtx* ctx, const double* x, const double* y, double* out) { return dot_n(ctx, x, y, ctx->ndof, out); }
 int norm2(FsiCtx* ctx, const double* x, double* out) {
   FSICHK(dot(ctx, x, x, out));
   *out = std::sqrt(*out);
   return FSI_OK;
 }
 
+// ---- inner solves of the block preconditioner: BiCGStab on one field block, ILU(0)-preconditioned ----------------------
+// W holds 8 work vectors of length M.n.  Never fails: on breakdown it returns what it has (the outer method is flexible).
+template <class Apply>
+int inner_bicgstab(FsiCtx* ctx, const SubMat& M, Apply&& apply, const double* rhs, double* x, double* W, double rtol,
+                   int maxit, int64_t* its_acc) {
+  const int64_t n = M.n;
+  hipStream_t st = ctx->stream;
+  double *r = W, *r0 = W + n, *p = W + 2 * n, *v = W + 3 * n, *s = W + 4 * n, *t = W + 5 * n, *ph = W + 6 * n, *tmp = W + 7 * n;
+  auto ilu = [&](const double* in, double* out) {
+    launch_sptrsv_levels(st, M.levels, M.rowptr, M.cols, M.diagpos, M.LU.p, in, tmp, out);
+  };
+  launch_copy(st, r, rhs, n);
+  launch_copy(st, r0, rhs, n);
+  launch_fill(st, x, n, 0.0);
+  launch_fill(st, p, n, 0.0);
+  launch_fill(st, v, n, 0.0);
+  double bb = 0.0;
+  FSICHK(dot_n(ctx, r, r, n, &bb));
+  if (!(bb > 0.0) || !std::isfinite(bb)) return FSI_OK;
+  const double target = rtol * rtol * bb;
+  double rho = 1.0, alpha = 1.0, omega = 1.0;
+  for (int it = 0; it < maxit; ++it) {
+    double rho1 = 0.0;
+    FSICHK(dot_n(ctx, r0, r, n, &rho1));
+    if (rho1 == 0.0 || !std::isfinite(rho1)) break;
+    const double beta = (rho1 / rho) * (alpha / omega);
+    launch_axpy(st, p, -omega, v, n);
+    launch_axpby(st, p, 1.0, r, beta, p, n);
+    ilu(p, ph);
+    apply(ph, v);
+    double r0v = 0.0;
+    FSICHK(dot_n(ctx, r0, v, n, &r0v));
+    if (r0v == 0.0 || !std::isfinite(r0v)) break;
+    alpha = rho1 / r0v;
+    launch_axpby(st, s, 1.0, r, -alpha, v, n);
+    launch_axpy(st, x, alpha, ph, n);
+    *its_acc += 1;
+    double ss = 0.0;
+    FSICHK(dot_n(ctx, s, s, n, &ss));
+    if (!(ss > target)) break;
+    ilu(s, ph);
+    apply(ph, t);
+    double ts = 0.0, tt = 0.0;
+    FSICHK(dot_n(ctx, t, s, n, &ts));
+    FSICHK(dot_n(ctx, t, t, n, &tt));
+    omega = tt > 0.0 ? ts / tt : 0.0;
+    if (!std::isfinite(omega) || omega == 0.0) break;
+    launch_axpy(st, x, omega, ph, n);
+    launch_axpby(st, r, 1.0, s, -omega, t, n);
+    double rr = 0.0;
+    FSICHK(dot_n(ctx, r, r, n, &rr));
+    rho = rho1;
+    if (!(rr > target)) break;
+  }
+  return FSI_OK;
+}
+
+// z = M^-1 r with the approximate block factorisation (see fsi_block.hip):  (v,p) by SIMPLE with the d-eliminated
+// velocity block, then d.
+int precondition_block(FsiCtx* ctx, const double* r, double* z) {
+  const int64_t n3 = 3 * ctx->N2, V = ctx->V, N2 = ctx->N2;
+  hipStream_t st = ctx->stream;
+  double* W = ctx->blk.p;
+  double *rd = W, *rv = W + n3, *rp = W + 2 * n3, *vs = W + 3 * n3, *tp = W + 4 * n3, *dp = W + 5 * n3, *dv = W + 6 * n3,
+         *td = W + 7 * n3, *dd = W + 8 * n3, *IW = W + 9 * n3, *w3 = W + 17 * n3;
+  launch_split(st, N2, V, r, rd, rv, rp);
+  // velocity predictor
+  FSICHK(inner_bicgstab(ctx, ctx->Mvv,
+                        [&](const double* in, double* out) { launch_spmv(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Mvv.vals.p, in, out); },
+                        rv, vs, IW, ctx->inner_rtol, ctx->inner_maxit, &ctx->inner_its[0]));
+  // pressure: S dp = rp - Apv~ vs,  S x = App x - Apv~ D^-1 Avp x
+  launch_pres_rows(st, V, ctx->rowptr_pp.p, ctx->cols_pp.p, ctx->App.p, nullptr, 0.0, ctx->rowptr_pv.p, ctx->cols_pv.p,
+                   ctx->Apv.p, vs, -1.0, rp, 1.0, tp);
+  FSICHK(inner_bicgstab(ctx, ctx->Ms,
+                        [&](const double* in, double* out) {
+                          launch_vel_correct(st, n3, ctx->rowptr_vp.p, ctx->cols_vp.p, ctx->Avp.p, in, ctx->diagpos3.p,
+                                             ctx->Mvv.vals.p, nullptr, w3);
+                          launch_pres_rows(st, V, ctx->rowptr_pp.p, ctx->cols_pp.p, ctx->App.p, in, 1.0, ctx->rowptr_pv.p,
+                                           ctx->cols_pv.p, ctx->Apv.p, w3, 1.0, nullptr, 0.0, out);
+                        },
+                        tp, dp, IW, ctx->inner_rtol, ctx->inner_maxit_p, &ctx->inner_its[1]));
+  // velocity correction and displacement
+  launch_vel_correct(st, n3, ctx->rowptr_vp.p, ctx->cols_vp.p, ctx->Avp.p, dp, ctx->diagpos3.p, ctx->Mvv.vals.p, vs, dv);
+  launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Adv.p, dv, rd, td);
+  FSICHK(inner_bicgstab(ctx, ctx->Mdd,
+                        [&](const double* in, double* out) { launch_spmv(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Mdd.vals.p, in, out); },
+                        td, dd, IW, ctx->inner_rtol, ctx->inner_maxit, &ctx->inner_its[2]));
+  launch_merge(st, N2, V, dd, dv, dp, z);
+  ctx->inner_calls += 1;
+  return FSI_OK;
+}
+
 int precondition(FsiCtx* ctx, const double* r, double* z) {
   Phase ph(ctx, &ctx->t_prec);
+  if (ctx->precond == 0) return precondition_block(ctx, r, z);
   launch_sptrsv_levels(ctx->stream, ctx->levels, ctx->rowptr.p, ctx->cols.p, ctx->diagpos.p, ctx->LU.p, r, ctx->tmp7.p, z);
   return FSI_OK;
 }
@@ -212,8 +308,58 @@ int solve_bicgstab(FsiCtx* ctx, const double* rhs, double* x, double rtol, int m
 
 }  // namespace
 
+// Factorisations for the active preconditioner, from the row-equilibrated Jacobian in ctx->A.
+int refresh_preconditioner(FsiCtx* ctx) {
+  Phase ph(ctx, &ctx->t_fac);
+  hipStream_t st = ctx->stream;
+  int32_t flags[4] = {0, 0, 0, 0};
+  if (ctx->precond == 0) {
+    launch_extract_blocks(st, ctx->N2, ctx->V, ctx->scheme.k * ctx->scheme.th0, ctx->rowptr.p, ctx->A.p, ctx->nadj_ptr.p,
+                          ctx->nadj.p, ctx->padj_ptr.p, ctx->vrank.p, ctx->node_solid.p, ctx->rowptr3.p, ctx->rowptr_vp.p,
+                          ctx->rowptr_pv.p, ctx->rowptr_pp.p, ctx->Mdd.vals.p, ctx->Adv.p, ctx->Mvv.vals.p, ctx->Avp.p,
+                          ctx->Apv.p, ctx->App.p);
+    HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
+    launch_schur_p1(st, ctx->V, ctx->vrank.p, ctx->nadj_ptr.p, ctx->nadj.p, ctx->padj_ptr.p, ctx->padj.p, ctx->rowptr_pv.p,
+                    ctx->Apv.p, ctx->rowptr_pp.p, ctx->App.p, ctx->rowptr_vp.p, ctx->Avp.p, ctx->diagpos3.p,
+                    ctx->Mvv.vals.p, ctx->Ms.vals.p, ctx->iflags.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
+    if (flags[1] & 4) { ctx->err = "Schur complement: a vertex has more than 512 vertex neighbours"; return FSI_ERR_INVALID; }
+    for (SubMat* M : {&ctx->Mdd, &ctx->Mvv, &ctx->Ms}) {
+      HIPCHK(hipMemcpyAsync(M->LU.p, M->vals.p, M->nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
+      launch_ilu0_levels(st, M->levels, M->rowptr, M->cols, M->diagpos, M->LU.p, ctx->iflags.p);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
+      if (flags[1] & 1) { ctx->err = "ILU(0): a row has more than 1024 entries"; return FSI_ERR_INVALID; }
+      if (flags[1] & 2) ctx->pivot_warnings += 1;      // pivot replaced by 1: the inner solve stays approximate
+    }
+    return FSI_OK;
+  }
+  if (!ctx->LU.p) HIPCHK(ctx->LU.alloc(ctx->nnz));
+  HIPCHK(hipMemcpyAsync(ctx->LU.p, ctx->A.p, ctx->nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
+  launch_ilu0_levels(st, ctx->levels, ctx->rowptr.p, ctx->cols.p, ctx->diagpos.p, ctx->LU.p, ctx->iflags.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
+  ctx->have_monolithic_lu = true;
+  if (flags[1] & 1) { ctx->err = "ILU(0): a row has more than 1024 entries"; return FSI_ERR_INVALID; }
+  if (flags[1] & 2) { ctx->err = "ILU(0): zero or non-finite pivot"; return FSI_ERR_PIVOT; }
+  return FSI_OK;
+}
+
 // =========================================================================================================
 extern "C" {
+
+int fsi_set_linear_solver(FsiCtx* ctx, int32_t precond, double inner_rtol, int32_t inner_max_it) {
+  if (!ctx || precond < 0 || precond > 1) return FSI_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  const bool changed = precond != ctx->precond;
+  ctx->precond = precond;
+  if (inner_rtol > 0.0) ctx->inner_rtol = inner_rtol;
+  if (inner_max_it > 0) { ctx->inner_maxit = inner_max_it; ctx->inner_maxit_p = inner_max_it + inner_max_it / 2; }
+  if (changed && ctx->have_jacobian) { ctx->kry_m = 0; return refresh_preconditioner(ctx); }
+  return FSI_OK;
+}
+
 
 const char* fsi_last_error(const FsiCtx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 int64_t fsi_num_dofs(const FsiCtx* ctx) { return ctx ? ctx->ndof : 0; }
@@ -236,6 +382,10 @@ int fsi_destroy(FsiCtx* ctx) {
   for (auto* b : i64) b->release();
   ctx->enbr.release();
   ctx->epnbr.release();
+  for (auto* b : {&ctx->Adv, &ctx->Avp, &ctx->Apv, &ctx->App, &ctx->blk, &ctx->Mdd.vals, &ctx->Mdd.LU, &ctx->Mvv.vals,
+                  &ctx->Mvv.LU, &ctx->Ms.vals, &ctx->Ms.LU}) b->release();
+  for (auto* b : {&ctx->node_solid, &ctx->vrank, &ctx->cols3, &ctx->cols_vp, &ctx->cols_pv, &ctx->cols_pp}) b->release();
+  for (auto* b : {&ctx->rowptr3, &ctx->diagpos3, &ctx->rowptr_vp, &ctx->rowptr_pv, &ctx->rowptr_pp, &ctx->diagpos_pp}) b->release();
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -474,10 +624,11 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   FSICHK(upload(ctx, ctx->rowptr, rowptr));
   HIPCHK(ctx->cols.alloc(ctx->nnz));
   HIPCHK(ctx->diagpos.alloc(ctx->ndof));
+  FSICHK(upload(ctx, ctx->vrank, prow_rank));
   {
-    DevBuf<int32_t> d_vrank, d_tv;
+    DevBuf<int32_t>& d_vrank = ctx->vrank;
+    DevBuf<int32_t> d_tv;
     DevBuf<double> d_coords;
-    FSICHK(upload(ctx, d_vrank, prow_rank));
     FSICHK(upload(ctx, d_tv, tet_vertices));
     FSICHK(upload(ctx, d_coords, ctx->h_coords));
     HIPCHK(ctx->geom.alloc((size_t)C * 10));
@@ -485,7 +636,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
                        ctx->rowptr.p, ctx->cols.p, ctx->diagpos.p);
     launch_geometry(ctx->stream, C, d_coords.p, d_tv.p, ctx->geom.p);
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    d_vrank.release(); d_tv.release(); d_coords.release();
+    d_tv.release(); d_coords.release();
   }
   const int64_t n = ctx->ndof;
   DevBuf<double>* vecs[] = {&ctx->U, &ctx->U1, &ctx->F, &ctx->b, &ctx->du, &ctx->bs, &ctx->tmp1, &ctx->tmp2, &ctx->tmp3,
@@ -496,7 +647,66 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   }
   HIPCHK(ctx->A_pre.alloc(ctx->nnz));
   HIPCHK(ctx->A.alloc(ctx->nnz));
-  HIPCHK(ctx->LU.alloc(ctx->nnz));
+  // ---- field blocks of the block preconditioner ------------------------------------------------------------------
+  {
+    std::vector<int32_t> node_solid(N2, 0);
+    for (int64_t c = 0; c < C; ++c)
+      if (mesh->cell_kind[c] == 1)
+        for (int a = 0; a < 10; ++a) node_solid[rk[tn[10 * c + a]]] = 1;
+    FSICHK(upload(ctx, ctx->node_solid, node_solid));
+    const int64_t nadj_total = ctx->h_nadj_ptr[N2], padj_total = ctx->h_padj_ptr[N2];
+    std::vector<int64_t> rowptr_pv(V + 1, 0), rowptr_pp(V + 1, 0), diagpos_pp(V, 0);
+    for (int64_t q = 0; q < V; ++q) {
+      const int32_t r = prow_rank[q];
+      rowptr_pv[q + 1] = rowptr_pv[q] + 3 * (ctx->h_nadj_ptr[r + 1] - ctx->h_nadj_ptr[r]);
+      rowptr_pp[q + 1] = rowptr_pp[q] + (ctx->h_padj_ptr[r + 1] - ctx->h_padj_ptr[r]);
+    }
+    std::vector<int32_t> cols_pp(rowptr_pp[V]);
+    for (int64_t q = 0; q < V; ++q) {
+      const int32_t r = prow_rank[q];
+      const int64_t a = ctx->h_padj_ptr[r], len = ctx->h_padj_ptr[r + 1] - a;
+      bool found = false;
+      for (int64_t k = 0; k < len; ++k) {
+        cols_pp[rowptr_pp[q] + k] = ctx->h_padj[a + k];
+        if (ctx->h_padj[a + k] == q) { diagpos_pp[q] = rowptr_pp[q] + k; found = true; }
+      }
+      if (!found) { ctx->err = "fsi_create: vertex missing from its own neighbour list"; return FSI_ERR_INVALID; }
+    }
+    FSICHK(upload(ctx, ctx->rowptr_pv, rowptr_pv));
+    FSICHK(upload(ctx, ctx->rowptr_pp, rowptr_pp));
+    FSICHK(upload(ctx, ctx->diagpos_pp, diagpos_pp));
+    FSICHK(upload(ctx, ctx->cols_pp, cols_pp));
+    HIPCHK(ctx->rowptr3.alloc(3 * N2 + 1));
+    HIPCHK(ctx->diagpos3.alloc(3 * N2));
+    HIPCHK(ctx->cols3.alloc(9 * nadj_total));
+    HIPCHK(ctx->rowptr_vp.alloc(3 * N2 + 1));
+    HIPCHK(ctx->cols_vp.alloc(3 * padj_total));
+    HIPCHK(ctx->cols_pv.alloc(rowptr_pv[V]));
+    launch_block_structure(ctx->stream, N2, V, ctx->nadj_ptr.p, ctx->nadj.p, ctx->padj_ptr.p, ctx->padj.p, ctx->vrank.p,
+                           ctx->rowptr3.p, ctx->cols3.p, ctx->diagpos3.p, ctx->rowptr_vp.p, ctx->cols_vp.p,
+                           ctx->rowptr_pv.p, ctx->cols_pv.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(ctx->Adv.alloc(9 * nadj_total));
+    HIPCHK(ctx->Avp.alloc(3 * padj_total));
+    HIPCHK(ctx->Apv.alloc(rowptr_pv[V]));
+    HIPCHK(ctx->App.alloc(rowptr_pp[V]));
+    for (SubMat* M : {&ctx->Mdd, &ctx->Mvv}) {
+      M->n = 3 * N2; M->nnz = 9 * nadj_total;
+      M->rowptr = ctx->rowptr3.p; M->cols = ctx->cols3.p; M->diagpos = ctx->diagpos3.p;
+      HIPCHK(M->vals.alloc(M->nnz));
+      HIPCHK(M->LU.alloc(M->nnz));
+    }
+    ctx->Ms.n = V; ctx->Ms.nnz = rowptr_pp[V];
+    ctx->Ms.rowptr = ctx->rowptr_pp.p; ctx->Ms.cols = ctx->cols_pp.p; ctx->Ms.diagpos = ctx->diagpos_pp.p;
+    HIPCHK(ctx->Ms.vals.alloc(ctx->Ms.nnz));
+    HIPCHK(ctx->Ms.LU.alloc(ctx->Ms.nnz));
+    for (const Level& L : ctx->levels) {
+      if (L.group_rows == 6) { ctx->Mdd.levels.push_back(Level{L.first_row / 2, L.ngroups, 3}); }
+      else ctx->Ms.levels.push_back(Level{L.first_row - 6 * N2, L.ngroups, 1});
+    }
+    ctx->Mvv.levels = ctx->Mdd.levels;
+    HIPCHK(ctx->blk.alloc((size_t)18 * 3 * N2));
+  }
   HIPCHK(hipMemsetAsync(ctx->A_pre.p, 0, ctx->nnz * sizeof(double), ctx->stream));
   HIPCHK(ctx->iflags.alloc(n + 16));
   // Krylov space: sized from free memory (the recycled directions are what 288 GB of HBM are used for)
@@ -664,19 +874,10 @@ int fsi_assemble_jacobian(FsiCtx* ctx) {
     HIPCHK(hipGetLastError());
     if (getenv("FSI_DEBUG")) { HIPCHK(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[fsi] matrix finish done\n"); fflush(stderr); }
   }
-  {
-    Phase ph(ctx, &ctx->t_fac);
-    HIPCHK(hipMemcpyAsync(ctx->LU.p, ctx->A.p, ctx->nnz * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    launch_ilu0_levels(ctx->stream, ctx->levels, ctx->rowptr.p, ctx->cols.p, ctx->diagpos.p, ctx->LU.p, ctx->iflags.p);
-    HIPCHK(hipGetLastError());
-  }
-  int32_t flags[4] = {0, 0, 0, 0};
-  HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
   ctx->kry_m = 0;          // the recycled directions belong to the previous matrix
   ctx->have_jacobian = true;
-  if (flags[1] & 1) { ctx->err = "ILU(0): a row has more than 1024 entries"; return FSI_ERR_INVALID; }
-  if (flags[1] & 2) { ctx->err = "ILU(0): zero or non-finite pivot"; return FSI_ERR_PIVOT; }
-  return FSI_OK;
+  ctx->have_monolithic_lu = false;
+  return refresh_preconditioner(ctx);
 }
 
 int fsi_solve(FsiCtx* ctx, double lin_rtol, int32_t lin_max_it, int32_t lin_solver, int32_t* iters, double* relres) {
@@ -822,13 +1023,16 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
   if (!ctx || !out) return FSI_ERR_INVALID;
   *out = FsiTimers{ctx->t_res.ms,  ctx->t_res.calls,  ctx->t_jac.ms,   ctx->t_jac.calls,   ctx->t_fac.ms, ctx->t_fac.calls,
                    ctx->t_spmv.ms, ctx->t_spmv.calls, ctx->t_prec.ms,  ctx->t_prec.calls,  ctx->t_ortho.ms,
-                   ctx->t_ortho.calls, ctx->t_kry.ms, ctx->t_kry.calls, ctx->kry_iters};
+                   ctx->t_ortho.calls, ctx->t_kry.ms, ctx->t_kry.calls, ctx->kry_iters,
+                   ctx->inner_its[0], ctx->inner_its[1], ctx->inner_its[2], ctx->inner_calls};
   if (reset) {
     for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_kry}) {
       t->ms = 0.0;
       t->calls = 0;
     }
     ctx->kry_iters = 0;
+    ctx->inner_its[0] = ctx->inner_its[1] = ctx->inner_its[2] = 0;
+    ctx->inner_calls = 0;
   }
   return FSI_OK;
 }

@@ -38,6 +38,16 @@ struct Level {
   int group_rows;
 };
 
+// A square sparse block with its ILU(0) factors, in CSR on structure arrays owned by the context.
+struct SubMat {
+  int64_t n = 0, nnz = 0;
+  const int64_t* rowptr = nullptr;
+  const int32_t* cols = nullptr;
+  const int64_t* diagpos = nullptr;
+  DevBuf<double> vals, LU;
+  std::vector<Level> levels;
+};
+
 struct PhaseTimer {
   double ms = 0.0;
   int64_t calls = 0;
@@ -107,6 +117,24 @@ struct FsiCtx {
   fsi::DevBuf<int32_t> rb_row, rb_col;
   fsi::DevBuf<double> rb_val;
   fsi::DevBuf<int64_t> rb_pos;               // position in the CSR values
+
+  // field blocks for the block preconditioner (fsi_block.hip)
+  int precond = 0;                           // 0 = field-split block preconditioner, 1 = monolithic multicolour ILU(0)
+  bool have_monolithic_lu = false;
+  fsi::DevBuf<int32_t> node_solid;           // [N2] by rank
+  fsi::DevBuf<int32_t> vrank;                // [V] rank of the node of pressure position q
+  fsi::DevBuf<int64_t> rowptr3, diagpos3;    // 3x3-blocked node structure (A_dd, Avv~, A_dv)
+  fsi::DevBuf<int32_t> cols3;
+  fsi::DevBuf<int64_t> rowptr_vp, rowptr_pv, rowptr_pp, diagpos_pp;
+  fsi::DevBuf<int32_t> cols_vp, cols_pv, cols_pp;
+  fsi::DevBuf<double> Adv, Avp, Apv, App;
+  fsi::SubMat Mdd, Mvv, Ms;                  // A_dd, Avv~, sparsified Schur complement (ILU only)
+  fsi::DevBuf<double> blk;                   // work vectors of the block preconditioner
+  double inner_rtol = 1e-2;
+  int inner_maxit = 40, inner_maxit_p = 60;
+  int64_t inner_its[3] = {0, 0, 0};          // accumulated inner iterations: vv, schur, dd
+  int64_t inner_calls = 0;
+  int64_t pivot_warnings = 0;
 
   // Krylov recycling space (GCR): P (search directions) and Q = A P (orthonormal)
   int64_t kry_cap = 0, kry_m = 0;

@@ -64,4 +64,29 @@ void launch_ilu0_levels(hipStream_t st, const std::vector<Level>& levels, const 
 void launch_sptrsv_levels(hipStream_t st, const std::vector<Level>& levels, const int64_t* rowptr, const int32_t* cols,
                           const int64_t* diagpos, const double* LU, const double* rhs, double* tmp, double* x);
 
+
+// fsi_block.hip — field blocks of the Jacobian and the pieces of the block preconditioner
+void launch_block_structure(hipStream_t st, int64_t N2, int64_t V, const int64_t* nadj_ptr, const int32_t* nadj,
+                            const int64_t* padj_ptr, const int32_t* padj, const int32_t* vrank, int64_t* rowptr3,
+                            int32_t* cols3, int64_t* diagpos3, int64_t* rowptr_vp, int32_t* cols_vp,
+                            const int64_t* rowptr_pv, int32_t* cols_pv);
+void launch_extract_blocks(hipStream_t st, int64_t N2, int64_t V, double ktheta, const int64_t* rowptr, const double* A,
+                           const int64_t* nadj_ptr, const int32_t* nadj, const int64_t* padj_ptr, const int32_t* vrank,
+                           const int32_t* node_solid, const int64_t* rowptr3, const int64_t* rowptr_vp,
+                           const int64_t* rowptr_pv, const int64_t* rowptr_pp, double* Add, double* Adv, double* Avv,
+                           double* Avp, double* Apv, double* App);
+void launch_schur_p1(hipStream_t st, int64_t V, const int32_t* vrank, const int64_t* nadj_ptr, const int32_t* nadj,
+                     const int64_t* padj_ptr, const int32_t* padj, const int64_t* rowptr_pv, const double* Apv,
+                     const int64_t* rowptr_pp, const double* App, const int64_t* rowptr_vp, const double* Avp,
+                     const int64_t* diagpos3, const double* Avv, double* S1, int32_t* flags);
+void launch_split(hipStream_t st, int64_t N2, int64_t V, const double* r, double* rd, double* rv, double* rp);
+void launch_merge(hipStream_t st, int64_t N2, int64_t V, const double* zd, const double* zv, const double* zp, double* z);
+void launch_vel_correct(hipStream_t st, int64_t n3, const int64_t* rowptr, const int32_t* cols, const double* vals,
+                        const double* dp, const int64_t* diagpos3, const double* Avv, const double* vs, double* dv);
+void launch_pres_rows(hipStream_t st, int64_t V, const int64_t* rowptr_pp, const int32_t* cols_pp, const double* App,
+                      const double* x, double alpha, const int64_t* rowptr_pv, const int32_t* cols_pv, const double* Apv,
+                      const double* w, double beta, const double* c, double gamma, double* y);
+void launch_residual_csr(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const double* vals,
+                         const double* x, const double* b, double* y);
+
 }  // namespace fsi
