@@ -1,0 +1,215 @@
+"""GPU parity: the HIP path (through the C-ABI, vasp_amd.capi.HipBackend) against the CPU oracle, the committed golden
+runs and the reference's known answers.  FP64 throughout; tolerances are written at each assert."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, prepare_case
+
+pytestmark = pytest.mark.gpu
+
+
+def random_state(mesh, ndof, seed=0):
+    rng = np.random.default_rng(seed)
+    N2, h = mesh.num_nodes, mesh.hmin()
+    U, U1 = np.zeros(ndof), np.zeros(ndof)
+    U[:3 * N2] = 0.02 * h * rng.standard_normal(3 * N2)
+    U1[:3 * N2] = U[:3 * N2] + 0.002 * h * rng.standard_normal(3 * N2)
+    U[3 * N2:6 * N2] = 0.1 * rng.standard_normal(3 * N2)
+    U1[3 * N2:6 * N2] = U[3 * N2:6 * N2] + 0.01 * rng.standard_normal(3 * N2)
+    U[6 * N2:] = 10 * rng.standard_normal(mesh.num_vertices)
+    return U, U1
+
+
+def boundary_data(case, t):
+    ns, desc, bc_values, pressure, hook = case
+    with contextlib.redirect_stdout(io.StringIO()):
+        ns["t"] = t
+        hook("pre_solve")(**ns)
+    return bc_values(), (float(pressure.P) if pressure is not None else 0.0)
+
+
+@pytest.fixture(scope="module")
+def cyl(cylinder_case):
+    from vasp_amd.capi import HipBackend
+    hb = HipBackend(cylinder_case[1])
+    yield hb
+    hb.close()
+
+
+@pytest.mark.parametrize("which", ["cylinder", "stenosis"])
+def test_residual_matches_oracle(which, cylinder_case, stenosis_case):
+    from oracle.fsi_oracle import FsiOracle
+    from vasp_amd.capi import HipBackend
+    case = cylinder_case if which == "cylinder" else stenosis_case
+    desc, mesh = case[1], case[0]["mesh"]
+    o = FsiOracle(desc)
+    hb = HipBackend(desc)
+    U, U1 = random_state(mesh, o.ndof)
+    g, P = boundary_data(case, 0.05)
+    hb.set_state("n", U); hb.set_state("n-1", U1); hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+    nrm = hb.assemble_residual()
+    b_ref = o.rhs(U, U1, P, g)
+    b = hb.get_state("b")
+    assert np.abs(b - b_ref).max() <= 1e-12 * np.abs(b_ref).max()          # round-off of a different summation order
+    assert np.isclose(nrm, np.linalg.norm(b_ref), rtol=1e-12)
+    assert np.array_equal(hb.get_state("n"), U)                             # user <-> solver permutation is lossless
+    hb.close()
+
+
+def test_jacobian_spmv_and_solve_match_oracle(cyl, cylinder_case):
+    import scipy.sparse.linalg as spla
+    from oracle.fsi_oracle import FsiOracle
+    desc, mesh = cylinder_case[1], cylinder_case[0]["mesh"]
+    o = FsiOracle(desc)
+    U, U1 = random_state(mesh, o.ndof, seed=1)
+    g, P = boundary_data(cylinder_case, 0.05)
+    cyl.set_state("n", U); cyl.set_state("n-1", U1); cyl.set_dirichlet_values(g); cyl.set_interface_pressure(P)
+    cyl.assemble_residual()
+    o.solver_setup(np.zeros(o.ndof), np.zeros(o.ndof))
+    A_ref = o.jacobian(U, U1)                                                # complex-step tangent, ident_zeros, bc rows
+    cyl.assemble_jacobian()
+    A = cyl.matrix()
+    rowmax = np.maximum(np.abs(A_ref).max(axis=1).toarray().ravel(), 1e-300)
+    rel = np.abs(A - A_ref).max(axis=1).toarray().ravel() / rowmax
+    assert rel.max() < 1e-11                                                # forward-mode vs complex-step, entries to 1e13
+    x = np.random.default_rng(2).standard_normal(o.ndof)
+    y = cyl.spmv(x)
+    assert np.abs(y - A_ref @ x).max() <= 1e-13 * np.abs(A_ref @ x).max() * 100
+    # zero rows -> identity (pressure dofs that touch only solid cells), Dirichlet rows -> identity
+    d = A.diagonal()
+    assert np.all(d[o.zero_rows] == 1.0) and np.all(d[o.bc_dofs] == 1.0)
+    b_ref = o.rhs(U, U1, P, g)
+    it, rr = cyl.solve(lin_rtol=1e-11)
+    du_ref = spla.splu(A_ref.tocsc()).solve(b_ref)
+    du = cyl.get_state("du")
+    assert np.linalg.norm(du - du_ref) <= 1e-6 * np.linalg.norm(du_ref)      # cond(A) ~ 1e12: LU itself carries ~1e-5
+
+
+def test_cylinder_three_steps_match_converged_golden(cylinder_case):
+    from vasp_amd.capi import HipBackend
+    ns, desc, bc_values, pressure, hook = cylinder_case
+    mesh = ns["mesh"]
+    gold = np.load(GOLDEN / "cylinder_tight.npz")["states"]
+    hb = HipBackend(desc, lin_rtol=1e-11)
+    N2 = mesh.num_nodes
+    for k in range(3):
+        g, P = boundary_data(cylinder_case, 1e-3 * (k + 1))
+        hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+        hist = hb.newton_solve(counter=k, first_step_num=0, atol=1e-11, rtol=1e-14, max_it=30, lmbda=1.0, recompute=20,
+                               recompute_tstep=20)
+        assert hist[-1][0] < 1e-11 or hist[-1][1] < 1e-14
+        hb.shift()
+        U = hb.get_state("n")
+        for name, sl in (("d", slice(0, 3 * N2)), ("v", slice(3 * N2, 6 * N2)), ("p", slice(6 * N2, None))):
+            err = np.linalg.norm(U[sl] - gold[k][sl]) / np.linalg.norm(gold[k][sl])
+            assert err < 1e-7, (k, name, err)                                # both sides solve F = 0 to 1e-11
+    hb.close()
+
+
+def test_offset_stenosis_known_answer_on_gpu(stenosis_case):
+    """The reference's primary known-answer test [REF tests/test_simulations.py:17-57] through the HIP path, with the
+    reference's Newton tolerances; compared with the pins at the oracle's tolerance."""
+    from test_oracle_pins import PIN_D, PIN_P, PIN_V, probe
+    from vasp_amd.capi import HipBackend
+    ns, desc, bc_values, pressure, hook = stenosis_case
+    mesh = ns["mesh"]
+    hb = HipBackend(desc, lin_rtol=1e-9)
+    for k in range(5):
+        g, P = boundary_data(stenosis_case, 0.01 * (k + 1))
+        hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+        hb.newton_solve(counter=k, first_step_num=0, atol=ns["atol"], rtol=ns["rtol"], max_it=ns["max_it"], lmbda=1.0,
+                        recompute=ns["recompute"], recompute_tstep=ns["recompute_tstep"])
+        hb.shift()
+    U = hb.get_state("n")
+    v = probe(mesh, U, ns["probe_points"][5], 1)
+    p = probe(mesh, U, ns["probe_points"][5], 2)
+    d = probe(mesh, U, ns["solid_probe_points"][5], 0)
+    assert np.abs(v - PIN_V).max() < 5e-5 * np.abs(PIN_V).max(), (v, PIN_V)
+    assert np.allclose(d, PIN_D, rtol=1e-5, atol=1e-8), (d, PIN_D)
+    assert abs(p - PIN_P) < 5e-4 * 1.6, (p, PIN_P)
+    gold = GOLDEN / "stenosis_ref.npz"
+    if gold.exists():
+        G = np.load(gold)["states"][4]
+        N2 = mesh.num_nodes
+        assert np.linalg.norm(U[3 * N2:6 * N2] - G[3 * N2:6 * N2]) < 2e-4 * np.linalg.norm(G[3 * N2:6 * N2])
+    hb.close()
+
+
+def test_robin_terms_match_oracle(tmp_path):
+    """aneurysm-style Robin boundary term on the outer wall [REF src/vasp/simulations/aneurysm.py:73-76]."""
+    from oracle.fsi_oracle import FsiOracle
+    from vasp_amd.capi import HipBackend
+    case = prepare_case("cylinder", GOLDEN / "cylinder" / "cylinder.h5", tmp_path)
+    ns, desc = case[0], dict(case[1])
+    mesh = ns["mesh"]
+    fids = np.nonzero(ns["boundaries"] == 33)[0]
+    desc["robin_facets"] = mesh.facet_nodes[fids]
+    desc["robin_k"] = np.full(len(fids), 1e5)
+    desc["robin_c"] = np.full(len(fids), 10.0)
+    o = FsiOracle(desc)
+    hb = HipBackend(desc)
+    U, U1 = random_state(mesh, o.ndof, seed=3)
+    g, P = boundary_data(case, 0.05)
+    hb.set_state("n", U); hb.set_state("n-1", U1); hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+    hb.assemble_residual()
+    b_ref = o.rhs(U, U1, P, g)
+    assert np.abs(hb.get_state("b") - b_ref).max() <= 1e-12 * np.abs(b_ref).max()
+    o.solver_setup(np.zeros(o.ndof), np.zeros(o.ndof))
+    A_ref = o.jacobian(U, U1)
+    hb.assemble_jacobian()
+    x = np.random.default_rng(4).standard_normal(o.ndof)
+    assert np.abs(hb.spmv(x) - A_ref @ x).max() <= 1e-11 * np.abs(A_ref @ x).max()
+    hb.close()
+
+
+def test_properties_on_generated_mesh(tmp_path):
+    """Size-independent properties on a synthetic ~50 k-tet offset stenosis (no oracle run at this size)."""
+    from vasp_amd.capi import HipBackend
+    from vasp_amd.meshgen import write_mesh
+    write_mesh(tmp_path / "s.h5", 50000)
+    case = prepare_case("offset_stenosis", tmp_path / "s.h5", tmp_path / "run", dt="0.001", T="0.002")
+    ns, desc = case[0], case[1]
+    mesh = ns["mesh"]
+    hb = HipBackend(desc)
+    # F(0; 0) = 0 with homogeneous data
+    hb.set_dirichlet_values(np.zeros(len(desc["bc_dofs"]))); hb.set_interface_pressure(0.0)
+    assert hb.assemble_residual() == 0.0
+    # SpMV is linear and reproducible
+    g, P = boundary_data(case, 1e-3)
+    hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+    hb.assemble_jacobian()
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(hb.ndof), rng.standard_normal(hb.ndof)
+    ax, ay, axy = hb.spmv(x), hb.spmv(y), hb.spmv(2 * x - 3 * y)
+    assert np.abs(axy - (2 * ax - 3 * ay)).max() <= 1e-12 * np.abs(axy).max()
+    assert np.array_equal(hb.spmv(x), ax)
+    # one time step: Newton residuals fall, and in the solid d = d1 + dt (theta v + (1 - theta) v1) holds nodally
+    hist = hb.newton_solve(counter=0, first_step_num=0, atol=1e-9, rtol=1e-12, max_it=20, lmbda=1.0, recompute=20,
+                           recompute_tstep=20)
+    res = [h[0] for h in hist]
+    assert res[-1] < 1e-3 * res[0]
+    U = hb.get_state("n")
+    d, v, _ = mesh.split(U)
+    solid_only = np.setdiff1d(np.unique(mesh.tet_nodes[mesh.cell_markers == 2]), np.unique(mesh.tet_nodes[mesh.cell_markers != 2]))
+    free = np.setdiff1d(solid_only, np.unique(desc["bc_dofs"][desc["bc_dofs"] < 3 * mesh.num_nodes] // 3))
+    assert np.abs(d[free] - 1e-3 * ns["theta"] * v[free]).max() <= 1e-6 * np.abs(d[free]).max()
+    hb.close()
+
+
+def test_error_behaviour(cyl, cylinder_case):
+    from vasp_amd.capi import FsiError
+    with pytest.raises(FsiError) as e:
+        cyl.set_dirichlet_values(np.zeros(3))                                # wrong length
+    assert e.value.code == 1
+    # a non-finite state makes the Newton loop report divergence, as the reference's RuntimeError
+    U = np.zeros(cyl.ndof)
+    U[5] = np.nan
+    cyl.set_state("n", U)
+    g, P = boundary_data(cylinder_case, 1e-3)
+    cyl.set_dirichlet_values(g)
+    with pytest.raises((RuntimeError, FsiError)):
+        cyl.newton_solve(counter=0, first_step_num=0, atol=1e-6, rtol=1e-6, max_it=3, lmbda=1.0, recompute=20, recompute_tstep=20)
+    cyl.set_state("n", np.zeros(cyl.ndof)); cyl.set_state("n-1", np.zeros(cyl.ndof))

@@ -276,6 +276,59 @@ void launch_pres_rows(hipStream_t st, int64_t V, const int64_t* rowptr_pp, const
   hipLaunchKernelGGL(k_pres_rows, dim3((unsigned)blocks), dim3(256), 0, st, V, rowptr_pp, cols_pp, App, x, alpha, rowptr_pv,
                      cols_pv, Apv, w, beta, c, gamma, y);
 }
+// ---- Chebyshev semi-iteration on a masked part of the velocity block, Jacobi-scaled -------------------------------------------
+// No inner products: a solve is a pure stream of SpMV + one fused vector kernel, nothing returns to the host.
+//   init : x = 0, r = mask .* rhs, d = r / (D theta)
+//   step : x += d; r -= mask .* t (t = A d); d = c1 d + c2 r / D
+__global__ void k_cheb_init(int64_t n, const double* __restrict__ mask, const double* __restrict__ rhs,
+                            const int64_t* __restrict__ diagpos, const double* __restrict__ A, double inv_theta,
+                            double* __restrict__ x, double* __restrict__ r, double* __restrict__ d) {
+  GS(i, n) {
+    const double ri = mask[i] * rhs[i];
+    x[i] = 0.0;
+    r[i] = ri;
+    d[i] = ri * inv_theta / A[diagpos[i]];
+  }
+}
+__global__ void k_cheb_step(int64_t n, const double* __restrict__ mask, const double* __restrict__ t,
+                            const int64_t* __restrict__ diagpos, const double* __restrict__ A, double c1, double c2,
+                            double* __restrict__ x, double* __restrict__ r, double* __restrict__ d) {
+  GS(i, n) {
+    const double di = d[i];
+    const double ri = r[i] - mask[i] * t[i];
+    x[i] += di;
+    r[i] = ri;
+    d[i] = c1 * di + c2 * ri / A[diagpos[i]];
+  }
+}
+void launch_cheb_init(hipStream_t st, int64_t n, const double* mask, const double* rhs, const int64_t* diagpos,
+                      const double* A, double inv_theta, double* x, double* r, double* d) {
+  hipLaunchKernelGGL(k_cheb_init, dim3(gridn(n)), dim3(256), 0, st, n, mask, rhs, diagpos, A, inv_theta, x, r, d);
+}
+void launch_cheb_step(hipStream_t st, int64_t n, const double* mask, const double* t, const int64_t* diagpos,
+                      const double* A, double c1, double c2, double* x, double* r, double* d) {
+  hipLaunchKernelGGL(k_cheb_step, dim3(gridn(n)), dim3(256), 0, st, n, mask, t, diagpos, A, c1, c2, x, r, d);
+}
+// y = mask .* (A x) ./ D   (power iteration for the largest eigenvalue of the Jacobi-scaled block)
+__global__ void k_mask_scale(int64_t n, const double* __restrict__ mask, const int64_t* __restrict__ diagpos,
+                             const double* __restrict__ A, double* __restrict__ y) {
+  GS(i, n) y[i] = mask[i] * y[i] / A[diagpos[i]];
+}
+// x = mask .* (pseudo-random +-1 ripple): start vector of the power iteration, rich in element-scale modes
+__global__ void k_mask_ripple(int64_t n, const double* __restrict__ mask, double* __restrict__ x) {
+  GS(i, n) {
+    uint64_t h = (uint64_t)i * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    x[i] = mask[i] * (((double)(h & 0xFFFF) / 65535.0) - 0.5);
+  }
+}
+void launch_mask_ripple(hipStream_t st, int64_t n, const double* mask, double* x) {
+  hipLaunchKernelGGL(k_mask_ripple, dim3(gridn(n)), dim3(256), 0, st, n, mask, x);
+}
+void launch_mask_scale(hipStream_t st, int64_t n, const double* mask, const int64_t* diagpos, const double* A, double* y) {
+  hipLaunchKernelGGL(k_mask_scale, dim3(gridn(n)), dim3(256), 0, st, n, mask, diagpos, A, y);
+}
+
 // y = b - A x, one wave per row (generic CSR)
 __global__ __launch_bounds__(256) void k_residual_csr(int64_t n, const int64_t* __restrict__ rowptr,
                                                       const int32_t* __restrict__ cols, const double* __restrict__ vals,

@@ -140,6 +140,43 @@ int inner_bicgstab(FsiCtx* ctx, const SubMat& M, Apply&& apply, const double* rh
   return FSI_OK;
 }
 
+// Chebyshev solve of the masked velocity block (see fsi_block.hip); W: 2 work vectors (r, t) + d
+void cheb_solve(FsiCtx* ctx, const double* mask, const double* rhs, double* x, double* W, int its, double lmax, double kappa) {
+  const int64_t n = 3 * ctx->N2;
+  hipStream_t st = ctx->stream;
+  double *r = W, *d = W + n, *t = W + 2 * n;
+  const double lmin = lmax / kappa, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
+  double rho = 1.0 / sig;
+  launch_cheb_init(st, n, mask, rhs, ctx->diagpos3.p, ctx->Mvv.vals.p, 1.0 / th, x, r, d);
+  for (int k = 0; k < its; ++k) {
+    launch_spmv(st, n, ctx->rowptr3.p, ctx->cols3.p, ctx->Mvv.vals.p, d, t);
+    const double rn = 1.0 / (2.0 * sig - rho);
+    launch_cheb_step(st, n, mask, t, ctx->diagpos3.p, ctx->Mvv.vals.p, rn * rho, 2.0 * rn / de, x, r, d);
+    rho = rn;
+  }
+}
+// largest eigenvalue of mask D^-1 Avv~ mask by power iteration (start vector: the mask itself plus a ripple)
+int power_lmax(FsiCtx* ctx, const double* mask, double* W, double* out) {
+  const int64_t n = 3 * ctx->N2;
+  hipStream_t st = ctx->stream;
+  double *x = W, *y = W + n;
+  launch_mask_ripple(st, n, mask, x);
+  double lam = 1.0;
+  for (int k = 0; k < 40; ++k) {
+    launch_spmv(st, n, ctx->rowptr3.p, ctx->cols3.p, ctx->Mvv.vals.p, x, y);
+    launch_mask_scale(st, n, mask, ctx->diagpos3.p, ctx->Mvv.vals.p, y);
+    double xx = 0.0, yy = 0.0;
+    FSICHK(dot_n(ctx, x, x, n, &xx));
+    FSICHK(dot_n(ctx, y, y, n, &yy));
+    if (!(xx > 0.0) || !(yy > 0.0) || !std::isfinite(yy)) break;
+    lam = std::sqrt(yy / xx);
+    launch_copy(st, x, y, n);
+    launch_scale(st, x, 1.0 / std::sqrt(yy), n);
+  }
+  *out = 1.2 * lam;
+  return FSI_OK;
+}
+
 // z = M^-1 r with the approximate block factorisation (see fsi_block.hip):  (v,p) by SIMPLE with the d-eliminated
 // velocity block, then d.
 int precondition_block(FsiCtx* ctx, const double* r, double* z) {
@@ -149,10 +186,15 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   double *rd = W, *rv = W + n3, *rp = W + 2 * n3, *vs = W + 3 * n3, *tp = W + 4 * n3, *dp = W + 5 * n3, *dv = W + 6 * n3,
          *td = W + 7 * n3, *dd = W + 8 * n3, *IW = W + 9 * n3, *w3 = W + 17 * n3;
   launch_split(st, N2, V, r, rd, rv, rp);
-  // velocity predictor
-  FSICHK(inner_bicgstab(ctx, ctx->Mvv,
-                        [&](const double* in, double* out) { launch_spmv(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Mvv.vals.p, in, out); },
-                        rv, vs, IW, ctx->inner_rtol, ctx->inner_maxit, &ctx->inner_its[0]));
+  // velocity predictor: block Gauss-Seidel solid (elasticity-dominated, many cheap sweeps) -> fluid interior (mass-dominated)
+  {
+    double *xs = IW + 3 * n3, *xf = IW + 4 * n3, *rhs2 = IW + 5 * n3;
+    cheb_solve(ctx, ctx->mask_s.p, rv, xs, IW, ctx->cheb_its_s, ctx->lmax_s, ctx->cheb_kappa_s);
+    launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Mvv.vals.p, xs, rv, rhs2);
+    cheb_solve(ctx, ctx->mask_f.p, rhs2, xf, IW, ctx->cheb_its_f, ctx->lmax_f, ctx->cheb_kappa_f);
+    launch_axpby(st, vs, 1.0, xs, 1.0, xf, n3);
+    ctx->inner_its[0] += ctx->cheb_its_s + ctx->cheb_its_f;
+  }
   // pressure: S dp = rp - Apv~ vs,  S x = App x - Apv~ D^-1 Avp x
   launch_pres_rows(st, V, ctx->rowptr_pp.p, ctx->cols_pp.p, ctx->App.p, nullptr, 0.0, ctx->rowptr_pv.p, ctx->cols_pv.p,
                    ctx->Apv.p, vs, -1.0, rp, 1.0, tp);
@@ -325,7 +367,9 @@ int refresh_preconditioner(FsiCtx* ctx) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
     if (flags[1] & 4) { ctx->err = "Schur complement: a vertex has more than 512 vertex neighbours"; return FSI_ERR_INVALID; }
-    for (SubMat* M : {&ctx->Mdd, &ctx->Mvv, &ctx->Ms}) {
+    FSICHK(power_lmax(ctx, ctx->mask_s.p, ctx->blk.p, &ctx->lmax_s));
+    FSICHK(power_lmax(ctx, ctx->mask_f.p, ctx->blk.p, &ctx->lmax_f));
+    for (SubMat* M : {&ctx->Mdd, &ctx->Ms}) {
       HIPCHK(hipMemcpyAsync(M->LU.p, M->vals.p, M->nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
       launch_ilu0_levels(st, M->levels, M->rowptr, M->cols, M->diagpos, M->LU.p, ctx->iflags.p);
       HIPCHK(hipGetLastError());
@@ -383,7 +427,7 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->enbr.release();
   ctx->epnbr.release();
   for (auto* b : {&ctx->Adv, &ctx->Avp, &ctx->Apv, &ctx->App, &ctx->blk, &ctx->Mdd.vals, &ctx->Mdd.LU, &ctx->Mvv.vals,
-                  &ctx->Mvv.LU, &ctx->Ms.vals, &ctx->Ms.LU}) b->release();
+                  &ctx->Mvv.LU, &ctx->Ms.vals, &ctx->Ms.LU, &ctx->mask_s, &ctx->mask_f}) b->release();
   for (auto* b : {&ctx->node_solid, &ctx->vrank, &ctx->cols3, &ctx->cols_vp, &ctx->cols_pv, &ctx->cols_pp}) b->release();
   for (auto* b : {&ctx->rowptr3, &ctx->diagpos3, &ctx->rowptr_vp, &ctx->rowptr_pv, &ctx->rowptr_pp, &ctx->diagpos_pp}) b->release();
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -654,6 +698,17 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
       if (mesh->cell_kind[c] == 1)
         for (int a = 0; a < 10; ++a) node_solid[rk[tn[10 * c + a]]] = 1;
     FSICHK(upload(ctx, ctx->node_solid, node_solid));
+    {
+      std::vector<double> ms(3 * N2), mf(3 * N2);
+      for (int64_t r = 0; r < N2; ++r)
+        for (int i = 0; i < 3; ++i) { ms[3 * r + i] = node_solid[r] ? 1.0 : 0.0; mf[3 * r + i] = node_solid[r] ? 0.0 : 1.0; }
+      FSICHK(upload(ctx, ctx->mask_s, ms));
+      FSICHK(upload(ctx, ctx->mask_f, mf));
+      if (const char* e = getenv("FSI_CHEB_S")) ctx->cheb_its_s = atoi(e);
+      if (const char* e = getenv("FSI_CHEB_F")) ctx->cheb_its_f = atoi(e);
+      if (const char* e = getenv("FSI_KAPPA_S")) ctx->cheb_kappa_s = atof(e);
+      if (const char* e = getenv("FSI_KAPPA_F")) ctx->cheb_kappa_f = atof(e);
+    }
     const int64_t nadj_total = ctx->h_nadj_ptr[N2], padj_total = ctx->h_padj_ptr[N2];
     std::vector<int64_t> rowptr_pv(V + 1, 0), rowptr_pp(V + 1, 0), diagpos_pp(V, 0);
     for (int64_t q = 0; q < V; ++q) {
@@ -694,7 +749,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
       M->n = 3 * N2; M->nnz = 9 * nadj_total;
       M->rowptr = ctx->rowptr3.p; M->cols = ctx->cols3.p; M->diagpos = ctx->diagpos3.p;
       HIPCHK(M->vals.alloc(M->nnz));
-      HIPCHK(M->LU.alloc(M->nnz));
+      if (M == &ctx->Mdd) HIPCHK(M->LU.alloc(M->nnz));
     }
     ctx->Ms.n = V; ctx->Ms.nnz = rowptr_pp[V];
     ctx->Ms.rowptr = ctx->rowptr_pp.p; ctx->Ms.cols = ctx->cols_pp.p; ctx->Ms.diagpos = ctx->diagpos_pp.p;

@@ -86,6 +86,12 @@ void launch_vel_correct(hipStream_t st, int64_t n3, const int64_t* rowptr, const
 void launch_pres_rows(hipStream_t st, int64_t V, const int64_t* rowptr_pp, const int32_t* cols_pp, const double* App,
                       const double* x, double alpha, const int64_t* rowptr_pv, const int32_t* cols_pv, const double* Apv,
                       const double* w, double beta, const double* c, double gamma, double* y);
+void launch_cheb_init(hipStream_t st, int64_t n, const double* mask, const double* rhs, const int64_t* diagpos,
+                      const double* A, double inv_theta, double* x, double* r, double* d);
+void launch_cheb_step(hipStream_t st, int64_t n, const double* mask, const double* t, const int64_t* diagpos,
+                      const double* A, double c1, double c2, double* x, double* r, double* d);
+void launch_mask_ripple(hipStream_t st, int64_t n, const double* mask, double* x);
+void launch_mask_scale(hipStream_t st, int64_t n, const double* mask, const int64_t* diagpos, const double* A, double* y);
 void launch_residual_csr(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const double* vals,
                          const double* x, const double* b, double* y);
 
