@@ -76,14 +76,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
     import torch
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    from vasp_amd.dist import aggregate, init_from_env
+    rank, local_rank, world, dist = init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -140,15 +135,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     tm = hb.timers()
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        nn = torch.tensor([n_newton], dtype=torch.float64, device="cuda")
-        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
-        total_newton = float(nn.item())
-    else:
-        total_newton = float(n_newton)
+    elapsed, total_newton = aggregate(dist, elapsed, n_newton, device="cuda")
 
     if rank == 0:
         ndof, nnz = hb.ndof, int(hb.lib.fsi_matrix_nnz(hb.ctx))

@@ -1,0 +1,152 @@
+"""Host side of the boundary: CLI, parameter handling, hooks, boundary data and log grammar of the re-hosted problem
+files (mirrors what VaSP's own tests observe through stdout; REF tests/test_simulations.py, log_plotter.py:71-82)."""
+import contextlib
+import io
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from vasp_amd import monolithic
+from vasp_amd.simulation_common import InterfacePressure
+
+# the reference's log grammar [REF src/vasp/postprocessing/log_plotter.py:71-81]
+TIME_STEP = re.compile(r"Solved for timestep (.*), t = (.*) in (.*) s")
+RAMP = re.compile(r"ramp_factor = (.*) m\^3/s")
+PRESSURE = re.compile(r"Instantaneous normal stress prescribed at the FSI interface (.*) Pa")
+NEWTON = re.compile(r'Newton iteration (.*): r \(atol\) = (.*) \(tol = .*\), r \(rel\) = (.*) \(tol = .*\)')
+PROBE = re.compile(r"Probe Point (.*): Velocity: \((.*), (.*), (.*)\) \| Pressure: (.*)")
+PROBE_D = re.compile(r"Probe Point (.*): Displacement: \((.*), (.*), (.*)\)")
+FLOW = re.compile(r"\s*Flow Rate at Inlet: (.*)")
+VEL = re.compile(r"\s*Velocity \(mean, min, max\): (.*), (.*), (.*)")
+CFL = re.compile(r"\s*CFL \(mean, min, max\): (.*), (.*), (.*)")
+RE = re.compile(r"\s*Reynolds Numbers \(mean, min, max\): (.*), (.*), (.*)")
+
+
+def test_cli_matches_the_reference_invocation():
+    # REF tests/test_simulations.py:22-23
+    a = monolithic.parse("-p offset_stenosis -dt 0.01 -T 0.04 --verbose True --theta 0.51 --folder tmp --sub-folder 1 "
+                         "--new-arguments mesh_path=some/mesh.h5 inlet_id=4".split())
+    assert a == dict(problem="offset_stenosis", dt=0.01, T=0.04, verbose=True, theta=0.51, folder="tmp", sub_folder="1",
+                     mesh_path="some/mesh.h5", inlet_id=4)
+    with pytest.raises(SystemExit):
+        monolithic.parse(["--new-arguments", "novalue"])
+
+
+def test_problem_parameters_offset_stenosis():
+    # REF src/vasp/simulations/offset_stenosis.py:27-82
+    from vasp_amd.problems import default_variables, offset_stenosis
+    v = offset_stenosis.set_problem_parameters(dict(default_variables))
+    assert v["mu_s"] == pytest.approx(1e6 / 2.9) and v["lambda_s"] == pytest.approx(0.45 * 2 * (1e6 / 2.9) / 0.1)
+    assert (v["atol"], v["rtol"], v["recompute"], v["recompute_tstep"]) == (1e-6, 1e-6, 20, 20)
+    assert v["dx_f_id"] == [1, 1001] and v["mu_f"] == [1.5e-3, 1.0e-2] and v["fsi_region"] == [0.008, 0, 0, 0.008]
+    # key set / order of turtleFSI's default_variables [REF tests/test_data/hemodynamics_data/Checkpoint/default_variables.json]
+    keys = list(default_variables)
+    assert keys[:8] == ["dt", "theta", "T", "t", "counter", "v_deg", "p_deg", "d_deg"]
+    assert keys.index("atol") < keys.index("rtol") < keys.index("max_it") < keys.index("lmbda") < keys.index("recompute")
+    monolithic.build_properties(v)
+    assert v["fluid_properties"] == [dict(dx_f_id=1, rho_f=1e3, mu_f=1.5e-3), dict(dx_f_id=1001, rho_f=1e3, mu_f=1e-2)]
+    assert v["solid_properties"][0]["material_model"] == "StVenantKirchoff"
+
+
+def test_boundary_conditions_offset_stenosis(stenosis_case):
+    ns, desc, bc_values, pressure, hook = stenosis_case
+    mesh = ns["mesh"]
+    N2 = mesh.num_nodes
+    bcs = ns["bcs"]
+    assert [(b.space.field, b.space.comp, b.marker) for b in bcs] == \
+        [(1, 0, 3), (1, 1, 3), (1, 2, 3), (0, None, 3), (1, None, 11), (0, None, 11), (0, None, 11)]  # REF :170-179
+    dofs = desc["bc_dofs"]
+    assert len(np.unique(dofs)) == len(dofs) and dofs.max() < 6 * N2          # no pressure Dirichlet conditions
+    # '+' side of the interface facets is the solid cell [REF :189]
+    assert np.all(ns["domains"][desc["pressure_facet_cell"]] == 2) and len(desc["pressure_facets"]) == 290
+    # inlet flux of the Womersley profile equals the prescribed flow rate Q(t) (ramped), up to the P2 interpolation
+    with contextlib.redirect_stdout(io.StringIO()):
+        ns["t"] = 0.3
+        hook("pre_solve")(**ns)
+    g = np.zeros(mesh.num_dofs)
+    g[dofs] = bc_values()
+    from vasp_amd.simulation_common import inlet_flux
+    An, Bn = np.loadtxt(GOLDEN.parent.parent / "vasp_amd" / "problems" / "FC_MCA_10").T
+    w = 2 * np.pi / 0.951
+    Q = np.real(np.sum((An - 1j * Bn) * 2.5e-6 * np.exp(1j * np.arange(len(An)) * w * 0.3)))
+    flux = -inlet_flux(mesh, mesh.split(g)[1], ns["dsi"])
+    assert flux == pytest.approx(Q, rel=2e-2)
+    # later conditions win on shared dofs: inlet rim nodes (also on the solid end, marker 11) carry zero velocity
+    rim = np.intersect1d(np.unique(mesh.facet_nodes[ns["boundaries"] == 3]), np.unique(mesh.facet_nodes[ns["boundaries"] == 11]))
+    assert len(rim) and np.all(mesh.split(g)[1][rim] == 0.0)
+
+
+def test_interface_pressure_formula():
+    # REF src/vasp/simulations/simulation_common.py:371-395
+    An, Bn = np.array([1.0, 0.1, -0.05]), np.array([0.0, 0.02, 0.03])
+    ip = InterfacePressure(t=0.0, t_ramp_start=0.0, t_ramp_end=0.2, An=An, Bn=Bn, period=0.951, P_mean=11200)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ip.update(0.05)
+    ramp = 0.5 - 0.5 * np.cos(np.pi * 0.25)
+    Pn = abs(sum((An[i] - 1j * Bn[i]) * np.exp(1j * i * 2 * np.pi / 0.951 * 0.05) for i in range(3)))
+    assert ip.P == pytest.approx(ramp * Pn * 11200, rel=1e-14)
+    lines = buf.getvalue().splitlines()
+    assert RAMP.match(lines[0]) and PRESSURE.match(lines[1])
+    with contextlib.redirect_stdout(io.StringIO()):
+        ip.update(0.5)
+    assert ip.P == pytest.approx(abs(sum((An[i] - 1j * Bn[i]) * np.exp(1j * i * 2 * np.pi / 0.951 * 0.5) for i in range(3))) * 11200)
+
+
+def test_time_loop_and_log_grammar_with_a_stub_backend(tmp_path):
+    """Hook order, number of steps (T/dt + 1, as `while t <= T + dt/10`) and every log line the reference's
+    log plotter parses - driven with a backend stub, so no GPU and no oracle is involved."""
+    calls = []
+
+    class Stub:
+        def __init__(self, desc):
+            self.n = 6 * desc["num_nodes"] + len(desc["coords"])
+            self.x = np.zeros(self.n)
+        def set_dirichlet_values(self, v): calls.append("bc")
+        def set_interface_pressure(self, P): calls.append("P")
+        def newton_solve(self, *, log=None, atol, rtol, **kw):
+            calls.append(("newton", kw["counter"], kw["first_step_num"]))
+            if log:
+                log("Compute Jacobian matrix")
+                log("Newton iteration %d: r (atol) = %.3e (tol = %.3e), r (rel) = %.3e (tol = %.3e) " % (0, 1e-3, atol, 1e-7, rtol))
+            return [(1e-3, 1e-7, True)]
+        def shift(self): calls.append("shift")
+        def get_state(self, which, out): out[:] = 1e-6; return out
+
+    lines = []
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ns = monolithic.run(["-p", "offset_stenosis", "-dt", "0.01", "-T", "0.02", "--theta", "0.51", "--folder", str(tmp_path),
+                             "--sub-folder", "1", "--new-arguments",
+                             f"mesh_path={GOLDEN / 'offset_stenosis' / 'offset_stenosis.h5'}"], backend_factory=Stub, out=lines.append)
+    assert [c for c in calls if isinstance(c, tuple)] == [("newton", 0, 0), ("newton", 1, 0), ("newton", 2, 0)]
+    assert calls[:4] == ["bc", "P", ("newton", 0, 0), "shift"]
+    assert ns["counter"] == 3 and ns["newton_iterations"] == 3
+    solved = [TIME_STEP.match(l) for l in lines if l.startswith("Solved")]
+    assert [int(m.group(1)) for m in solved] == [1, 2, 3] and [float(m.group(2)) for m in solved] == [0.01, 0.02, 0.03]
+    assert sum(bool(NEWTON.match(l)) for l in lines) == 3
+    out = buf.getvalue().splitlines()
+    for pat, count in ((RAMP, 3), (PRESSURE, 3), (PROBE, 3 * 7), (PROBE_D, 3 * 50), (FLOW, 3), (VEL, 3), (CFL, 3), (RE, 3)):
+        assert sum(bool(pat.match(l)) for l in out) == count, pat.pattern
+    assert sum(l.startswith("Minimum Jacobian: ") for l in out) == 3       # the solver's spelling [REF simulation_common.py:343]
+    # output tree [REF docs/offset_stenosis.md:209-228] and the relabelled mesh file the post-processing tools read
+    from vasp_amd.h5lite import read_h5
+    g = read_h5(tmp_path / "1" / "Mesh" / "mesh.h5")
+    vals = np.asarray(g["domains"]["values"].data)
+    assert (vals == 1001).sum() == 77 and (tmp_path / "1" / "Checkpoint").is_dir() and (tmp_path / "1" / "Visualization").is_dir()
+
+
+def test_cylinder_hooks(cylinder_case):
+    ns, desc, bc_values, pressure, hook = cylinder_case
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ns["t"] = 0.05
+        hook("pre_solve")(**ns)
+    assert pressure.P == pytest.approx(0.5 * 10000)                       # cosine ramp half way [REF cylinder.py:133-157]
+    assert "v (centerline, at inlet) = 0.37" in buf.getvalue() and " m/s" in buf.getvalue()
+    g = np.zeros(ns["mesh"].num_dofs)
+    g[desc["bc_dofs"]] = bc_values()
+    v = ns["mesh"].split(g)[1]
+    assert np.abs(v).max() == pytest.approx(0.375, rel=0.05)               # parabola peak at the inlet centre

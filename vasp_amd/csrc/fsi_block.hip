@@ -284,7 +284,7 @@ __global__ void k_cheb_init(int64_t n, const double* __restrict__ mask, const do
                             const int64_t* __restrict__ diagpos, const double* __restrict__ A, double inv_theta,
                             double* __restrict__ x, double* __restrict__ r, double* __restrict__ d) {
   GS(i, n) {
-    const double ri = mask[i] * rhs[i];
+    const double ri = mask ? mask[i] * rhs[i] : rhs[i];
     x[i] = 0.0;
     r[i] = ri;
     d[i] = ri * inv_theta / A[diagpos[i]];
@@ -295,7 +295,7 @@ __global__ void k_cheb_step(int64_t n, const double* __restrict__ mask, const do
                             double* __restrict__ x, double* __restrict__ r, double* __restrict__ d) {
   GS(i, n) {
     const double di = d[i];
-    const double ri = r[i] - mask[i] * t[i];
+    const double ri = r[i] - (mask ? mask[i] * t[i] : t[i]);
     x[i] += di;
     r[i] = ri;
     d[i] = c1 * di + c2 * ri / A[diagpos[i]];
@@ -312,14 +312,33 @@ void launch_cheb_step(hipStream_t st, int64_t n, const double* mask, const doubl
 // y = mask .* (A x) ./ D   (power iteration for the largest eigenvalue of the Jacobi-scaled block)
 __global__ void k_mask_scale(int64_t n, const double* __restrict__ mask, const int64_t* __restrict__ diagpos,
                              const double* __restrict__ A, double* __restrict__ y) {
-  GS(i, n) y[i] = mask[i] * y[i] / A[diagpos[i]];
+  GS(i, n) y[i] = (mask ? mask[i] : 1.0) * y[i] / A[diagpos[i]];
+}
+// compact solid block: values gathered from Avv~ (vals[e] = src[pos[e]]), vectors gathered / scattered by node list
+__global__ void k_gather_vals(int64_t n, const int64_t* __restrict__ pos, const double* __restrict__ src, double* __restrict__ dst) {
+  GS(e, n) dst[e] = src[pos[e]];
+}
+__global__ void k_gather3(int64_t nS, const int32_t* __restrict__ snode, const double* __restrict__ full, double* __restrict__ comp) {
+  GS(t, 3 * nS) comp[t] = full[3 * (int64_t)snode[t / 3] + t % 3];
+}
+__global__ void k_scatter3(int64_t nS, const int32_t* __restrict__ snode, const double* __restrict__ comp, double* __restrict__ full) {
+  GS(t, 3 * nS) full[3 * (int64_t)snode[t / 3] + t % 3] = comp[t];
+}
+void launch_gather_vals(hipStream_t st, int64_t n, const int64_t* pos, const double* src, double* dst) {
+  hipLaunchKernelGGL(k_gather_vals, dim3(gridn(n)), dim3(256), 0, st, n, pos, src, dst);
+}
+void launch_gather3(hipStream_t st, int64_t nS, const int32_t* snode, const double* full, double* comp) {
+  hipLaunchKernelGGL(k_gather3, dim3(gridn(3 * nS)), dim3(256), 0, st, nS, snode, full, comp);
+}
+void launch_scatter3(hipStream_t st, int64_t nS, const int32_t* snode, const double* comp, double* full) {
+  hipLaunchKernelGGL(k_scatter3, dim3(gridn(3 * nS)), dim3(256), 0, st, nS, snode, comp, full);
 }
 // x = mask .* (pseudo-random +-1 ripple): start vector of the power iteration, rich in element-scale modes
 __global__ void k_mask_ripple(int64_t n, const double* __restrict__ mask, double* __restrict__ x) {
   GS(i, n) {
     uint64_t h = (uint64_t)i * 0x9E3779B97F4A7C15ull;
     h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
-    x[i] = mask[i] * (((double)(h & 0xFFFF) / 65535.0) - 0.5);
+    x[i] = (mask ? mask[i] : 1.0) * (((double)(h & 0xFFFF) / 65535.0) - 0.5);
   }
 }
 void launch_mask_ripple(hipStream_t st, int64_t n, const double* mask, double* x) {

@@ -141,30 +141,41 @@ int inner_bicgstab(FsiCtx* ctx, const SubMat& M, Apply&& apply, const double* rh
 }
 
 // Chebyshev solve of the masked velocity block (see fsi_block.hip); W: 2 work vectors (r, t) + d
-void cheb_solve(FsiCtx* ctx, const double* mask, const double* rhs, double* x, double* W, int its, double lmax, double kappa) {
-  const int64_t n = 3 * ctx->N2;
+struct CsrRef { int64_t n; const int64_t* rowptr; const int32_t* cols; const double* vals; const int64_t* diagpos; };
+// Chebyshev solve with a Jacobi scaling taken from (dvals, diagpos); `apply(in, out)` is the operator. W: 3 work vectors.
+template <class Apply>
+void cheb_solve_op(FsiCtx* ctx, int64_t n, Apply&& apply, const double* dvals, const int64_t* diagpos, const double* mask,
+                   const double* rhs, double* x, double* W, int its, double lmax, double kappa) {
   hipStream_t st = ctx->stream;
   double *r = W, *d = W + n, *t = W + 2 * n;
   const double lmin = lmax / kappa, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
   double rho = 1.0 / sig;
-  launch_cheb_init(st, n, mask, rhs, ctx->diagpos3.p, ctx->Mvv.vals.p, 1.0 / th, x, r, d);
+  launch_cheb_init(st, n, mask, rhs, diagpos, dvals, 1.0 / th, x, r, d);
   for (int k = 0; k < its; ++k) {
-    launch_spmv(st, n, ctx->rowptr3.p, ctx->cols3.p, ctx->Mvv.vals.p, d, t);
+    apply(d, t);
     const double rn = 1.0 / (2.0 * sig - rho);
-    launch_cheb_step(st, n, mask, t, ctx->diagpos3.p, ctx->Mvv.vals.p, rn * rho, 2.0 * rn / de, x, r, d);
+    launch_cheb_step(st, n, mask, t, diagpos, dvals, rn * rho, 2.0 * rn / de, x, r, d);
     rho = rn;
   }
 }
-// largest eigenvalue of mask D^-1 Avv~ mask by power iteration (start vector: the mask itself plus a ripple)
-int power_lmax(FsiCtx* ctx, const double* mask, double* W, double* out) {
-  const int64_t n = 3 * ctx->N2;
+void cheb_solve(FsiCtx* ctx, const CsrRef& M, const double* mask, const double* rhs, double* x, double* W, int its,
+                double lmax, double kappa) {
+  cheb_solve_op(ctx, M.n, [&](const double* in, double* out) { launch_spmv(ctx->stream, M.n, M.rowptr, M.cols, M.vals, in, out); },
+                M.vals, M.diagpos, mask, rhs, x, W, its, lmax, kappa);
+}
+CsrRef vv_ref(FsiCtx* c) { return CsrRef{3 * c->N2, c->rowptr3.p, c->cols3.p, c->Mvv.vals.p, c->diagpos3.p}; }
+CsrRef ss_ref(FsiCtx* c) { return CsrRef{3 * c->nS, c->ss_rowptr.p, c->ss_cols.p, c->ss_vals.p, c->ss_diagpos.p}; }
+// largest eigenvalue of mask D^-1 A mask by power iteration from a pseudo-random start (rich in element-scale modes)
+template <class Apply>
+int power_lmax_op(FsiCtx* ctx, int64_t n, Apply&& apply, const double* dvals, const int64_t* diagpos, const double* mask,
+                  double* W, double* out) {
   hipStream_t st = ctx->stream;
   double *x = W, *y = W + n;
   launch_mask_ripple(st, n, mask, x);
   double lam = 1.0;
   for (int k = 0; k < 40; ++k) {
-    launch_spmv(st, n, ctx->rowptr3.p, ctx->cols3.p, ctx->Mvv.vals.p, x, y);
-    launch_mask_scale(st, n, mask, ctx->diagpos3.p, ctx->Mvv.vals.p, y);
+    apply(x, y);
+    launch_mask_scale(st, n, mask, diagpos, dvals, y);
     double xx = 0.0, yy = 0.0;
     FSICHK(dot_n(ctx, x, x, n, &xx));
     FSICHK(dot_n(ctx, y, y, n, &yy));
@@ -175,6 +186,18 @@ int power_lmax(FsiCtx* ctx, const double* mask, double* W, double* out) {
   }
   *out = 1.2 * lam;
   return FSI_OK;
+}
+int power_lmax(FsiCtx* ctx, const CsrRef& M, const double* mask, double* W, double* out) {
+  return power_lmax_op(ctx, M.n, [&](const double* in, double* o) { launch_spmv(ctx->stream, M.n, M.rowptr, M.cols, M.vals, in, o); },
+                       M.vals, M.diagpos, mask, W, out);
+}
+// Schur operator y = (A_pp - Apv~ D^-1 A_vp) x ; w3: work vector of length 3 N2
+void schur_apply(FsiCtx* ctx, const double* in, double* out, double* w3) {
+  const int64_t n3 = 3 * ctx->N2;
+  launch_vel_correct(ctx->stream, n3, ctx->rowptr_vp.p, ctx->cols_vp.p, ctx->Avp.p, in, ctx->diagpos3.p, ctx->Mvv.vals.p,
+                     nullptr, w3);
+  launch_pres_rows(ctx->stream, ctx->V, ctx->rowptr_pp.p, ctx->cols_pp.p, ctx->App.p, in, 1.0, ctx->rowptr_pv.p,
+                   ctx->cols_pv.p, ctx->Apv.p, w3, 1.0, nullptr, 0.0, out);
 }
 
 // z = M^-1 r with the approximate block factorisation (see fsi_block.hip):  (v,p) by SIMPLE with the d-eliminated
@@ -189,23 +212,27 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   // velocity predictor: block Gauss-Seidel solid (elasticity-dominated, many cheap sweeps) -> fluid interior (mass-dominated)
   {
     double *xs = IW + 3 * n3, *xf = IW + 4 * n3, *rhs2 = IW + 5 * n3;
-    cheb_solve(ctx, ctx->mask_s.p, rv, xs, IW, ctx->cheb_its_s, ctx->lmax_s, ctx->cheb_kappa_s);
+    double *cs_rhs = IW + 6 * n3, *cs_x = IW + 7 * n3;            // compact solid vectors (3 nS <= n3)
+    launch_gather3(st, ctx->nS, ctx->snode.p, rv, cs_rhs);
+    cheb_solve(ctx, ss_ref(ctx), nullptr, cs_rhs, cs_x, IW, ctx->cheb_its_s, ctx->lmax_s, ctx->cheb_kappa_s);
+    launch_fill(st, xs, n3, 0.0);
+    launch_scatter3(st, ctx->nS, ctx->snode.p, cs_x, xs);
     launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Mvv.vals.p, xs, rv, rhs2);
-    cheb_solve(ctx, ctx->mask_f.p, rhs2, xf, IW, ctx->cheb_its_f, ctx->lmax_f, ctx->cheb_kappa_f);
+    cheb_solve(ctx, vv_ref(ctx), ctx->mask_f.p, rhs2, xf, IW, ctx->cheb_its_f, ctx->lmax_f, ctx->cheb_kappa_f);
     launch_axpby(st, vs, 1.0, xs, 1.0, xf, n3);
     ctx->inner_its[0] += ctx->cheb_its_s + ctx->cheb_its_f;
   }
   // pressure: S dp = rp - Apv~ vs,  S x = App x - Apv~ D^-1 Avp x
   launch_pres_rows(st, V, ctx->rowptr_pp.p, ctx->cols_pp.p, ctx->App.p, nullptr, 0.0, ctx->rowptr_pv.p, ctx->cols_pv.p,
                    ctx->Apv.p, vs, -1.0, rp, 1.0, tp);
-  FSICHK(inner_bicgstab(ctx, ctx->Ms,
-                        [&](const double* in, double* out) {
-                          launch_vel_correct(st, n3, ctx->rowptr_vp.p, ctx->cols_vp.p, ctx->Avp.p, in, ctx->diagpos3.p,
-                                             ctx->Mvv.vals.p, nullptr, w3);
-                          launch_pres_rows(st, V, ctx->rowptr_pp.p, ctx->cols_pp.p, ctx->App.p, in, 1.0, ctx->rowptr_pv.p,
-                                           ctx->cols_pv.p, ctx->Apv.p, w3, 1.0, nullptr, 0.0, out);
-                        },
-                        tp, dp, IW, ctx->inner_rtol, ctx->inner_maxit_p, &ctx->inner_its[1]));
+  if (ctx->cheb_its_p > 0) {
+    cheb_solve_op(ctx, V, [&](const double* in, double* out) { schur_apply(ctx, in, out, w3); }, ctx->Ms.vals.p,
+                  ctx->diagpos_pp.p, nullptr, tp, dp, IW, ctx->cheb_its_p, ctx->lmax_p, ctx->cheb_kappa_p);
+    ctx->inner_its[1] += ctx->cheb_its_p;
+  } else {
+    FSICHK(inner_bicgstab(ctx, ctx->Ms, [&](const double* in, double* out) { schur_apply(ctx, in, out, w3); }, tp, dp, IW,
+                          ctx->inner_rtol, ctx->inner_maxit_p, &ctx->inner_its[1]));
+  }
   // velocity correction and displacement
   launch_vel_correct(st, n3, ctx->rowptr_vp.p, ctx->cols_vp.p, ctx->Avp.p, dp, ctx->diagpos3.p, ctx->Mvv.vals.p, vs, dv);
   launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Adv.p, dv, rd, td);
@@ -367,8 +394,11 @@ int refresh_preconditioner(FsiCtx* ctx) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
     if (flags[1] & 4) { ctx->err = "Schur complement: a vertex has more than 512 vertex neighbours"; return FSI_ERR_INVALID; }
-    FSICHK(power_lmax(ctx, ctx->mask_s.p, ctx->blk.p, &ctx->lmax_s));
-    FSICHK(power_lmax(ctx, ctx->mask_f.p, ctx->blk.p, &ctx->lmax_f));
+    launch_gather_vals(st, (int64_t)ctx->ss_vals.n, ctx->ss_src.p, ctx->Mvv.vals.p, ctx->ss_vals.p);
+    FSICHK(power_lmax(ctx, ss_ref(ctx), nullptr, ctx->blk.p, &ctx->lmax_s));
+    FSICHK(power_lmax(ctx, vv_ref(ctx), ctx->mask_f.p, ctx->blk.p, &ctx->lmax_f));
+    FSICHK(power_lmax_op(ctx, ctx->V, [&](const double* in, double* o) { schur_apply(ctx, in, o, ctx->blk.p + 17 * 3 * ctx->N2); },
+                         ctx->Ms.vals.p, ctx->diagpos_pp.p, nullptr, ctx->blk.p, &ctx->lmax_p));
     for (SubMat* M : {&ctx->Mdd, &ctx->Ms}) {
       HIPCHK(hipMemcpyAsync(M->LU.p, M->vals.p, M->nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
       launch_ilu0_levels(st, M->levels, M->rowptr, M->cols, M->diagpos, M->LU.p, ctx->iflags.p);
@@ -427,7 +457,9 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->enbr.release();
   ctx->epnbr.release();
   for (auto* b : {&ctx->Adv, &ctx->Avp, &ctx->Apv, &ctx->App, &ctx->blk, &ctx->Mdd.vals, &ctx->Mdd.LU, &ctx->Mvv.vals,
-                  &ctx->Mvv.LU, &ctx->Ms.vals, &ctx->Ms.LU, &ctx->mask_s, &ctx->mask_f}) b->release();
+                  &ctx->Mvv.LU, &ctx->Ms.vals, &ctx->Ms.LU, &ctx->mask_s, &ctx->mask_f, &ctx->ss_vals}) b->release();
+  for (auto* b : {&ctx->snode, &ctx->ss_cols}) b->release();
+  for (auto* b : {&ctx->ss_rowptr, &ctx->ss_diagpos, &ctx->ss_src}) b->release();
   for (auto* b : {&ctx->node_solid, &ctx->vrank, &ctx->cols3, &ctx->cols_vp, &ctx->cols_pv, &ctx->cols_pp}) b->release();
   for (auto* b : {&ctx->rowptr3, &ctx->diagpos3, &ctx->rowptr_vp, &ctx->rowptr_pv, &ctx->rowptr_pp, &ctx->diagpos_pp}) b->release();
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -702,12 +734,43 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
       std::vector<double> ms(3 * N2), mf(3 * N2);
       for (int64_t r = 0; r < N2; ++r)
         for (int i = 0; i < 3; ++i) { ms[3 * r + i] = node_solid[r] ? 1.0 : 0.0; mf[3 * r + i] = node_solid[r] ? 0.0 : 1.0; }
+      std::vector<int32_t> snode, sidx(N2, -1);
+      for (int64_t r = 0; r < N2; ++r)
+        if (node_solid[r]) { sidx[r] = (int32_t)snode.size(); snode.push_back((int32_t)r); }
+      const int64_t nS = (int64_t)snode.size();
+      ctx->nS = nS;
+      std::vector<int64_t> ss_rowptr(3 * nS + 1, 0), ss_diagpos(3 * nS, 0), ss_src;
+      std::vector<int32_t> ss_cols;
+      for (int64_t i = 0; i < nS; ++i) {
+        const int64_t r = snode[i], a = ctx->h_nadj_ptr[r], deg = ctx->h_nadj_ptr[r + 1] - a;
+        for (int c = 0; c < 3; ++c) {
+          const int64_t row0 = 9 * a + 3 * c * deg;            // start of row 3r+c in the 3x3-blocked structure
+          for (int64_t k = 0; k < deg; ++k) {
+            const int32_t si = sidx[ctx->h_nadj[a + k]];
+            if (si < 0) continue;
+            for (int j = 0; j < 3; ++j) {
+              if (si == i && j == c) ss_diagpos[3 * i + c] = (int64_t)ss_cols.size();
+              ss_cols.push_back(3 * si + j);
+              ss_src.push_back(row0 + 3 * k + j);
+            }
+          }
+          ss_rowptr[3 * i + c + 1] = (int64_t)ss_cols.size();
+        }
+      }
+      FSICHK(upload(ctx, ctx->snode, snode));
+      FSICHK(upload(ctx, ctx->ss_rowptr, ss_rowptr));
+      FSICHK(upload(ctx, ctx->ss_diagpos, ss_diagpos));
+      FSICHK(upload(ctx, ctx->ss_cols, ss_cols));
+      FSICHK(upload(ctx, ctx->ss_src, ss_src));
+      HIPCHK(ctx->ss_vals.alloc(ss_cols.size()));
       FSICHK(upload(ctx, ctx->mask_s, ms));
       FSICHK(upload(ctx, ctx->mask_f, mf));
       if (const char* e = getenv("FSI_CHEB_S")) ctx->cheb_its_s = atoi(e);
       if (const char* e = getenv("FSI_CHEB_F")) ctx->cheb_its_f = atoi(e);
       if (const char* e = getenv("FSI_KAPPA_S")) ctx->cheb_kappa_s = atof(e);
       if (const char* e = getenv("FSI_KAPPA_F")) ctx->cheb_kappa_f = atof(e);
+      if (const char* e = getenv("FSI_CHEB_P")) ctx->cheb_its_p = atoi(e);
+      if (const char* e = getenv("FSI_KAPPA_P")) ctx->cheb_kappa_p = atof(e);
     }
     const int64_t nadj_total = ctx->h_nadj_ptr[N2], padj_total = ctx->h_padj_ptr[N2];
     std::vector<int64_t> rowptr_pv(V + 1, 0), rowptr_pp(V + 1, 0), diagpos_pp(V, 0);

@@ -130,9 +130,13 @@ struct FsiCtx {
   fsi::DevBuf<double> Adv, Avp, Apv, App;
   fsi::SubMat Mdd, Mvv, Ms;                  // A_dd, Avv~, sparsified Schur complement (ILU only)
   fsi::DevBuf<double> blk;                   // work vectors of the block preconditioner
+  int64_t nS = 0;                            // solid (incl. interface) nodes; compact velocity block A_SS on them
+  fsi::DevBuf<int32_t> snode, ss_cols;
+  fsi::DevBuf<int64_t> ss_rowptr, ss_diagpos, ss_src;
+  fsi::DevBuf<double> ss_vals;
   fsi::DevBuf<double> mask_s, mask_f;        // [3 N2] 1 on velocity dofs of solid (incl. interface) / fluid-interior nodes
-  int cheb_its_s = 300, cheb_its_f = 20;     // Chebyshev sweeps on the solid / fluid part of the velocity block
-  double cheb_kappa_s = 1e4, cheb_kappa_f = 100.0, lmax_s = 1.0, lmax_f = 1.0;
+  int cheb_its_s = 300, cheb_its_f = 20, cheb_its_p = 40;     // Chebyshev sweeps on the solid / fluid part of the velocity block
+  double cheb_kappa_s = 1e4, cheb_kappa_f = 100.0, cheb_kappa_p = 100.0, lmax_s = 1.0, lmax_f = 1.0, lmax_p = 1.0;
   double inner_rtol = 1e-2;
   int inner_maxit = 40, inner_maxit_p = 60;
   int64_t inner_its[3] = {0, 0, 0};          // accumulated inner iterations: vv, schur, dd

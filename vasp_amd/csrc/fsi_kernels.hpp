@@ -90,6 +90,9 @@ void launch_cheb_init(hipStream_t st, int64_t n, const double* mask, const doubl
                       const double* A, double inv_theta, double* x, double* r, double* d);
 void launch_cheb_step(hipStream_t st, int64_t n, const double* mask, const double* t, const int64_t* diagpos,
                       const double* A, double c1, double c2, double* x, double* r, double* d);
+void launch_gather_vals(hipStream_t st, int64_t n, const int64_t* pos, const double* src, double* dst);
+void launch_gather3(hipStream_t st, int64_t nS, const int32_t* snode, const double* full, double* comp);
+void launch_scatter3(hipStream_t st, int64_t nS, const int32_t* snode, const double* comp, double* full);
 void launch_mask_ripple(hipStream_t st, int64_t n, const double* mask, double* x);
 void launch_mask_scale(hipStream_t st, int64_t n, const double* mask, const int64_t* diagpos, const double* A, double* y);
 void launch_residual_csr(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const double* vals,
