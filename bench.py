@@ -97,6 +97,8 @@ def main():
             ["-p", "offset_stenosis", "-dt", str(args.dt), "-T", str(T_end), "--theta", "0.501", "--verbose", "False",
              "--folder", str(tmp / "results"), "--sub-folder", "1", "--new-arguments", f"mesh_path={mesh_path}"])
     hb = HipBackend(desc, device=local_rank)
+    ns_cheb = (int(os.environ.get("FSI_CHEB_S", 300)), int(os.environ.get("FSI_CHEB_F", 20)))
+    solid_fp32 = int(os.environ.get("FSI_SOLID_FP32", 1)) != 0
     mesh = ns["mesh"]
     setup_s = time.perf_counter() - t_setup
     newton = dict(atol=ns["atol"], rtol=ns["rtol"], max_it=ns["max_it"], lmbda=ns["lmbda"], recompute=ns["recompute"],
@@ -141,8 +143,16 @@ def main():
         ndof, nnz = hb.ndof, int(hb.lib.fsi_matrix_nnz(hb.ctx))
         C = mesh.num_cells
         # algorithmic bytes per launch of each timed kernel
+        sweeps = tm["inner_vv_iters"] * (ns_cheb[0] / max(1, ns_cheb[0] + ns_cheb[1]))     # solid-block SpMV launches
+        ss_avg = tm["solid_spmv_ms"] / max(1, tm["solid_spmv_calls"])
         kernels = {
-            "k_spmv (monolithic Jacobian, CSR f64 + i32)": (tm["spmv_ms"], tm["spmv_calls"], nnz * 12.0 + ndof * 16.0 + (ndof + 1) * 8.0),
+            # (time attributed in the timed region [ms], launches, algorithmic bytes per launch, avg launch [ms])
+            ("k_spmv_sb (solid velocity block, FP32 3x3 block-CSR, Chebyshev sweeps; avg from sampled HIP events)"
+             if solid_fp32 else "k_spmv<1> (solid velocity block, CSR f64, Chebyshev sweeps; avg from sampled HIP events)"):
+                (ss_avg * sweeps, int(sweeps),
+                 (tm["solid_nnz"] * 4.0 + tm["solid_nnz"] / 9 * 4.0 + tm["solid_rows"] * 8.0 + (tm["solid_rows"] / 3 + 1) * 8.0) if solid_fp32
+                 else (tm["solid_nnz"] * 12.0 + tm["solid_rows"] * 16.0 + (tm["solid_rows"] + 1) * 8.0)),
+            "k_spmv<0> (monolithic Jacobian, CSR f64 + i32)": (tm["spmv_ms"], tm["spmv_calls"], nnz * 12.0 + ndof * 16.0 + (ndof + 1) * 8.0),
             "k_residual (element residual + scatter-add)": (tm["residual_ms"], tm["residual_calls"], C * 1676.0),
             "k_jacobian<nonlinear> (element Jacobian + scatter-add)": (tm["jacobian_ms"], tm["jacobian_calls"], C * 33420.0),
         }

@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "fsi_set_pressure_facets", "fsi_set_interface_pressure", "fsi_set_robin_facets", "fsi_solver_setup",
     "fsi_assemble_residual", "fsi_assemble_jacobian", "fsi_solve", "fsi_newton_solve", "fsi_shift",
     "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_get_matrix", "fsi_spmv",
-    "fsi_get_timers", "fsi_set_linear_solver",
+    "fsi_get_timers", "fsi_set_linear_solver", "fsi_set_chebyshev",
 )
 
 
@@ -56,7 +56,8 @@ class FsiTimers(C.Structure):
                 ("precond_calls", C.c_int64), ("ortho_ms", C.c_double), ("ortho_calls", C.c_int64),
                 ("krylov_ms", C.c_double), ("krylov_solves", C.c_int64), ("krylov_iters", C.c_int64),
                 ("inner_vv_iters", C.c_int64), ("inner_schur_iters", C.c_int64), ("inner_dd_iters", C.c_int64),
-                ("precond_applies", C.c_int64)]
+                ("precond_applies", C.c_int64), ("solid_spmv_ms", C.c_double), ("solid_spmv_calls", C.c_int64),
+                ("solid_nnz", C.c_int64), ("solid_rows", C.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -107,6 +108,7 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_spmv.argtypes = [vp, vp, vp]
     lib.fsi_get_timers.argtypes = [vp, C.POINTER(FsiTimers), C.c_int]
     lib.fsi_set_linear_solver.argtypes = [vp, i32, dbl, i32]
+    lib.fsi_set_chebyshev.argtypes = [vp, i32, dbl, i32, dbl, i32, dbl, i32, dbl]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("fsi_last_error", "fsi_num_dofs", "fsi_matrix_nnz"):
@@ -260,6 +262,12 @@ class HipBackend:
 
     def set_linear_solver(self, precond: int = 0, inner_rtol: float = 0.0, inner_max_it: int = 0):
         self._check(self.lib.fsi_set_linear_solver(self.ctx, int(precond), float(inner_rtol), int(inner_max_it)))
+
+    def set_chebyshev(self, its_solid=0, kappa_solid=0.0, its_fluid=0, kappa_fluid=0.0, its_schur=0, kappa_schur=0.0,
+                      its_disp=0, kappa_disp=0.0):
+        self._check(self.lib.fsi_set_chebyshev(self.ctx, int(its_solid), float(kappa_solid), int(its_fluid),
+                                               float(kappa_fluid), int(its_schur), float(kappa_schur), int(its_disp),
+                                               float(kappa_disp)))
 
     def timers(self, reset=False) -> dict:
         t = FsiTimers()

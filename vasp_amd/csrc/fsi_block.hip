@@ -196,6 +196,69 @@ void launch_schur_p1(hipStream_t st, int64_t V, const int32_t* vrank, const int6
                      rowptr_pp, App, rowptr_vp, Avp, diagpos3, Avv, S1, flags);
 }
 
+// ---- explicit Schur complement S = A_pp - Apv~ D^-1 A_vp on its full pattern (vertices within two elements) ----------------
+// One wave per pressure row; the pattern (s_rowptr, s_cols: ascending pressure positions) is built once on the host.
+static constexpr int MAXS2 = 1024;
+__global__ __launch_bounds__(64) void k_schur_full(int64_t V, const int64_t* __restrict__ s_rowptr,
+                                                   const int32_t* __restrict__ s_cols, const int32_t* __restrict__ vrank,
+                                                   const int64_t* __restrict__ nadj_ptr, const int32_t* __restrict__ nadj,
+                                                   const int64_t* __restrict__ padj_ptr, const int32_t* __restrict__ padj,
+                                                   const int64_t* __restrict__ rowptr_pv, const double* __restrict__ Apv,
+                                                   const int64_t* __restrict__ rowptr_pp, const double* __restrict__ App,
+                                                   const int64_t* __restrict__ rowptr_vp, const double* __restrict__ Avp,
+                                                   const int64_t* __restrict__ diagpos3, const double* __restrict__ Avv,
+                                                   double* __restrict__ S, int32_t* __restrict__ flags) {
+  __shared__ double acc[MAXS2];
+  __shared__ int32_t scol[MAXS2];
+  const int lane = threadIdx.x;
+  for (int64_t q = blockIdx.x; q < V; q += gridDim.x) {
+    const int64_t s0 = s_rowptr[q];
+    const int len = (int)(s_rowptr[q + 1] - s0);
+    if (len > MAXS2) { if (lane == 0) atomicOr(&flags[1], 4); continue; }
+    __syncthreads();
+    for (int t = lane; t < len; t += 64) { acc[t] = 0.0; scol[t] = s_cols[s0 + t]; }
+    __syncthreads();
+    auto find = [&](int32_t c) {
+      int lo = 0, hi = len - 1;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (scol[mid] < c) lo = mid + 1; else hi = mid; }
+      return lo;
+    };
+    const int32_t r = vrank[q];
+    {
+      const int64_t a = padj_ptr[r], pdeg = padj_ptr[r + 1] - a, op = rowptr_pp[q];
+      for (int64_t k = lane; k < pdeg; k += 64) {
+        const double v = App[op + k];
+        if (v != 0.0) atomicAdd(&acc[find(padj[a + k])], v);
+      }
+    }
+    const int64_t a = nadj_ptr[r], deg = nadj_ptr[r + 1] - a, ov = rowptr_pv[q];
+    for (int64_t e = lane; e < 3 * deg; e += 64) {
+      const int32_t b = nadj[a + e / 3];
+      const int j = (int)(e % 3);
+      const double bq = Apv[ov + e];
+      if (bq == 0.0) continue;
+      const int64_t R = 3 * (int64_t)b + j;
+      const double coef = bq / Avv[diagpos3[R]];
+      const int64_t pa = padj_ptr[b], pdeg = padj_ptr[b + 1] - pa, o = rowptr_vp[R];
+      for (int64_t k = 0; k < pdeg; ++k) {
+        const double v = Avp[o + k];
+        if (v != 0.0) atomicAdd(&acc[find(padj[pa + k])], -coef * v);
+      }
+    }
+    __syncthreads();
+    for (int t = lane; t < len; t += 64) S[s0 + t] = acc[t];
+  }
+}
+void launch_schur_full(hipStream_t st, int64_t V, const int64_t* s_rowptr, const int32_t* s_cols, const int32_t* vrank,
+                       const int64_t* nadj_ptr, const int32_t* nadj, const int64_t* padj_ptr, const int32_t* padj,
+                       const int64_t* rowptr_pv, const double* Apv, const int64_t* rowptr_pp, const double* App,
+                       const int64_t* rowptr_vp, const double* Avp, const int64_t* diagpos3, const double* Avv, double* S,
+                       int32_t* flags) {
+  const unsigned blocks = (unsigned)(V < 32768 ? V : 32768);
+  hipLaunchKernelGGL(k_schur_full, dim3(blocks), dim3(64), 0, st, V, s_rowptr, s_cols, vrank, nadj_ptr, nadj, padj_ptr, padj,
+                     rowptr_pv, Apv, rowptr_pp, App, rowptr_vp, Avp, diagpos3, Avv, S, flags);
+}
+
 // ---- field vectors <-> monolithic vector (solver ordering: 6 per node [d d d v v v], then pressure) ---------------------------
 #define GS(i, n) for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 __global__ void k_split(int64_t N2, int64_t V, const double* __restrict__ r, double* __restrict__ rd,
@@ -314,6 +377,56 @@ __global__ void k_mask_scale(int64_t n, const double* __restrict__ mask, const i
                              const double* __restrict__ A, double* __restrict__ y) {
   GS(i, n) y[i] = (mask ? mask[i] : 1.0) * y[i] / A[diagpos[i]];
 }
+// ---- component-diagonal node-block format ("db"): for node r and neighbour k the three entries (i,i) of the 3x3 block ---------
+// A_dd is exactly of this form (mass / mesh Laplacian act per component); the fluid-interior velocity block is dominated
+// by it (mass + convection), which is all its Chebyshev *preconditioner* sweeps need.  28 B per node pair instead of 108.
+__global__ void k_extract_db(int64_t N2, const int64_t* __restrict__ nadj_ptr, const int64_t* __restrict__ rowptr3,
+                             const double* __restrict__ vals, double* __restrict__ db, int32_t* __restrict__ flags, int check) {
+  GS(e, nadj_ptr[N2]) {
+    // node r of pair e: binary search in nadj_ptr
+    int64_t lo = 0, hi = N2 - 1;
+    while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if (nadj_ptr[mid] <= e) lo = mid; else hi = mid - 1; }
+    const int64_t r = lo, k = e - nadj_ptr[r];
+    bool off = false;
+    for (int i = 0; i < 3; ++i) {
+      const double* row = vals + rowptr3[3 * r + i] + 3 * k;
+      db[3 * e + i] = row[i];
+      for (int j = 0; j < 3; ++j) off |= (j != i && row[j] != 0.0);
+    }
+    if (check && off) atomicOr(&flags[1], 8);
+  }
+}
+// y[3r+i] = sum_k db[e][i] x[3 s_k + i]; 16 lanes per node (4 nodes per wave)
+__global__ __launch_bounds__(256) void k_spmv_db(int64_t N2, const int64_t* __restrict__ nadj_ptr,
+                                                 const int32_t* __restrict__ nadj, const double* __restrict__ db,
+                                                 const double* __restrict__ x, double* __restrict__ y) {
+  const int sub = threadIdx.x & 15;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t r = grp; r < N2; r += ngrp) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t e = nadj_ptr[r] + sub; e < nadj_ptr[r + 1]; e += 16) {
+      const double* xs = x + 3 * (int64_t)nadj[e];
+      const double* c = db + 3 * e;
+      s0 += c[0] * xs[0]; s1 += c[1] * xs[1]; s2 += c[2] * xs[2];
+    }
+    for (int off = 8; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
+    }
+    if (sub == 0) { y[3 * r] = s0; y[3 * r + 1] = s1; y[3 * r + 2] = s2; }
+  }
+}
+void launch_extract_db(hipStream_t st, int64_t N2, int64_t npairs, const int64_t* nadj_ptr, const int64_t* rowptr3,
+                       const double* vals, double* db, int32_t* flags, int check) {
+  hipLaunchKernelGGL(k_extract_db, dim3(gridn(npairs)), dim3(256), 0, st, N2, nadj_ptr, rowptr3, vals, db, flags, check);
+}
+void launch_spmv_db(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
+                    const double* x, double* y) {
+  int64_t blocks = (N2 + 15) / 16;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_spmv_db, dim3((unsigned)blocks), dim3(256), 0, st, N2, nadj_ptr, nadj, db, x, y);
+}
+
 // compact solid block: values gathered from Avv~ (vals[e] = src[pos[e]]), vectors gathered / scattered by node list
 __global__ void k_gather_vals(int64_t n, const int64_t* __restrict__ pos, const double* __restrict__ src, double* __restrict__ dst) {
   GS(e, n) dst[e] = src[pos[e]];
@@ -333,6 +446,89 @@ void launch_gather3(hipStream_t st, int64_t nS, const int32_t* snode, const doub
 void launch_scatter3(hipStream_t st, int64_t nS, const int32_t* snode, const double* comp, double* full) {
   hipLaunchKernelGGL(k_scatter3, dim3(gridn(3 * nS)), dim3(256), 0, st, nS, snode, comp, full);
 }
+// ---- solid velocity block in FP32 block-CSR (3x3 blocks, one column index per block): 40 B per 9 entries ---------------------
+// The Chebyshev sweeps on this block deliver ~1e-2 accuracy to a flexible outer method, so single precision is enough;
+// it more than halves the bytes of the most often launched kernel.
+__global__ void k_sb_gather(int64_t nb, const int32_t* __restrict__ sb_row, const int64_t* __restrict__ sb_src,
+                            const int32_t* __restrict__ sb_stride, const double* __restrict__ Avv, float* __restrict__ vals) {
+  GS(b, nb) {
+    const int64_t src = sb_src[b];
+    const int64_t stride = sb_stride[sb_row[b]];
+    for (int c = 0; c < 3; ++c)
+      for (int j = 0; j < 3; ++j) vals[9 * b + 3 * c + j] = (float)Avv[src + c * stride + j];
+  }
+}
+__global__ void k_sb_dinv(int64_t nS, const int32_t* __restrict__ snode, const int64_t* __restrict__ diagpos3,
+                          const double* __restrict__ Avv, float* __restrict__ dinv) {
+  GS(t, 3 * nS) dinv[t] = (float)(1.0 / Avv[diagpos3[3 * (int64_t)snode[t / 3] + t % 3]]);
+}
+__global__ __launch_bounds__(256) void k_spmv_sb(int64_t nS, const int64_t* __restrict__ sb_ptr,
+                                                 const int32_t* __restrict__ sb_col, const float* __restrict__ vals,
+                                                 const float* __restrict__ x, float* __restrict__ y) {
+  const int sub = threadIdx.x & 15;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t i = grp; i < nS; i += ngrp) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int64_t b = sb_ptr[i] + sub; b < sb_ptr[i + 1]; b += 16) {
+      const float* xs = x + 3 * (int64_t)sb_col[b];
+      const float* a = vals + 9 * b;
+      const float x0 = xs[0], x1 = xs[1], x2 = xs[2];
+      s0 += a[0] * x0 + a[1] * x1 + a[2] * x2;
+      s1 += a[3] * x0 + a[4] * x1 + a[5] * x2;
+      s2 += a[6] * x0 + a[7] * x1 + a[8] * x2;
+    }
+    for (int off = 8; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
+    }
+    if (sub == 0) { y[3 * i] = s0; y[3 * i + 1] = s1; y[3 * i + 2] = s2; }
+  }
+}
+__global__ void k_cheb_init_f32(int64_t n, const float* __restrict__ rhs, const float* __restrict__ dinv, float inv_theta,
+                                float* __restrict__ x, float* __restrict__ r, float* __restrict__ d) {
+  GS(i, n) { const float ri = rhs[i]; x[i] = 0.f; r[i] = ri; d[i] = ri * inv_theta * dinv[i]; }
+}
+__global__ void k_cheb_step_f32(int64_t n, const float* __restrict__ t, const float* __restrict__ dinv, float c1, float c2,
+                                float* __restrict__ x, float* __restrict__ r, float* __restrict__ d) {
+  GS(i, n) {
+    const float di = d[i], ri = r[i] - t[i];
+    x[i] += di;
+    r[i] = ri;
+    d[i] = c1 * di + c2 * ri * dinv[i];
+  }
+}
+__global__ void k_gather3_f32(int64_t nS, const int32_t* __restrict__ snode, const double* __restrict__ full, float* __restrict__ comp) {
+  GS(t, 3 * nS) comp[t] = (float)full[3 * (int64_t)snode[t / 3] + t % 3];
+}
+__global__ void k_scatter3_f32(int64_t nS, const int32_t* __restrict__ snode, const float* __restrict__ comp, double* __restrict__ full) {
+  GS(t, 3 * nS) full[3 * (int64_t)snode[t / 3] + t % 3] = (double)comp[t];
+}
+void launch_sb_gather(hipStream_t st, int64_t nb, const int32_t* sb_row, const int64_t* sb_src, const int32_t* sb_stride,
+                      const double* Avv, float* vals) {
+  hipLaunchKernelGGL(k_sb_gather, dim3(gridn(nb)), dim3(256), 0, st, nb, sb_row, sb_src, sb_stride, Avv, vals);
+}
+void launch_sb_dinv(hipStream_t st, int64_t nS, const int32_t* snode, const int64_t* diagpos3, const double* Avv, float* dinv) {
+  hipLaunchKernelGGL(k_sb_dinv, dim3(gridn(3 * nS)), dim3(256), 0, st, nS, snode, diagpos3, Avv, dinv);
+}
+void launch_spmv_sb(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
+                    const float* x, float* y) {
+  int64_t blocks = (nS + 15) / 16;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_spmv_sb, dim3((unsigned)blocks), dim3(256), 0, st, nS, sb_ptr, sb_col, vals, x, y);
+}
+void launch_cheb_init_f32(hipStream_t st, int64_t n, const float* rhs, const float* dinv, float inv_theta, float* x, float* r, float* d) {
+  hipLaunchKernelGGL(k_cheb_init_f32, dim3(gridn(n)), dim3(256), 0, st, n, rhs, dinv, inv_theta, x, r, d);
+}
+void launch_cheb_step_f32(hipStream_t st, int64_t n, const float* t, const float* dinv, float c1, float c2, float* x, float* r, float* d) {
+  hipLaunchKernelGGL(k_cheb_step_f32, dim3(gridn(n)), dim3(256), 0, st, n, t, dinv, c1, c2, x, r, d);
+}
+void launch_gather3_f32(hipStream_t st, int64_t nS, const int32_t* snode, const double* full, float* comp) {
+  hipLaunchKernelGGL(k_gather3_f32, dim3(gridn(3 * nS)), dim3(256), 0, st, nS, snode, full, comp);
+}
+void launch_scatter3_f32(hipStream_t st, int64_t nS, const int32_t* snode, const float* comp, double* full) {
+  hipLaunchKernelGGL(k_scatter3_f32, dim3(gridn(3 * nS)), dim3(256), 0, st, nS, snode, comp, full);
+}
+
 // x = mask .* (pseudo-random +-1 ripple): start vector of the power iteration, rich in element-scale modes
 __global__ void k_mask_ripple(int64_t n, const double* __restrict__ mask, double* __restrict__ x) {
   GS(i, n) {

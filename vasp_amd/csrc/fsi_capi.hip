@@ -193,11 +193,8 @@ int power_lmax(FsiCtx* ctx, const CsrRef& M, const double* mask, double* W, doub
 }
 // Schur operator y = (A_pp - Apv~ D^-1 A_vp) x ; w3: work vector of length 3 N2
 void schur_apply(FsiCtx* ctx, const double* in, double* out, double* w3) {
-  const int64_t n3 = 3 * ctx->N2;
-  launch_vel_correct(ctx->stream, n3, ctx->rowptr_vp.p, ctx->cols_vp.p, ctx->Avp.p, in, ctx->diagpos3.p, ctx->Mvv.vals.p,
-                     nullptr, w3);
-  launch_pres_rows(ctx->stream, ctx->V, ctx->rowptr_pp.p, ctx->cols_pp.p, ctx->App.p, in, 1.0, ctx->rowptr_pv.p,
-                   ctx->cols_pv.p, ctx->Apv.p, w3, 1.0, nullptr, 0.0, out);
+  (void)w3;
+  launch_spmv(ctx->stream, ctx->V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->s_vals.p, in, out, SPMV_FIELD_BLOCK);
 }
 
 // z = M^-1 r with the approximate block factorisation (see fsi_block.hip):  (v,p) by SIMPLE with the d-eliminated
@@ -213,12 +210,48 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   {
     double *xs = IW + 3 * n3, *xf = IW + 4 * n3, *rhs2 = IW + 5 * n3;
     double *cs_rhs = IW + 6 * n3, *cs_x = IW + 7 * n3;            // compact solid vectors (3 nS <= n3)
+    if (ctx->solid_fp32) {
+      const int64_t n = 3 * ctx->nS;
+      float* F = reinterpret_cast<float*>(IW);
+      float *fr = F, *fd = F + n, *ft = F + 2 * n, *fx = F + 3 * n, *frhs = F + 4 * n;
+      launch_gather3_f32(st, ctx->nS, ctx->snode.p, rv, frhs);
+      const double lmax = ctx->lmax_s, lmin = lmax / ctx->cheb_kappa_s, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
+      double rho = 1.0 / sig;
+      launch_cheb_init_f32(st, n, frhs, ctx->sb_dinv.p, (float)(1.0 / th), fx, fr, fd);
+      for (int k = 0; k < ctx->cheb_its_s; ++k) {
+        const bool timed = k < 8 && ctx->ss_ev0[0];
+        if (timed) (void)hipEventRecord(ctx->ss_ev0[k], st);
+        launch_spmv_sb(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_col.p, ctx->sb_vals.p, fd, ft);
+        if (timed) (void)hipEventRecord(ctx->ss_ev1[k], st);
+        const double rn = 1.0 / (2.0 * sig - rho);
+        launch_cheb_step_f32(st, n, ft, ctx->sb_dinv.p, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
+        rho = rn;
+      }
+      ctx->ss_samples_pending = ctx->ss_ev0[0] ? std::min(8, ctx->cheb_its_s) : 0;
+      launch_fill(st, xs, n3, 0.0);
+      launch_scatter3_f32(st, ctx->nS, ctx->snode.p, fx, xs);
+    } else {
     launch_gather3(st, ctx->nS, ctx->snode.p, rv, cs_rhs);
-    cheb_solve(ctx, ss_ref(ctx), nullptr, cs_rhs, cs_x, IW, ctx->cheb_its_s, ctx->lmax_s, ctx->cheb_kappa_s);
+    {
+      const CsrRef M = ss_ref(ctx);
+      int sample = 0;
+      cheb_solve_op(ctx, M.n,
+                    [&](const double* in, double* out) {
+                      const bool timed = sample < 8 && ctx->ss_ev0[0];
+                      if (timed) (void)hipEventRecord(ctx->ss_ev0[sample], st);
+                      launch_spmv(st, M.n, M.rowptr, M.cols, M.vals, in, out, SPMV_SOLID_BLOCK);
+                      if (timed) (void)hipEventRecord(ctx->ss_ev1[sample], st);
+                      sample += timed ? 1 : 0;
+                    },
+                    M.vals, M.diagpos, nullptr, cs_rhs, cs_x, IW, ctx->cheb_its_s, ctx->lmax_s, ctx->cheb_kappa_s);
+      ctx->ss_samples_pending = sample;
+    }
     launch_fill(st, xs, n3, 0.0);
     launch_scatter3(st, ctx->nS, ctx->snode.p, cs_x, xs);
+    }
     launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Mvv.vals.p, xs, rv, rhs2);
-    cheb_solve(ctx, vv_ref(ctx), ctx->mask_f.p, rhs2, xf, IW, ctx->cheb_its_f, ctx->lmax_f, ctx->cheb_kappa_f);
+    cheb_solve_op(ctx, n3, [&](const double* in, double* out) { launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->vv_db.p, in, out); },
+                  ctx->Mvv.vals.p, ctx->diagpos3.p, ctx->mask_f.p, rhs2, xf, IW, ctx->cheb_its_f, ctx->lmax_f, ctx->cheb_kappa_f);
     launch_axpby(st, vs, 1.0, xs, 1.0, xf, n3);
     ctx->inner_its[0] += ctx->cheb_its_s + ctx->cheb_its_f;
   }
@@ -226,8 +259,8 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   launch_pres_rows(st, V, ctx->rowptr_pp.p, ctx->cols_pp.p, ctx->App.p, nullptr, 0.0, ctx->rowptr_pv.p, ctx->cols_pv.p,
                    ctx->Apv.p, vs, -1.0, rp, 1.0, tp);
   if (ctx->cheb_its_p > 0) {
-    cheb_solve_op(ctx, V, [&](const double* in, double* out) { schur_apply(ctx, in, out, w3); }, ctx->Ms.vals.p,
-                  ctx->diagpos_pp.p, nullptr, tp, dp, IW, ctx->cheb_its_p, ctx->lmax_p, ctx->cheb_kappa_p);
+    cheb_solve_op(ctx, V, [&](const double* in, double* out) { schur_apply(ctx, in, out, w3); }, ctx->s_vals.p,
+                  ctx->s_diagpos.p, nullptr, tp, dp, IW, ctx->cheb_its_p, ctx->lmax_p, ctx->cheb_kappa_p);
     ctx->inner_its[1] += ctx->cheb_its_p;
   } else {
     FSICHK(inner_bicgstab(ctx, ctx->Ms, [&](const double* in, double* out) { schur_apply(ctx, in, out, w3); }, tp, dp, IW,
@@ -236,11 +269,29 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   // velocity correction and displacement
   launch_vel_correct(st, n3, ctx->rowptr_vp.p, ctx->cols_vp.p, ctx->Avp.p, dp, ctx->diagpos3.p, ctx->Mvv.vals.p, vs, dv);
   launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Adv.p, dv, rd, td);
-  FSICHK(inner_bicgstab(ctx, ctx->Mdd,
-                        [&](const double* in, double* out) { launch_spmv(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Mdd.vals.p, in, out); },
-                        td, dd, IW, ctx->inner_rtol, ctx->inner_maxit, &ctx->inner_its[2]));
+  if (ctx->cheb_its_d > 0) {
+    if (ctx->dd_is_db)
+      cheb_solve_op(ctx, n3, [&](const double* in, double* out) { launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_db.p, in, out); },
+                    ctx->Mdd.vals.p, ctx->diagpos3.p, nullptr, td, dd, IW, ctx->cheb_its_d, ctx->lmax_d, ctx->cheb_kappa_d);
+    else
+      cheb_solve(ctx, CsrRef{n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Mdd.vals.p, ctx->diagpos3.p}, nullptr, td, dd, IW,
+                 ctx->cheb_its_d, ctx->lmax_d, ctx->cheb_kappa_d);
+    ctx->inner_its[2] += ctx->cheb_its_d;
+  } else {
+    FSICHK(inner_bicgstab(ctx, ctx->Mdd,
+                          [&](const double* in, double* out) { launch_spmv(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Mdd.vals.p, in, out); },
+                          td, dd, IW, ctx->inner_rtol, ctx->inner_maxit, &ctx->inner_its[2]));
+  }
   launch_merge(st, N2, V, dd, dv, dp, z);
   ctx->inner_calls += 1;
+  if (ctx->ss_samples_pending > 0) {      // sampled launch durations of the solid-block SpMV (first 8 of every apply)
+    (void)hipEventSynchronize(ctx->ss_ev1[ctx->ss_samples_pending - 1]);
+    for (int k = 0; k < ctx->ss_samples_pending; ++k) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ctx->ss_ev0[k], ctx->ss_ev1[k]) == hipSuccess) { ctx->t_ss.ms += ms; ctx->t_ss.calls += 1; }
+    }
+    ctx->ss_samples_pending = 0;
+  }
   return FSI_OK;
 }
 
@@ -252,7 +303,7 @@ int precondition(FsiCtx* ctx, const double* r, double* z) {
 }
 int spmv(FsiCtx* ctx, const double* x, double* y) {
   Phase ph(ctx, &ctx->t_spmv);
-  launch_spmv(ctx->stream, ctx->ndof, ctx->rowptr.p, ctx->cols.p, ctx->A.p, x, y);
+  launch_spmv(ctx->stream, ctx->ndof, ctx->rowptr.p, ctx->cols.p, ctx->A.p, x, y, SPMV_MONOLITHIC);
   return FSI_OK;
 }
 
@@ -382,6 +433,10 @@ int refresh_preconditioner(FsiCtx* ctx) {
   Phase ph(ctx, &ctx->t_fac);
   hipStream_t st = ctx->stream;
   int32_t flags[4] = {0, 0, 0, 0};
+  if (!ctx->coloured && (ctx->precond != 0 || ctx->cheb_its_d <= 0 || ctx->cheb_its_p <= 0)) {
+    ctx->err = "the ILU(0)-based solver options need the multicolour node ordering: create the context with FSI_ORDER=colour";
+    return FSI_ERR_INVALID;
+  }
   if (ctx->precond == 0) {
     launch_extract_blocks(st, ctx->N2, ctx->V, ctx->scheme.k * ctx->scheme.th0, ctx->rowptr.p, ctx->A.p, ctx->nadj_ptr.p,
                           ctx->nadj.p, ctx->padj_ptr.p, ctx->vrank.p, ctx->node_solid.p, ctx->rowptr3.p, ctx->rowptr_vp.p,
@@ -393,13 +448,31 @@ int refresh_preconditioner(FsiCtx* ctx) {
                     ctx->Mvv.vals.p, ctx->Ms.vals.p, ctx->iflags.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
-    if (flags[1] & 4) { ctx->err = "Schur complement: a vertex has more than 512 vertex neighbours"; return FSI_ERR_INVALID; }
+    launch_schur_full(st, ctx->V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->vrank.p, ctx->nadj_ptr.p, ctx->nadj.p, ctx->padj_ptr.p,
+                      ctx->padj.p, ctx->rowptr_pv.p, ctx->Apv.p, ctx->rowptr_pp.p, ctx->App.p, ctx->rowptr_vp.p, ctx->Avp.p,
+                      ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->s_vals.p, ctx->iflags.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
+    if (flags[1] & 4) { ctx->err = "Schur complement: a vertex has too many (two-ring) vertex neighbours"; return FSI_ERR_INVALID; }
+    {
+      const int64_t npairs = (int64_t)ctx->dd_db.n / 3;
+      launch_extract_db(st, ctx->N2, npairs, ctx->nadj_ptr.p, ctx->rowptr3.p, ctx->Mdd.vals.p, ctx->dd_db.p, ctx->iflags.p, 1);
+      launch_extract_db(st, ctx->N2, npairs, ctx->nadj_ptr.p, ctx->rowptr3.p, ctx->Mvv.vals.p, ctx->vv_db.p, ctx->iflags.p, 0);
+      HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
+      ctx->dd_is_db = !(flags[1] & 8);      // A_dd acts per component (always so for the forms of SURVEY.md A.2)
+    }
     launch_gather_vals(st, (int64_t)ctx->ss_vals.n, ctx->ss_src.p, ctx->Mvv.vals.p, ctx->ss_vals.p);
+    launch_sb_gather(st, ctx->sb_nblocks, ctx->sb_row.p, ctx->sb_src.p, ctx->sb_stride.p, ctx->Mvv.vals.p, ctx->sb_vals.p);
+    launch_sb_dinv(st, ctx->nS, ctx->snode.p, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->sb_dinv.p);
     FSICHK(power_lmax(ctx, ss_ref(ctx), nullptr, ctx->blk.p, &ctx->lmax_s));
-    FSICHK(power_lmax(ctx, vv_ref(ctx), ctx->mask_f.p, ctx->blk.p, &ctx->lmax_f));
+    FSICHK(power_lmax_op(ctx, 3 * ctx->N2, [&](const double* in, double* o) { launch_spmv_db(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->vv_db.p, in, o); },
+                         ctx->Mvv.vals.p, ctx->diagpos3.p, ctx->mask_f.p, ctx->blk.p, &ctx->lmax_f));
+    FSICHK(power_lmax(ctx, CsrRef{3 * ctx->N2, ctx->rowptr3.p, ctx->cols3.p, ctx->Mdd.vals.p, ctx->diagpos3.p}, nullptr,
+                      ctx->blk.p, &ctx->lmax_d));
     FSICHK(power_lmax_op(ctx, ctx->V, [&](const double* in, double* o) { schur_apply(ctx, in, o, ctx->blk.p + 17 * 3 * ctx->N2); },
-                         ctx->Ms.vals.p, ctx->diagpos_pp.p, nullptr, ctx->blk.p, &ctx->lmax_p));
+                         ctx->s_vals.p, ctx->s_diagpos.p, nullptr, ctx->blk.p, &ctx->lmax_p));
     for (SubMat* M : {&ctx->Mdd, &ctx->Ms}) {
+      if ((M == &ctx->Mdd && ctx->cheb_its_d > 0) || (M == &ctx->Ms && ctx->cheb_its_p > 0)) continue;   // Jacobi-Chebyshev: no factors
       HIPCHK(hipMemcpyAsync(M->LU.p, M->vals.p, M->nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
       launch_ilu0_levels(st, M->levels, M->rowptr, M->cols, M->diagpos, M->LU.p, ctx->iflags.p);
       HIPCHK(hipGetLastError());
@@ -422,6 +495,21 @@ int refresh_preconditioner(FsiCtx* ctx) {
 
 // =========================================================================================================
 extern "C" {
+
+int fsi_set_chebyshev(FsiCtx* ctx, int32_t its_solid, double kappa_solid, int32_t its_fluid, double kappa_fluid,
+                      int32_t its_schur, double kappa_schur, int32_t its_disp, double kappa_disp) {
+  if (!ctx) return FSI_ERR_INVALID;
+  if (its_disp > 0) ctx->cheb_its_d = its_disp;
+  if (kappa_disp > 1.0) ctx->cheb_kappa_d = kappa_disp;
+  if (its_solid > 0) ctx->cheb_its_s = its_solid;
+  if (kappa_solid > 1.0) ctx->cheb_kappa_s = kappa_solid;
+  if (its_fluid > 0) ctx->cheb_its_f = its_fluid;
+  if (kappa_fluid > 1.0) ctx->cheb_kappa_f = kappa_fluid;
+  if (its_schur > 0) ctx->cheb_its_p = its_schur;
+  if (kappa_schur > 1.0) ctx->cheb_kappa_p = kappa_schur;
+  ctx->kry_m = 0;     // the recycled directions were built with another (fixed) preconditioner
+  return FSI_OK;
+}
 
 int fsi_set_linear_solver(FsiCtx* ctx, int32_t precond, double inner_rtol, int32_t inner_max_it) {
   if (!ctx || precond < 0 || precond > 1) return FSI_ERR_INVALID;
@@ -457,11 +545,14 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->enbr.release();
   ctx->epnbr.release();
   for (auto* b : {&ctx->Adv, &ctx->Avp, &ctx->Apv, &ctx->App, &ctx->blk, &ctx->Mdd.vals, &ctx->Mdd.LU, &ctx->Mvv.vals,
-                  &ctx->Mvv.LU, &ctx->Ms.vals, &ctx->Ms.LU, &ctx->mask_s, &ctx->mask_f, &ctx->ss_vals}) b->release();
-  for (auto* b : {&ctx->snode, &ctx->ss_cols}) b->release();
+                  &ctx->Mvv.LU, &ctx->Ms.vals, &ctx->Ms.LU, &ctx->mask_s, &ctx->mask_f, &ctx->ss_vals, &ctx->dd_db, &ctx->vv_db, &ctx->s_vals}) b->release();
+  ctx->s_rowptr.release(); ctx->s_diagpos.release(); ctx->s_cols.release();
+  for (auto* b : {&ctx->snode, &ctx->ss_cols, &ctx->sb_col, &ctx->sb_row, &ctx->sb_stride}) b->release();
+  ctx->sb_ptr.release(); ctx->sb_src.release(); ctx->sb_vals.release(); ctx->sb_dinv.release();
   for (auto* b : {&ctx->ss_rowptr, &ctx->ss_diagpos, &ctx->ss_src}) b->release();
   for (auto* b : {&ctx->node_solid, &ctx->vrank, &ctx->cols3, &ctx->cols_vp, &ctx->cols_pv, &ctx->cols_pp}) b->release();
   for (auto* b : {&ctx->rowptr3, &ctx->diagpos3, &ctx->rowptr_vp, &ctx->rowptr_pv, &ctx->rowptr_pp, &ctx->diagpos_pp}) b->release();
+  for (int k = 0; k < 8; ++k) { if (ctx->ss_ev0[k]) (void)hipEventDestroy(ctx->ss_ev0[k]); if (ctx->ss_ev1[k]) (void)hipEventDestroy(ctx->ss_ev1[k]); }
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -560,8 +651,15 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   std::vector<uint64_t>().swap(pairs);
 
   // ---- greedy multicolouring of the node graph (base order): nodes of one colour share no element -----------------
-  std::vector<int32_t> color(N2, -1);
+  // (only the ILU(0) paths need it; the default Chebyshev-based preconditioner keeps the mesh's own node order, whose
+  //  locality is what the gathers of every SpMV live on.  FSI_ORDER=colour selects the multicolour ordering.)
   {
+    const char* e = getenv("FSI_ORDER");
+    ctx->coloured = e && (e[0] == 'c' || e[0] == 'C');
+  }
+  std::vector<int32_t> color(N2, ctx->coloured ? -1 : 0);
+  if (!ctx->coloured) ctx->ncolors = 1;
+  if (ctx->coloured) {
     std::vector<int32_t> mark(1024, -1);
     for (int64_t r = 0; r < N2; ++r) {
       const int32_t nd = base[r];
@@ -757,18 +855,46 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
           ss_rowptr[3 * i + c + 1] = (int64_t)ss_cols.size();
         }
       }
+      {   // block-CSR structure of the same block
+        std::vector<int64_t> sb_ptr(nS + 1, 0), sb_src;
+        std::vector<int32_t> sb_col, sb_row, sb_stride(nS);
+        for (int64_t i = 0; i < nS; ++i) {
+          const int64_t r = snode[i], a = ctx->h_nadj_ptr[r], deg = ctx->h_nadj_ptr[r + 1] - a;
+          sb_stride[i] = (int32_t)(3 * deg);
+          for (int64_t k = 0; k < deg; ++k) {
+            const int32_t si = sidx[ctx->h_nadj[a + k]];
+            if (si < 0) continue;
+            sb_col.push_back(si);
+            sb_row.push_back((int32_t)i);
+            sb_src.push_back(9 * a + 3 * k);
+          }
+          sb_ptr[i + 1] = (int64_t)sb_col.size();
+        }
+        ctx->sb_nblocks = (int64_t)sb_col.size();
+        FSICHK(upload(ctx, ctx->sb_ptr, sb_ptr));
+        FSICHK(upload(ctx, ctx->sb_src, sb_src));
+        FSICHK(upload(ctx, ctx->sb_col, sb_col));
+        FSICHK(upload(ctx, ctx->sb_row, sb_row));
+        FSICHK(upload(ctx, ctx->sb_stride, sb_stride));
+        HIPCHK(ctx->sb_vals.alloc(9 * sb_col.size()));
+        HIPCHK(ctx->sb_dinv.alloc(3 * nS));
+        if (const char* e = getenv("FSI_SOLID_FP32")) ctx->solid_fp32 = atoi(e);
+      }
       FSICHK(upload(ctx, ctx->snode, snode));
       FSICHK(upload(ctx, ctx->ss_rowptr, ss_rowptr));
       FSICHK(upload(ctx, ctx->ss_diagpos, ss_diagpos));
       FSICHK(upload(ctx, ctx->ss_cols, ss_cols));
       FSICHK(upload(ctx, ctx->ss_src, ss_src));
       HIPCHK(ctx->ss_vals.alloc(ss_cols.size()));
+      for (int k = 0; k < 8; ++k) { HIPCHK(hipEventCreate(&ctx->ss_ev0[k])); HIPCHK(hipEventCreate(&ctx->ss_ev1[k])); }
       FSICHK(upload(ctx, ctx->mask_s, ms));
       FSICHK(upload(ctx, ctx->mask_f, mf));
       if (const char* e = getenv("FSI_CHEB_S")) ctx->cheb_its_s = atoi(e);
       if (const char* e = getenv("FSI_CHEB_F")) ctx->cheb_its_f = atoi(e);
       if (const char* e = getenv("FSI_KAPPA_S")) ctx->cheb_kappa_s = atof(e);
       if (const char* e = getenv("FSI_KAPPA_F")) ctx->cheb_kappa_f = atof(e);
+      if (const char* e = getenv("FSI_CHEB_D")) ctx->cheb_its_d = atoi(e);
+      if (const char* e = getenv("FSI_KAPPA_D")) ctx->cheb_kappa_d = atof(e);
       if (const char* e = getenv("FSI_CHEB_P")) ctx->cheb_its_p = atoi(e);
       if (const char* e = getenv("FSI_KAPPA_P")) ctx->cheb_kappa_p = atof(e);
     }
@@ -805,6 +931,8 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
                            ctx->rowptr_pv.p, ctx->cols_pv.p);
     HIPCHK(hipGetLastError());
     HIPCHK(ctx->Adv.alloc(9 * nadj_total));
+    HIPCHK(ctx->dd_db.alloc(3 * nadj_total));
+    HIPCHK(ctx->vv_db.alloc(3 * nadj_total));
     HIPCHK(ctx->Avp.alloc(3 * padj_total));
     HIPCHK(ctx->Apv.alloc(rowptr_pv[V]));
     HIPCHK(ctx->App.alloc(rowptr_pp[V]));
@@ -823,6 +951,31 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
       else ctx->Ms.levels.push_back(Level{L.first_row - 6 * N2, L.ngroups, 1});
     }
     ctx->Mvv.levels = ctx->Mdd.levels;
+    {   // pattern of the explicit Schur complement: vertices that share a velocity node's element neighbourhood
+      std::vector<int64_t> s_rowptr(V + 1, 0), s_diagpos(V, 0);
+      std::vector<int32_t> s_cols, mark(V, -1), row;
+      s_cols.reserve((size_t)V * 64);
+      for (int64_t q = 0; q < V; ++q) {
+        const int32_t r = prow_rank[q];
+        row.clear();
+        for (int64_t kb = ctx->h_nadj_ptr[r]; kb < ctx->h_nadj_ptr[r + 1]; ++kb) {
+          const int32_t b = ctx->h_nadj[kb];
+          for (int64_t t = ctx->h_padj_ptr[b]; t < ctx->h_padj_ptr[b + 1]; ++t) {
+            const int32_t u = ctx->h_padj[t];
+            if (mark[u] != (int32_t)q) { mark[u] = (int32_t)q; row.push_back(u); }
+          }
+        }
+        std::sort(row.begin(), row.end());
+        for (size_t t = 0; t < row.size(); ++t)
+          if (row[t] == (int32_t)q) s_diagpos[q] = (int64_t)s_cols.size() + (int64_t)t;
+        s_cols.insert(s_cols.end(), row.begin(), row.end());
+        s_rowptr[q + 1] = (int64_t)s_cols.size();
+      }
+      FSICHK(upload(ctx, ctx->s_rowptr, s_rowptr));
+      FSICHK(upload(ctx, ctx->s_diagpos, s_diagpos));
+      FSICHK(upload(ctx, ctx->s_cols, s_cols));
+      HIPCHK(ctx->s_vals.alloc(s_cols.size()));
+    }
     HIPCHK(ctx->blk.alloc((size_t)18 * 3 * N2));
   }
   HIPCHK(hipMemsetAsync(ctx->A_pre.p, 0, ctx->nnz * sizeof(double), ctx->stream));
@@ -831,7 +984,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
   int64_t cap = (int64_t)((double)free_b * 0.5 / (16.0 * (double)n));
-  cap = std::max<int64_t>(8, std::min<int64_t>(cap, 1000));
+  cap = std::max<int64_t>(8, std::min<int64_t>(cap, getenv("FSI_KRYLOV_CAP") ? atoi(getenv("FSI_KRYLOV_CAP")) : 400));
   ctx->kry_cap = cap;
   HIPCHK(ctx->KP.alloc((size_t)cap * n));
   HIPCHK(ctx->KQ.alloc((size_t)cap * n));
@@ -1125,7 +1278,7 @@ int fsi_spmv(FsiCtx* ctx, const double* x, double* y) {
   const int64_t n = ctx->ndof;
   HIPCHK(hipMemcpyAsync(ctx->tmp7.p, x, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   launch_scatter(ctx->stream, ctx->tmp1.p, ctx->tmp7.p, ctx->user2solver.p, n);
-  launch_spmv(ctx->stream, n, ctx->rowptr.p, ctx->cols.p, ctx->A.p, ctx->tmp1.p, ctx->tmp2.p);
+  launch_spmv(ctx->stream, n, ctx->rowptr.p, ctx->cols.p, ctx->A.p, ctx->tmp1.p, ctx->tmp2.p, SPMV_MONOLITHIC);
   // undo the row equilibration: y = D^-1 (D A) x
   launch_gather(ctx->stream, ctx->tmp7.p, ctx->tmp2.p, ctx->user2solver.p, n);
   std::vector<double> ys(n), sc(n);
@@ -1142,9 +1295,10 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
   *out = FsiTimers{ctx->t_res.ms,  ctx->t_res.calls,  ctx->t_jac.ms,   ctx->t_jac.calls,   ctx->t_fac.ms, ctx->t_fac.calls,
                    ctx->t_spmv.ms, ctx->t_spmv.calls, ctx->t_prec.ms,  ctx->t_prec.calls,  ctx->t_ortho.ms,
                    ctx->t_ortho.calls, ctx->t_kry.ms, ctx->t_kry.calls, ctx->kry_iters,
-                   ctx->inner_its[0], ctx->inner_its[1], ctx->inner_its[2], ctx->inner_calls};
+                   ctx->inner_its[0], ctx->inner_its[1], ctx->inner_its[2], ctx->inner_calls,
+                   ctx->t_ss.ms, ctx->t_ss.calls, ctx->solid_fp32 ? 9 * ctx->sb_nblocks : (int64_t)ctx->ss_vals.n, 3 * ctx->nS};
   if (reset) {
-    for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_kry}) {
+    for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_kry, &ctx->t_ss}) {
       t->ms = 0.0;
       t->calls = 0;
     }

@@ -89,6 +89,7 @@ struct FsiCtx {
   std::vector<int32_t> h_prank;               // vertex -> position in the pressure block
   std::vector<fsi::Level> levels;
   int ncolors = 0;
+  bool coloured = false;                     // multicolour node ordering (needed by the ILU(0) kernels) or mesh order
   fsi::DevBuf<int64_t> nadj_ptr, padj_ptr;
   fsi::DevBuf<int32_t> nadj, padj;
   fsi::DevBuf<int64_t> rowptr;               // [ndof+1]
@@ -128,15 +129,25 @@ struct FsiCtx {
   fsi::DevBuf<int64_t> rowptr_vp, rowptr_pv, rowptr_pp, diagpos_pp;
   fsi::DevBuf<int32_t> cols_vp, cols_pv, cols_pp;
   fsi::DevBuf<double> Adv, Avp, Apv, App;
+  fsi::DevBuf<int64_t> s_rowptr, s_diagpos;  // explicit Schur complement on its full (two-ring) vertex pattern
+  fsi::DevBuf<int32_t> s_cols;
+  fsi::DevBuf<double> s_vals;
+  fsi::DevBuf<double> dd_db, vv_db;          // component-diagonal node-block copies of A_dd and Avv~ ([pairs][3])
+  bool dd_is_db = false;
   fsi::SubMat Mdd, Mvv, Ms;                  // A_dd, Avv~, sparsified Schur complement (ILU only)
   fsi::DevBuf<double> blk;                   // work vectors of the block preconditioner
   int64_t nS = 0;                            // solid (incl. interface) nodes; compact velocity block A_SS on them
   fsi::DevBuf<int32_t> snode, ss_cols;
   fsi::DevBuf<int64_t> ss_rowptr, ss_diagpos, ss_src;
   fsi::DevBuf<double> ss_vals;
+  int64_t sb_nblocks = 0;                    // FP32 block-CSR copy of A_SS used by the Chebyshev sweeps
+  fsi::DevBuf<int64_t> sb_ptr, sb_src;
+  fsi::DevBuf<int32_t> sb_col, sb_row, sb_stride;
+  fsi::DevBuf<float> sb_vals, sb_dinv;
+  int solid_fp32 = 1;
   fsi::DevBuf<double> mask_s, mask_f;        // [3 N2] 1 on velocity dofs of solid (incl. interface) / fluid-interior nodes
-  int cheb_its_s = 300, cheb_its_f = 20, cheb_its_p = 40;     // Chebyshev sweeps on the solid / fluid part of the velocity block
-  double cheb_kappa_s = 1e4, cheb_kappa_f = 100.0, cheb_kappa_p = 100.0, lmax_s = 1.0, lmax_f = 1.0, lmax_p = 1.0;
+  int cheb_its_s = 300, cheb_its_f = 20, cheb_its_p = 80, cheb_its_d = 60;     // Chebyshev sweeps on the solid / fluid part of the velocity block
+  double cheb_kappa_s = 1e4, cheb_kappa_f = 100.0, cheb_kappa_p = 400.0, lmax_s = 1.0, lmax_f = 1.0, lmax_p = 1.0, cheb_kappa_d = 1000.0, lmax_d = 1.0;
   double inner_rtol = 1e-2;
   int inner_maxit = 40, inner_maxit_p = 60;
   int64_t inner_its[3] = {0, 0, 0};          // accumulated inner iterations: vv, schur, dd
@@ -149,7 +160,9 @@ struct FsiCtx {
   fsi::DevBuf<double> hcoef;                 // [kry_cap] coefficients on device
 
   // timers
-  fsi::PhaseTimer t_res, t_jac, t_fac, t_spmv, t_prec, t_ortho, t_kry;
+  fsi::PhaseTimer t_res, t_jac, t_fac, t_spmv, t_prec, t_ortho, t_kry, t_ss;
+  hipEvent_t ss_ev0[8] = {}, ss_ev1[8] = {};
+  int ss_samples_pending = 0;
   int64_t kry_iters = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 

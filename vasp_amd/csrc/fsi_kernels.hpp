@@ -51,8 +51,9 @@ void launch_matrix_finish(hipStream_t st, int64_t n, const int64_t* rowptr, cons
 void launch_robin_residual(hipStream_t st, int64_t n, const int32_t* row, const int32_t* col, const double* val,
                            double th0, double th1, const double* U, const double* U1, double* F);
 void launch_add_at(hipStream_t st, double* vals, const int64_t* pos, const double* v, double a, int64_t n);
+enum SpmvTag : int { SPMV_MONOLITHIC = 0, SPMV_SOLID_BLOCK = 1, SPMV_FIELD_BLOCK = 2 };
 void launch_spmv(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const double* vals,
-                 const double* x, double* y);
+                 const double* x, double* y, int tag = SPMV_FIELD_BLOCK);
 // reductions: out[0] = x.y (deterministic two-stage); scratch must hold >= 4096 doubles
 void launch_dot(hipStream_t st, const double* x, const double* y, int64_t n, double* scratch, double* out);
 // h[i] = Q_i . w for i < m  (Q stored as m contiguous vectors of length n); then w -= sum_i h[i] Q_i
@@ -79,6 +80,11 @@ void launch_schur_p1(hipStream_t st, int64_t V, const int32_t* vrank, const int6
                      const int64_t* padj_ptr, const int32_t* padj, const int64_t* rowptr_pv, const double* Apv,
                      const int64_t* rowptr_pp, const double* App, const int64_t* rowptr_vp, const double* Avp,
                      const int64_t* diagpos3, const double* Avv, double* S1, int32_t* flags);
+void launch_schur_full(hipStream_t st, int64_t V, const int64_t* s_rowptr, const int32_t* s_cols, const int32_t* vrank,
+                       const int64_t* nadj_ptr, const int32_t* nadj, const int64_t* padj_ptr, const int32_t* padj,
+                       const int64_t* rowptr_pv, const double* Apv, const int64_t* rowptr_pp, const double* App,
+                       const int64_t* rowptr_vp, const double* Avp, const int64_t* diagpos3, const double* Avv, double* S,
+                       int32_t* flags);
 void launch_split(hipStream_t st, int64_t N2, int64_t V, const double* r, double* rd, double* rv, double* rp);
 void launch_merge(hipStream_t st, int64_t N2, int64_t V, const double* zd, const double* zv, const double* zp, double* z);
 void launch_vel_correct(hipStream_t st, int64_t n3, const int64_t* rowptr, const int32_t* cols, const double* vals,
@@ -90,6 +96,19 @@ void launch_cheb_init(hipStream_t st, int64_t n, const double* mask, const doubl
                       const double* A, double inv_theta, double* x, double* r, double* d);
 void launch_cheb_step(hipStream_t st, int64_t n, const double* mask, const double* t, const int64_t* diagpos,
                       const double* A, double c1, double c2, double* x, double* r, double* d);
+void launch_extract_db(hipStream_t st, int64_t N2, int64_t npairs, const int64_t* nadj_ptr, const int64_t* rowptr3,
+                       const double* vals, double* db, int32_t* flags, int check);
+void launch_spmv_db(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
+                    const double* x, double* y);
+void launch_sb_gather(hipStream_t st, int64_t nb, const int32_t* sb_row, const int64_t* sb_src, const int32_t* sb_stride,
+                      const double* Avv, float* vals);
+void launch_sb_dinv(hipStream_t st, int64_t nS, const int32_t* snode, const int64_t* diagpos3, const double* Avv, float* dinv);
+void launch_spmv_sb(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
+                    const float* x, float* y);
+void launch_cheb_init_f32(hipStream_t st, int64_t n, const float* rhs, const float* dinv, float inv_theta, float* x, float* r, float* d);
+void launch_cheb_step_f32(hipStream_t st, int64_t n, const float* t, const float* dinv, float c1, float c2, float* x, float* r, float* d);
+void launch_gather3_f32(hipStream_t st, int64_t nS, const int32_t* snode, const double* full, float* comp);
+void launch_scatter3_f32(hipStream_t st, int64_t nS, const int32_t* snode, const float* comp, double* full);
 void launch_gather_vals(hipStream_t st, int64_t n, const int64_t* pos, const double* src, double* dst);
 void launch_gather3(hipStream_t st, int64_t nS, const int32_t* snode, const double* full, double* comp);
 void launch_scatter3(hipStream_t st, int64_t nS, const int32_t* snode, const double* comp, double* full);

@@ -182,6 +182,8 @@ void launch_matrix_finish(hipStream_t st, int64_t n, const int64_t* rowptr, cons
 // ---------------------------------------------------------------------------------------------------------
 // SpMV, one wave per row (rows have ~100-400 entries)
 // ---------------------------------------------------------------------------------------------------------
+// TAG only names the instantiation (profiles list the monolithic, solid-block and other-block products separately)
+template <int TAG>
 __global__ __launch_bounds__(256) void k_spmv(int64_t n, const int64_t* __restrict__ rowptr,
                                               const int32_t* __restrict__ cols, const double* __restrict__ vals,
                                               const double* __restrict__ x, double* __restrict__ y) {
@@ -197,10 +199,15 @@ __global__ __launch_bounds__(256) void k_spmv(int64_t n, const int64_t* __restri
   }
 }
 void launch_spmv(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const double* vals,
-                 const double* x, double* y) {
+                 const double* x, double* y, int tag) {
   int64_t blocks = (n + 3) / 4;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(k_spmv, dim3((unsigned)blocks), dim3(256), 0, st, n, rowptr, cols, vals, x, y);
+  if (tag == SPMV_MONOLITHIC)
+    hipLaunchKernelGGL(k_spmv<SPMV_MONOLITHIC>, dim3((unsigned)blocks), dim3(256), 0, st, n, rowptr, cols, vals, x, y);
+  else if (tag == SPMV_SOLID_BLOCK)
+    hipLaunchKernelGGL(k_spmv<SPMV_SOLID_BLOCK>, dim3((unsigned)blocks), dim3(256), 0, st, n, rowptr, cols, vals, x, y);
+  else
+    hipLaunchKernelGGL(k_spmv<SPMV_FIELD_BLOCK>, dim3((unsigned)blocks), dim3(256), 0, st, n, rowptr, cols, vals, x, y);
 }
 
 // ---------------------------------------------------------------------------------------------------------
