@@ -416,6 +416,44 @@ __global__ __launch_bounds__(256) void k_spmv_db(int64_t N2, const int64_t* __re
     if (sub == 0) { y[3 * r] = s0; y[3 * r + 1] = s1; y[3 * r + 2] = s2; }
   }
 }
+// FP32 variants for the preconditioner sweeps (values converted once per Jacobian refresh)
+__global__ __launch_bounds__(256) void k_spmv_db_f32(int64_t N2, const int64_t* __restrict__ nadj_ptr,
+                                                     const int32_t* __restrict__ nadj, const float* __restrict__ db,
+                                                     const float* __restrict__ x, float* __restrict__ y) {
+  const int sub = threadIdx.x & 15;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t r = grp; r < N2; r += ngrp) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int64_t e = nadj_ptr[r] + sub; e < nadj_ptr[r + 1]; e += 16) {
+      const float* xs = x + 3 * (int64_t)nadj[e];
+      const float* c = db + 3 * e;
+      s0 += c[0] * xs[0]; s1 += c[1] * xs[1]; s2 += c[2] * xs[2];
+    }
+    for (int off = 8; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
+    }
+    if (sub == 0) { y[3 * r] = s0; y[3 * r + 1] = s1; y[3 * r + 2] = s2; }
+  }
+}
+__global__ void k_to_f32(int64_t n, const double* __restrict__ a, float* __restrict__ b) { GS(i, n) b[i] = (float)a[i]; }
+__global__ void k_from_f32(int64_t n, const float* __restrict__ a, double* __restrict__ b) { GS(i, n) b[i] = (double)a[i]; }
+// dinv[i] = mask[i] / A[diagpos[i]]  (mask may be null)
+__global__ void k_dinv_f32(int64_t n, const double* __restrict__ mask, const int64_t* __restrict__ diagpos,
+                           const double* __restrict__ A, float* __restrict__ dinv) {
+  GS(i, n) dinv[i] = (float)((mask ? mask[i] : 1.0) / A[diagpos[i]]);
+}
+void launch_spmv_db_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const float* db,
+                        const float* x, float* y) {
+  int64_t blocks = (N2 + 15) / 16;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_spmv_db_f32, dim3((unsigned)blocks), dim3(256), 0, st, N2, nadj_ptr, nadj, db, x, y);
+}
+void launch_to_f32(hipStream_t st, int64_t n, const double* a, float* b) { hipLaunchKernelGGL(k_to_f32, dim3(gridn(n)), dim3(256), 0, st, n, a, b); }
+void launch_from_f32(hipStream_t st, int64_t n, const float* a, double* b) { hipLaunchKernelGGL(k_from_f32, dim3(gridn(n)), dim3(256), 0, st, n, a, b); }
+void launch_dinv_f32(hipStream_t st, int64_t n, const double* mask, const int64_t* diagpos, const double* A, float* dinv) {
+  hipLaunchKernelGGL(k_dinv_f32, dim3(gridn(n)), dim3(256), 0, st, n, mask, diagpos, A, dinv);
+}
 void launch_extract_db(hipStream_t st, int64_t N2, int64_t npairs, const int64_t* nadj_ptr, const int64_t* rowptr3,
                        const double* vals, double* db, int32_t* flags, int check) {
   hipLaunchKernelGGL(k_extract_db, dim3(gridn(npairs)), dim3(256), 0, st, N2, nadj_ptr, rowptr3, vals, db, flags, check);

@@ -197,6 +197,26 @@ void schur_apply(FsiCtx* ctx, const double* in, double* out, double* w3) {
   launch_spmv(ctx->stream, ctx->V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->s_vals.p, in, out, SPMV_FIELD_BLOCK);
 }
 
+// FP32 Chebyshev sweeps on a component-diagonal node-block matrix; dinv carries the Jacobi scaling and the mask
+void cheb_db_f32(FsiCtx* ctx, const float* db, const float* dinv, const double* rhs, double* x, double* W, int its,
+                 double lmax, double kappa) {
+  const int64_t n = 3 * ctx->N2;
+  hipStream_t st = ctx->stream;
+  float* F = reinterpret_cast<float*>(W);
+  float *fr = F, *fd = F + n, *ft = F + 2 * n, *fx = F + 3 * n, *frhs = F + 4 * n;
+  launch_to_f32(st, n, rhs, frhs);
+  const double lmin = lmax / kappa, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
+  double rho = 1.0 / sig;
+  launch_cheb_init_f32(st, n, frhs, dinv, (float)(1.0 / th), fx, fr, fd);
+  for (int k = 0; k < its; ++k) {
+    launch_spmv_db_f32(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, db, fd, ft);
+    const double rn = 1.0 / (2.0 * sig - rho);
+    launch_cheb_step_f32(st, n, ft, dinv, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
+    rho = rn;
+  }
+  launch_from_f32(st, n, fx, x);
+}
+
 // z = M^-1 r with the approximate block factorisation (see fsi_block.hip):  (v,p) by SIMPLE with the d-eliminated
 // velocity block, then d.
 int precondition_block(FsiCtx* ctx, const double* r, double* z) {
@@ -250,8 +270,11 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
     launch_scatter3(st, ctx->nS, ctx->snode.p, cs_x, xs);
     }
     launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Mvv.vals.p, xs, rv, rhs2);
-    cheb_solve_op(ctx, n3, [&](const double* in, double* out) { launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->vv_db.p, in, out); },
-                  ctx->Mvv.vals.p, ctx->diagpos3.p, ctx->mask_f.p, rhs2, xf, IW, ctx->cheb_its_f, ctx->lmax_f, ctx->cheb_kappa_f);
+    if (ctx->sweeps_fp32)
+      cheb_db_f32(ctx, ctx->vv_db32.p, ctx->vvf_dinv32.p, rhs2, xf, IW, ctx->cheb_its_f, ctx->lmax_f, ctx->cheb_kappa_f);
+    else
+      cheb_solve_op(ctx, n3, [&](const double* in, double* out) { launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->vv_db.p, in, out); },
+                    ctx->Mvv.vals.p, ctx->diagpos3.p, ctx->mask_f.p, rhs2, xf, IW, ctx->cheb_its_f, ctx->lmax_f, ctx->cheb_kappa_f);
     launch_axpby(st, vs, 1.0, xs, 1.0, xf, n3);
     ctx->inner_its[0] += ctx->cheb_its_s + ctx->cheb_its_f;
   }
@@ -268,9 +291,16 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   }
   // velocity correction and displacement
   launch_vel_correct(st, n3, ctx->rowptr_vp.p, ctx->cols_vp.p, ctx->Avp.p, dp, ctx->diagpos3.p, ctx->Mvv.vals.p, vs, dv);
-  launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Adv.p, dv, rd, td);
+  if (ctx->adv_is_db) {
+    launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->adv_db.p, dv, w3);
+    launch_axpby(st, td, 1.0, rd, -1.0, w3, n3);
+  } else {
+    launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Adv.p, dv, rd, td);
+  }
   if (ctx->cheb_its_d > 0) {
-    if (ctx->dd_is_db)
+    if (ctx->dd_is_db && ctx->sweeps_fp32)
+      cheb_db_f32(ctx, ctx->dd_db32.p, ctx->dd_dinv32.p, td, dd, IW, ctx->cheb_its_d, ctx->lmax_d, ctx->cheb_kappa_d);
+    else if (ctx->dd_is_db)
       cheb_solve_op(ctx, n3, [&](const double* in, double* out) { launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_db.p, in, out); },
                     ctx->Mdd.vals.p, ctx->diagpos3.p, nullptr, td, dd, IW, ctx->cheb_its_d, ctx->lmax_d, ctx->cheb_kappa_d);
     else
@@ -334,16 +364,23 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
     FSICHK(precondition(ctx, r, z));
     FSICHK(spmv(ctx, z, w));
     m = (int)std::min<int64_t>(ctx->kry_m, ctx->kry_cap);
+    double wn = 0.0;
     if (m > 0) {
       Phase ph(ctx, &ctx->t_ortho);
-      for (int pass = 0; pass < 2; ++pass) {   // classical Gram-Schmidt, twice
+      // classical Gram-Schmidt; a second pass only when the first one cancelled most of w (Daniel et al. criterion)
+      double w0 = 0.0;
+      FSICHK(norm2(ctx, w, &w0));
+      for (int pass = 0; pass < 2; ++pass) {
         launch_multi_dot(st, ctx->KQ.p, n, m, w, ctx->scratch.p, ctx->hcoef.p);
         launch_multi_axpy(st, ctx->KQ.p, n, m, ctx->hcoef.p, -1.0, w);
         launch_multi_axpy(st, ctx->KP.p, n, m, ctx->hcoef.p, -1.0, z);
+        FSICHK(norm2(ctx, w, &wn));
+        if (wn > 0.5 * w0) break;
+        w0 = wn;
       }
+    } else {
+      FSICHK(norm2(ctx, w, &wn));
     }
-    double wn = 0.0;
-    FSICHK(norm2(ctx, w, &wn));
     if (!(wn > 0.0) || !std::isfinite(wn)) { ctx->err = "GCR breakdown (A M^-1 r vanished or is not finite)"; return FSI_ERR_LINEAR; }
     launch_scale(st, w, 1.0 / wn, n);
     launch_scale(st, z, 1.0 / wn, n);
@@ -460,6 +497,14 @@ int refresh_preconditioner(FsiCtx* ctx) {
       launch_extract_db(st, ctx->N2, npairs, ctx->nadj_ptr.p, ctx->rowptr3.p, ctx->Mvv.vals.p, ctx->vv_db.p, ctx->iflags.p, 0);
       HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
       ctx->dd_is_db = !(flags[1] & 8);      // A_dd acts per component (always so for the forms of SURVEY.md A.2)
+      HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
+      launch_extract_db(st, ctx->N2, npairs, ctx->nadj_ptr.p, ctx->rowptr3.p, ctx->Adv.p, ctx->adv_db.p, ctx->iflags.p, 1);
+      HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
+      ctx->adv_is_db = !(flags[1] & 8);
+      launch_to_f32(st, 3 * npairs, ctx->dd_db.p, ctx->dd_db32.p);
+      launch_to_f32(st, 3 * npairs, ctx->vv_db.p, ctx->vv_db32.p);
+      launch_dinv_f32(st, 3 * ctx->N2, nullptr, ctx->diagpos3.p, ctx->Mdd.vals.p, ctx->dd_dinv32.p);
+      launch_dinv_f32(st, 3 * ctx->N2, ctx->mask_f.p, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->vvf_dinv32.p);
     }
     launch_gather_vals(st, (int64_t)ctx->ss_vals.n, ctx->ss_src.p, ctx->Mvv.vals.p, ctx->ss_vals.p);
     launch_sb_gather(st, ctx->sb_nblocks, ctx->sb_row.p, ctx->sb_src.p, ctx->sb_stride.p, ctx->Mvv.vals.p, ctx->sb_vals.p);
@@ -545,10 +590,11 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->enbr.release();
   ctx->epnbr.release();
   for (auto* b : {&ctx->Adv, &ctx->Avp, &ctx->Apv, &ctx->App, &ctx->blk, &ctx->Mdd.vals, &ctx->Mdd.LU, &ctx->Mvv.vals,
-                  &ctx->Mvv.LU, &ctx->Ms.vals, &ctx->Ms.LU, &ctx->mask_s, &ctx->mask_f, &ctx->ss_vals, &ctx->dd_db, &ctx->vv_db, &ctx->s_vals}) b->release();
+                  &ctx->Mvv.LU, &ctx->Ms.vals, &ctx->Ms.LU, &ctx->mask_s, &ctx->mask_f, &ctx->ss_vals, &ctx->dd_db, &ctx->vv_db, &ctx->adv_db, &ctx->s_vals}) b->release();
   ctx->s_rowptr.release(); ctx->s_diagpos.release(); ctx->s_cols.release();
   for (auto* b : {&ctx->snode, &ctx->ss_cols, &ctx->sb_col, &ctx->sb_row, &ctx->sb_stride}) b->release();
   ctx->sb_ptr.release(); ctx->sb_src.release(); ctx->sb_vals.release(); ctx->sb_dinv.release();
+  ctx->dd_db32.release(); ctx->vv_db32.release(); ctx->dd_dinv32.release(); ctx->vvf_dinv32.release();
   for (auto* b : {&ctx->ss_rowptr, &ctx->ss_diagpos, &ctx->ss_src}) b->release();
   for (auto* b : {&ctx->node_solid, &ctx->vrank, &ctx->cols3, &ctx->cols_vp, &ctx->cols_pv, &ctx->cols_pp}) b->release();
   for (auto* b : {&ctx->rowptr3, &ctx->diagpos3, &ctx->rowptr_vp, &ctx->rowptr_pv, &ctx->rowptr_pp, &ctx->diagpos_pp}) b->release();
@@ -933,6 +979,12 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
     HIPCHK(ctx->Adv.alloc(9 * nadj_total));
     HIPCHK(ctx->dd_db.alloc(3 * nadj_total));
     HIPCHK(ctx->vv_db.alloc(3 * nadj_total));
+    HIPCHK(ctx->adv_db.alloc(3 * nadj_total));
+    HIPCHK(ctx->dd_db32.alloc(3 * nadj_total));
+    HIPCHK(ctx->vv_db32.alloc(3 * nadj_total));
+    HIPCHK(ctx->dd_dinv32.alloc(3 * N2));
+    HIPCHK(ctx->vvf_dinv32.alloc(3 * N2));
+    if (const char* e = getenv("FSI_SWEEPS_FP32")) ctx->sweeps_fp32 = atoi(e);
     HIPCHK(ctx->Avp.alloc(3 * padj_total));
     HIPCHK(ctx->Apv.alloc(rowptr_pv[V]));
     HIPCHK(ctx->App.alloc(rowptr_pp[V]));

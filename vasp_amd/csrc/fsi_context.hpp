@@ -133,7 +133,10 @@ struct FsiCtx {
   fsi::DevBuf<int32_t> s_cols;
   fsi::DevBuf<double> s_vals;
   fsi::DevBuf<double> dd_db, vv_db;          // component-diagonal node-block copies of A_dd and Avv~ ([pairs][3])
-  bool dd_is_db = false;
+  fsi::DevBuf<double> adv_db;
+  bool dd_is_db = false, adv_is_db = false;
+  fsi::DevBuf<float> dd_db32, vv_db32, dd_dinv32, vvf_dinv32;   // FP32 copies for the Chebyshev sweeps
+  int sweeps_fp32 = 1;
   fsi::SubMat Mdd, Mvv, Ms;                  // A_dd, Avv~, sparsified Schur complement (ILU only)
   fsi::DevBuf<double> blk;                   // work vectors of the block preconditioner
   int64_t nS = 0;                            // solid (incl. interface) nodes; compact velocity block A_SS on them

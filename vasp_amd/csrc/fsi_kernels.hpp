@@ -100,6 +100,11 @@ void launch_extract_db(hipStream_t st, int64_t N2, int64_t npairs, const int64_t
                        const double* vals, double* db, int32_t* flags, int check);
 void launch_spmv_db(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
                     const double* x, double* y);
+void launch_spmv_db_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const float* db,
+                        const float* x, float* y);
+void launch_to_f32(hipStream_t st, int64_t n, const double* a, float* b);
+void launch_from_f32(hipStream_t st, int64_t n, const float* a, double* b);
+void launch_dinv_f32(hipStream_t st, int64_t n, const double* mask, const int64_t* diagpos, const double* A, float* dinv);
 void launch_sb_gather(hipStream_t st, int64_t nb, const int32_t* sb_row, const int64_t* sb_src, const int32_t* sb_stride,
                       const double* Avv, float* vals);
 void launch_sb_dinv(hipStream_t st, int64_t nS, const int32_t* snode, const int64_t* diagpos3, const double* Avv, float* dinv);
