@@ -68,7 +68,8 @@ typedef struct FsiNewtonOpts {
   int32_t recompute_tstep;     /* ... and every `recompute_tstep` time steps                                */
   int32_t counter;             /* time-step counter of this call                                            */
   int32_t first_step_num;      /* counter value of the first step of this run (forces a Jacobian)           */
-  double lin_rtol;             /* Krylov stop: ||r|| <= lin_rtol * ||b||   (row-equilibrated norms)         */
+  double lin_rtol;             /* Krylov stop: ||r|| <= eta ||b|| (row-equilibrated norms),                  */
+                               /* eta = max(lin_rtol, min(1e-2, 1e-3 atol / ||b||_newton))  (inexact Newton) */
   int32_t lin_max_it;          /* Krylov iteration cap per linear solve                                     */
   int32_t lin_solver;          /* 0 = GCR with recycled directions, 1 = BiCGStab                            */
 } FsiNewtonOpts;
@@ -153,6 +154,8 @@ typedef struct FsiTimers {
   int64_t precond_applies;
   double solid_spmv_ms;  int64_t solid_spmv_calls;   /* sampled launches of the solid-block SpMV (Chebyshev sweeps)   */
   int64_t solid_nnz;     int64_t solid_rows;         /* size of that block                                            */
+  double db_spmv_ms;     int64_t db_spmv_calls;      /* sampled launches of the FP32 component-diagonal SpMV          */
+  int64_t db_pairs;      int64_t db_nodes;           /* node pairs / nodes of that structure                          */
 } FsiTimers;
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
 

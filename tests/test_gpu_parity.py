@@ -224,3 +224,22 @@ def test_error_behaviour(cyl, cylinder_case):
     with pytest.raises((RuntimeError, FsiError)):
         cyl.newton_solve(counter=0, first_step_num=0, atol=1e-6, rtol=1e-6, max_it=3, lmbda=1.0, recompute=20, recompute_tstep=20)
     cyl.set_state("n", np.zeros(cyl.ndof)); cyl.set_state("n-1", np.zeros(cyl.ndof))
+
+
+def test_aneurysm_runs_and_prints_sane_flow_properties(tmp_path):
+    """REF tests/test_simulations.py:80-125: the aneurysm problem (Robin wall) runs; velocity, CFL and Reynolds numbers
+    printed by post_solve are finite and non-negative (the reference pins nothing else for this problem)."""
+    import re
+    from vasp_amd import monolithic
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        monolithic.run(["-p", "aneurysm", "-dt", "0.001", "-T", "0.002", "--theta", "0.51", "--folder", str(tmp_path), "--sub-folder", "1",
+                        "--new-arguments", f"mesh_path={GOLDEN / 'aneurysm' / 'small_aneurysm.h5'}", "inlet_id=4"], out=print)
+    out = buf.getvalue()
+    for pat in (r"Velocity \(mean, min, max\): (.*), (.*), (.*)", r"CFL \(mean, min, max\): (.*), (.*), (.*)",
+                r"Reynolds Numbers \(mean, min, max\): (.*), (.*), (.*)"):
+        m = re.findall(pat, out)
+        assert len(m) == 3
+        vals = np.array([[float(x) for x in row] for row in m])
+        assert np.all(np.isfinite(vals)) and np.all(vals >= 0)
+    assert out.count("Solved for timestep") == 3

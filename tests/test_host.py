@@ -150,3 +150,15 @@ def test_cylinder_hooks(cylinder_case):
     g[desc["bc_dofs"]] = bc_values()
     v = ns["mesh"].split(g)[1]
     assert np.abs(v).max() == pytest.approx(0.375, rel=0.05)               # parabola peak at the inlet centre
+
+
+def test_aneurysm_problem_with_robin_condition(tmp_path):
+    # REF src/vasp/simulations/aneurysm.py:29-87 and tests/test_simulations.py:80-90 (inlet_id=4 for the small fixture)
+    from conftest import prepare_case
+    ns, desc, bc_values, pressure, hook = prepare_case("aneurysm", GOLDEN / "aneurysm" / "small_aneurysm.h5", tmp_path,
+                                                       extra=("inlet_id=4",))
+    assert ns["robin_bc"] and ns["atol"] == 1e-10 and ns["rtol"] == 1e-9
+    assert len(desc["robin_facets"]) == 698 and np.all(desc["robin_k"] == 1e5) and np.all(desc["robin_c"] == 10.0)
+    assert len(desc["pressure_facets"]) == 698 and ns["probe_points"].shape == (14, 3)
+    lo, hi = ns["mesh"].coords.min(axis=0), ns["mesh"].coords.max(axis=0)
+    assert np.all(ns["probe_points"] >= lo - 1e-3) and np.all(ns["probe_points"] <= hi + 1e-3)   # mm -> m [REF :157-158]

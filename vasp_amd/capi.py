@@ -57,7 +57,8 @@ class FsiTimers(C.Structure):
                 ("krylov_ms", C.c_double), ("krylov_solves", C.c_int64), ("krylov_iters", C.c_int64),
                 ("inner_vv_iters", C.c_int64), ("inner_schur_iters", C.c_int64), ("inner_dd_iters", C.c_int64),
                 ("precond_applies", C.c_int64), ("solid_spmv_ms", C.c_double), ("solid_spmv_calls", C.c_int64),
-                ("solid_nnz", C.c_int64), ("solid_rows", C.c_int64)]
+                ("solid_nnz", C.c_int64), ("solid_rows", C.c_int64), ("db_spmv_ms", C.c_double),
+                ("db_spmv_calls", C.c_int64), ("db_pairs", C.c_int64), ("db_nodes", C.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -209,7 +209,10 @@ void cheb_db_f32(FsiCtx* ctx, const float* db, const float* dinv, const double* 
   double rho = 1.0 / sig;
   launch_cheb_init_f32(st, n, frhs, dinv, (float)(1.0 / th), fx, fr, fd);
   for (int k = 0; k < its; ++k) {
+    const bool timed = k < 4 && ctx->db_ev0[0] && ctx->db_samples_pending < 8;
+    if (timed) (void)hipEventRecord(ctx->db_ev0[ctx->db_samples_pending], st);
     launch_spmv_db_f32(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, db, fd, ft);
+    if (timed) { (void)hipEventRecord(ctx->db_ev1[ctx->db_samples_pending], st); ctx->db_samples_pending += 1; }
     const double rn = 1.0 / (2.0 * sig - rho);
     launch_cheb_step_f32(st, n, ft, dinv, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
     rho = rn;
@@ -314,6 +317,14 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   }
   launch_merge(st, N2, V, dd, dv, dp, z);
   ctx->inner_calls += 1;
+  if (ctx->db_samples_pending > 0) {      // sampled launch durations of the FP32 component-diagonal SpMV
+    (void)hipEventSynchronize(ctx->db_ev1[ctx->db_samples_pending - 1]);
+    for (int k = 0; k < ctx->db_samples_pending; ++k) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ctx->db_ev0[k], ctx->db_ev1[k]) == hipSuccess) { ctx->t_db.ms += ms; ctx->t_db.calls += 1; }
+    }
+    ctx->db_samples_pending = 0;
+  }
   if (ctx->ss_samples_pending > 0) {      // sampled launch durations of the solid-block SpMV (first 8 of every apply)
     (void)hipEventSynchronize(ctx->ss_ev1[ctx->ss_samples_pending - 1]);
     for (int k = 0; k < ctx->ss_samples_pending; ++k) {
@@ -599,6 +610,7 @@ int fsi_destroy(FsiCtx* ctx) {
   for (auto* b : {&ctx->node_solid, &ctx->vrank, &ctx->cols3, &ctx->cols_vp, &ctx->cols_pv, &ctx->cols_pp}) b->release();
   for (auto* b : {&ctx->rowptr3, &ctx->diagpos3, &ctx->rowptr_vp, &ctx->rowptr_pv, &ctx->rowptr_pp, &ctx->diagpos_pp}) b->release();
   for (int k = 0; k < 8; ++k) { if (ctx->ss_ev0[k]) (void)hipEventDestroy(ctx->ss_ev0[k]); if (ctx->ss_ev1[k]) (void)hipEventDestroy(ctx->ss_ev1[k]); }
+  for (int k = 0; k < 8; ++k) { if (ctx->db_ev0[k]) (void)hipEventDestroy(ctx->db_ev0[k]); if (ctx->db_ev1[k]) (void)hipEventDestroy(ctx->db_ev1[k]); }
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -933,6 +945,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
       FSICHK(upload(ctx, ctx->ss_src, ss_src));
       HIPCHK(ctx->ss_vals.alloc(ss_cols.size()));
       for (int k = 0; k < 8; ++k) { HIPCHK(hipEventCreate(&ctx->ss_ev0[k])); HIPCHK(hipEventCreate(&ctx->ss_ev1[k])); }
+      for (int k = 0; k < 8; ++k) { HIPCHK(hipEventCreate(&ctx->db_ev0[k])); HIPCHK(hipEventCreate(&ctx->db_ev1[k])); }
       FSICHK(upload(ctx, ctx->mask_s, ms));
       FSICHK(upload(ctx, ctx->mask_f, mf));
       if (const char* e = getenv("FSI_CHEB_S")) ctx->cheb_its_s = atoi(e);
@@ -1241,7 +1254,11 @@ int fsi_newton_solve(FsiCtx* ctx, const FsiNewtonOpts* o, FsiNewtonIter* iters, 
     last_residual = residual;
     int32_t lit = 0;
     double lrr = 0.0;
-    FSICHK(fsi_solve(ctx, o->lin_rtol, o->lin_max_it, o->lin_solver, &lit, &lrr));
+    // inexact Newton: the update only has to push the residual three orders below the Newton tolerance, never tighter
+    // than lin_rtol; without this the last iteration of every step solves a 1e-10-sized system to 1e-20
+    double eta = o->lin_rtol;
+    if (bnorm > 0.0 && o->atol > 0.0) eta = std::max(eta, std::min(1e-2, 1e-3 * o->atol / bnorm));
+    FSICHK(fsi_solve(ctx, eta, o->lin_max_it, o->lin_solver, &lit, &lrr));
     launch_axpy(ctx->stream, ctx->U.p, o->lmbda, ctx->du.p, ctx->ndof);
     launch_bc_set(ctx->stream, ctx->U.p, ctx->bc_dofs.p, ctx->bc_vals.p, ctx->nbc);
     residual = bnorm;
@@ -1348,9 +1365,10 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
                    ctx->t_spmv.ms, ctx->t_spmv.calls, ctx->t_prec.ms,  ctx->t_prec.calls,  ctx->t_ortho.ms,
                    ctx->t_ortho.calls, ctx->t_kry.ms, ctx->t_kry.calls, ctx->kry_iters,
                    ctx->inner_its[0], ctx->inner_its[1], ctx->inner_its[2], ctx->inner_calls,
-                   ctx->t_ss.ms, ctx->t_ss.calls, ctx->solid_fp32 ? 9 * ctx->sb_nblocks : (int64_t)ctx->ss_vals.n, 3 * ctx->nS};
+                   ctx->t_ss.ms, ctx->t_ss.calls, ctx->solid_fp32 ? 9 * ctx->sb_nblocks : (int64_t)ctx->ss_vals.n, 3 * ctx->nS,
+                   ctx->t_db.ms, ctx->t_db.calls, (int64_t)ctx->dd_db.n / 3, ctx->N2};
   if (reset) {
-    for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_kry, &ctx->t_ss}) {
+    for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_kry, &ctx->t_ss, &ctx->t_db}) {
       t->ms = 0.0;
       t->calls = 0;
     }

@@ -166,6 +166,9 @@ struct FsiCtx {
   fsi::PhaseTimer t_res, t_jac, t_fac, t_spmv, t_prec, t_ortho, t_kry, t_ss;
   hipEvent_t ss_ev0[8] = {}, ss_ev1[8] = {};
   int ss_samples_pending = 0;
+  fsi::PhaseTimer t_db;
+  hipEvent_t db_ev0[8] = {}, db_ev1[8] = {};
+  int db_samples_pending = 0;
   int64_t kry_iters = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
