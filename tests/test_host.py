@@ -114,6 +114,7 @@ def test_time_loop_and_log_grammar_with_a_stub_backend(tmp_path):
             return [(1e-3, 1e-7, True)]
         def shift(self): calls.append("shift")
         def get_state(self, which, out): out[:] = 1e-6; return out
+        def set_state(self, which, x): calls.append(("set_state", which, float(x[0])))
 
     lines = []
     buf = io.StringIO()
@@ -136,6 +137,21 @@ def test_time_loop_and_log_grammar_with_a_stub_backend(tmp_path):
     g = read_h5(tmp_path / "1" / "Mesh" / "mesh.h5")
     vals = np.asarray(g["domains"]["values"].data)
     assert (vals == 1001).sum() == 77 and (tmp_path / "1" / "Checkpoint").is_dir() and (tmp_path / "1" / "Visualization").is_dir()
+    # save_step = 1, save_deg = 2: three frames per field on the refined mesh (V + E = 9554 nodes); checkpoint at counter 0
+    viz = read_h5(tmp_path / "1" / "Visualization" / "velocity.h5")
+    assert sorted(viz["VisualisationVector"]) == ["0", "1", "2"] and viz["VisualisationVector"]["2"].data.shape == (9554, 3)
+    import json
+    meta = json.loads((tmp_path / "1" / "Checkpoint" / "default_variables.json").read_text())
+    assert meta["counter"] == 0 and meta["t"] == 0.01 and meta["fsi_region"] == [0.008, 0, 0, 0.008]
+    # restart from that checkpoint: state handed to the backend, time continues from the stored t
+    calls.clear()
+    lines2 = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        monolithic.run(["-p", "offset_stenosis", "-dt", "0.01", "-T", "0.03", "--theta", "0.51", "--folder", str(tmp_path),
+                        "--sub-folder", "2", "--restart-folder", str(tmp_path / "1"), "--new-arguments",
+                        f"mesh_path={GOLDEN / 'offset_stenosis' / 'offset_stenosis.h5'}"], backend_factory=Stub, out=lines2.append)
+    assert calls[0] == ("set_state", "n", 1e-6) and calls[1][:2] == ("set_state", "n-1")
+    assert [float(TIME_STEP.match(l).group(2)) for l in lines2 if l.startswith("Solved")] == [0.02, 0.03, 0.04]
 
 
 def test_cylinder_hooks(cylinder_case):

@@ -26,6 +26,7 @@ from . import problems as _defaults
 from .fem import (DirichletBC, FormTerms, MixedFunction, MixedSpace, RobinTerm, SurfacePressureTerm,
                   resolve_bcs)
 from .mesh import FsiMesh
+from .output import VisualizationWriter, checkpoint, read_checkpoint
 
 MATERIAL_IDS = {"StVenantKirchoff": 0, "MooneyRivlin": 1}
 
@@ -235,6 +236,16 @@ def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_ba
     state = ns["_state"]
     backend = backend_factory(desc)
     ns["backend"] = backend
+    mesh = ns["mesh"]
+    if ns.get("restart_folder"):                  # --restart-folder: resume from Checkpoint/ of an earlier run
+        ck = Path(str(ns["restart_folder"])) / "Checkpoint"
+        meta = json.loads((ck / "default_variables.json").read_text())
+        state["n"][:] = read_checkpoint(ck, mesh)
+        state["n-1"][:] = state["n"]
+        backend.set_state("n", state["n"])
+        backend.set_state("n-1", state["n-1"])
+        ns["t"], ns["counter"] = float(meta["t"]), int(meta["counter"])
+    viz = VisualizationWriter(ns["visualization_folder"], mesh, ns["save_deg"]) if ns.get("save_step") else None
     first_step_num = ns["counter"]
     newton_keys = ("atol", "rtol", "max_it", "lmbda", "recompute", "recompute_tstep")
 
@@ -257,7 +268,12 @@ def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_ba
         backend.get_state("n", state["n"])
         state["n-1"][:] = state["n"]
 
-        hook("post_solve")(**ns)
+        upd = hook("post_solve")(**ns)
+        ns.update(upd or {})
+        if ns.get("checkpoint_step") and ns["counter"] % int(ns["checkpoint_step"]) == 0:
+            checkpoint(ns["checkpoint_folder"], mesh, state["n"], ns["default_variables"], t, ns["counter"])
+        if viz is not None and ns["counter"] % int(ns["save_step"]) == 0:
+            viz.write(state["n"], t)
         ns["counter"] += 1
         out("Solved for timestep %d, t = %.4f in %.1f s" % (ns["counter"], t, _time.perf_counter() - t0))
     ns["time_loop_seconds"] = _time.perf_counter() - t_loop

@@ -1,0 +1,196 @@
+"""Result files of a run: `Visualization/{displacement,velocity,pressure}.{h5,xdmf}` and
+`Checkpoint/checkpoint_{d,v,p}1.{h5,xdmf}` + `default_variables.json`, libhdf5-free.
+
+Counterpart of turtleFSI's `save_files_visualization` / `checkpoint` in the on-disk
+layout VaSP's post-processing reads:
+
+* `<name>.h5:/Mesh/0/mesh/{geometry f64[N,3], topology i64[M,4]}` and `/VisualisationVector/<k>` f64[N,3] (vectors) or
+  [N,1] (pressure); XDMF text with `<Time Value="..."/>` and `"HDF"><name>.h5:/VisualisationVector/<k></DataItem>`,
+  exactly what `output_file_lists` parses [REF src/vasp/postprocessing/postprocessing_common.py:63-121] and what the
+  reference's own XDMF template reproduces [REF src/vasp/postprocessing/postprocessing_h5py/postprocessing_h5py_common.py:543-579].
+* save_deg = 1: nodal values on the mesh itself.  save_deg = 2: the P2 field as a P1 field on the once-refined mesh
+  (N = V + E, M = 8 C; original vertices first, then one vertex per edge - cross-check
+  [REF tests/test_postprocess_mesh.py:33-42]: 2 500 = 352 + 2 148 nodes, 13 176 = 8 * 1 647 cells on the cylinder).
+* checkpoints: DOLFIN `XDMFFile.write_checkpoint` layout `/<name>/<name>_0/{vector, cell_dofs, x_cell_dofs, cells,
+  mesh/geometry, mesh/topology}`, XDMF `ItemType="FiniteElementFunction"` [REF postprocessing_h5py_common.py:639-670;
+  detection string REF postprocessing_common.py:87]; the dof numbering in these files is this package's P2/P1 node
+  numbering, carried by `cell_dofs` as DOLFIN's files carry theirs.
+"""
+from __future__ import annotations
+
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+
+from .h5lite import Dataset, Group, write_h5
+from .mesh import FsiMesh
+
+FIELDS = (("displacement", 0, "Vector"), ("velocity", 1, "Vector"), ("pressure", 2, "Scalar"))
+
+
+def refine_topology(mesh: FsiMesh) -> np.ndarray:
+    """8 children per tetrahedron from its 10 P2 nodes (red refinement; interior octahedron cut along edge nodes 4-9
+    local = (e0, e5): the two mid-edge nodes of the opposite edges (v2,v3) and (v0,v1))."""
+    tn = mesh.tet_nodes
+    v0, v1, v2, v3 = tn[:, 0], tn[:, 1], tn[:, 2], tn[:, 3]
+    e23, e13, e12, e03, e02, e01 = (tn[:, 4 + i] for i in range(6))
+    kids = [
+        (v0, e01, e02, e03), (v1, e01, e12, e13), (v2, e02, e12, e23), (v3, e03, e13, e23),
+        (e01, e23, e02, e03), (e01, e23, e03, e13), (e01, e23, e13, e12), (e01, e23, e12, e02),
+    ]
+    return np.stack([np.stack(k, axis=1) for k in kids], axis=1).reshape(-1, 4)
+
+
+class VisualizationWriter:
+    def __init__(self, folder, mesh: FsiMesh, save_deg: int):
+        self.folder = Path(folder)
+        self.folder.mkdir(parents=True, exist_ok=True)
+        self.mesh, self.save_deg = mesh, int(save_deg)
+        if self.save_deg >= 2:
+            self.geometry = mesh.node_coords
+            self.topology = refine_topology(mesh).astype(np.int64)
+        else:
+            self.geometry = mesh.coords
+            self.topology = mesh.tets.astype(np.int64)
+        self.frames = {name: [] for name, _, _ in FIELDS}
+        self.times = []
+
+    def write(self, state: np.ndarray, t: float) -> None:
+        d, v, p = self.mesh.split(state)
+        V, N = self.mesh.num_vertices, len(self.geometry)
+        if self.save_deg >= 2:      # P1 pressure -> refined-mesh vertices: edge vertices get the edge mean
+            e = self.mesh.edges
+            pn = np.concatenate([p, 0.5 * (p[e[:, 0]] + p[e[:, 1]])])
+            vals = (d, v, pn[:, None])
+        else:
+            vals = (d[:V], v[:V], p[:, None])
+        self.times.append(float(t))
+        for (name, _, att), val in zip(FIELDS, vals):
+            self.frames[name].append(np.ascontiguousarray(val, dtype=np.float64).reshape(N, -1).copy())
+            self._flush(name, att)
+
+    def _flush(self, name: str, att: str) -> None:
+        root, meshg, zero, inner = Group(), Group(), Group(), Group()
+        inner["geometry"] = Dataset(np.ascontiguousarray(self.geometry))
+        inner["topology"] = Dataset(self.topology, {"celltype": "tetrahedron"})
+        zero["mesh"] = inner
+        meshg["0"] = zero
+        vec = Group()
+        for k, fr in enumerate(self.frames[name]):
+            vec[str(k)] = Dataset(fr)
+        root["Mesh"], root["VisualisationVector"] = meshg, vec
+        tmp = self.folder / f"tmp_{name}.h5"
+        write_h5(tmp, root)
+        os.replace(tmp, self.folder / f"{name}.h5")
+        N, M = len(self.geometry), len(self.topology)
+        ndim = "3" if att == "Vector" else "1"
+        lines = f'''<?xml version="1.0"?>
+<!DOCTYPE Xdmf SYSTEM "Xdmf.dtd" []>
+<Xdmf Version="3.0" xmlns:xi="http://www.w3.org/2001/XInclude">
+  <Domain>
+    <Grid Name="TimeSeries_{name}" GridType="Collection" CollectionType="Temporal">
+      <Grid Name="mesh" GridType="Uniform">
+        <Topology NumberOfElements="{M}" TopologyType="Tetrahedron" NodesPerElement="4">
+          <DataItem Dimensions="{M} 4" NumberType="UInt" Format="HDF">{name}.h5:/Mesh/0/mesh/topology</DataItem>
+        </Topology>
+        <Geometry GeometryType="XYZ">
+          <DataItem Dimensions="{N} 3" Format="HDF">{name}.h5:/Mesh/0/mesh/geometry</DataItem>
+        </Geometry>
+'''
+        for k, t in enumerate(self.times):
+            if k > 0:
+                lines += f'''      <Grid>
+        <xi:include xpointer="xpointer(//Grid[@Name=&quot;TimeSeries_{name}&quot;]/Grid[1]/*[self::Topology or self::Geometry])" />
+'''
+            lines += f'''        <Time Value="{t!r}" />
+        <Attribute Name="{name}" AttributeType="{att}" Center="Node">
+          <DataItem Dimensions="{N} {ndim}" Format="HDF">{name}.h5:/VisualisationVector/{k}</DataItem>
+        </Attribute>
+      </Grid>
+'''
+        lines += "    </Grid>\n  </Domain>\n</Xdmf>\n"
+        (self.folder / f"{name}.xdmf").write_text(lines)
+
+
+def _json_default(o):
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    if isinstance(o, (np.floating,)):
+        return float(o)
+    if isinstance(o, np.ndarray):
+        return o.tolist()
+    return str(o)
+
+
+def checkpoint(folder, mesh: FsiMesh, state: np.ndarray, default_variables: dict, t: float, counter: int) -> None:
+    """JSON dump of the parameters (+ t, counter) and the three fields, written to tmp_ files then renamed."""
+    folder = Path(folder)
+    folder.mkdir(parents=True, exist_ok=True)
+    dv = dict(default_variables)
+    dv.update(t=float(t), counter=int(counter))
+    tmp = folder / "tmp_default_variables.json"
+    tmp.write_text(json.dumps(dv, default=_json_default))
+    os.replace(tmp, folder / "default_variables.json")
+    d, v, p = mesh.split(state)
+    C = mesh.num_cells
+    for name, vals, nodes, ncomp, fam_deg in (("d1", d, mesh.tet_nodes, 3, 2), ("v1", v, mesh.tet_nodes, 3, 2),
+                                              ("p1", p[:, None], mesh.tets, 1, 1)):
+        nloc = nodes.shape[1]
+        cell_dofs = (ncomp * nodes[:, :, None] + np.arange(ncomp)[None, None, :]).transpose(0, 2, 1).reshape(C, -1)
+        g0 = Group()
+        g0["vector"] = Dataset(np.ascontiguousarray(vals, dtype=np.float64).reshape(-1, 1))
+        g0["cell_dofs"] = Dataset(cell_dofs.reshape(-1).astype(np.int64))
+        g0["x_cell_dofs"] = Dataset((np.arange(C + 1) * nloc * ncomp).astype(np.int64))
+        g0["cells"] = Dataset(np.arange(C, dtype=np.int64))
+        mg = Group()
+        mg["geometry"] = Dataset(np.ascontiguousarray(mesh.coords))
+        mg["topology"] = Dataset(mesh.tets.astype(np.int64), {"celltype": "tetrahedron"})
+        g0["mesh"] = mg
+        outer, root = Group(), Group()
+        outer[f"{name}_0"] = g0
+        root[name] = outer
+        fname = f"checkpoint_{name}"
+        write_h5(folder / f"tmp_{fname}.h5", root)
+        os.replace(folder / f"tmp_{fname}.h5", folder / f"{fname}.h5")
+        att = "Vector" if ncomp == 3 else "Scalar"
+        ndofs = C * nloc * ncomp
+        xdmf = f'''<?xml version="1.0"?>
+<Xdmf Version="3.0">
+  <Domain>
+    <Grid GridType="Collection" CollectionType="Temporal" Name="{name}">
+      <Grid Name="{name}_0" GridType="Uniform">
+        <Topology NumberOfElements="{C}" TopologyType="Tetrahedron" NodesPerElement="4">
+          <DataItem Dimensions="{C} 4" NumberType="UInt" Format="HDF">{fname}.h5:{name}/{name}_0/mesh/topology</DataItem>
+        </Topology>
+        <Geometry GeometryType="XYZ">
+          <DataItem Dimensions="{mesh.num_vertices} 3" Format="HDF">{fname}.h5:{name}/{name}_0/mesh/geometry</DataItem>
+        </Geometry>
+         <Time Value="{float(t)!r}" />
+        <Attribute ItemType="FiniteElementFunction" ElementFamily="CG" ElementDegree="{fam_deg}" ElementCell="tetrahedron" Name="{name}" Center="Other" AttributeType="{att}">
+          <DataItem Dimensions="{ndofs} 1" NumberType="UInt" Format="HDF">{fname}.h5:{name}/{name}_0/cell_dofs</DataItem>
+          <DataItem Dimensions="{len(vals) * ncomp} 1" NumberType="Float" Format="HDF">{fname}.h5:{name}/{name}_0/vector</DataItem>
+          <DataItem Dimensions="{C + 1} 1" NumberType="UInt" Format="HDF">{fname}.h5:{name}/{name}_0/x_cell_dofs</DataItem>
+          <DataItem Dimensions="{C} 1" NumberType="UInt" Format="HDF">{fname}.h5:{name}/{name}_0/cells</DataItem>
+        </Attribute>
+      </Grid>
+    </Grid>
+  </Domain>
+</Xdmf>
+'''
+        (folder / f"{fname}.xdmf").write_text(xdmf)
+
+
+def read_checkpoint(folder, mesh: FsiMesh) -> np.ndarray:
+    """State vector from `Checkpoint/checkpoint_{d,v,p}1.h5` (restart)."""
+    from .h5lite import read_h5
+    folder = Path(folder)
+    parts = []
+    for name in ("d1", "v1", "p1"):
+        g = read_h5(folder / f"checkpoint_{name}.h5")
+        parts.append(np.asarray(g[name][f"{name}_0"]["vector"].data, dtype=np.float64).ravel())
+    x = np.concatenate(parts)
+    if len(x) != mesh.num_dofs:
+        raise ValueError("checkpoint does not match the mesh")
+    return x
