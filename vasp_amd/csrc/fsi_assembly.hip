@@ -173,6 +173,31 @@ __global__ __launch_bounds__(64) void k_residual(ElemArrays ea, ElemParams ep, c
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// L2(Omega) norm of a mixed function: out += int |d|^2 + |v|^2 + p^2 dx over the cells  (`norm(dvp_res, 'l2')` of the
+// reference's newtonsolver is DOLFIN's *function* norm; see oracle/fsi_oracle.py:function_norm)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_l2norm(ElemArrays ea, const double* __restrict__ X, double* __restrict__ out) {
+  const int64_t c = blockIdx.x;
+  const int lane = threadIdx.x;
+  __shared__ double sU[NLOC], sJ[10];
+  sU[lane] = X[ea.cell_dofs[c * NLOC + lane]];
+  if (lane < 10) sJ[lane] = ea.geom[c * 10 + lane];
+  __syncthreads();
+  double s = 0.0;
+  if (lane < NQ) {
+    Kin<double> k;
+    interpolate(sU, sJ, lane, k);
+    s = sJ[9] * c_qw[lane] * (k.d[0] * k.d[0] + k.d[1] * k.d[1] + k.d[2] * k.d[2] + k.v[0] * k.v[0] + k.v[1] * k.v[1] +
+                              k.v[2] * k.v[2] + k.p * k.p);
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) unsafeAtomicAdd(out, s);
+}
+void launch_l2norm(hipStream_t st, int64_t C, const ElemArrays& ea, const double* X, double* out) {
+  hipLaunchKernelGGL(k_l2norm, dim3((unsigned)C), dim3(64), 0, st, ea, X, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Jacobian: vals += d(element vector)/d(local dofs), PART selects F_linear (A_pre) or F_nonlinear
 // ---------------------------------------------------------------------------------------------------------
 template <int PART>

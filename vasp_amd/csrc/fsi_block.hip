@@ -443,6 +443,74 @@ __global__ void k_dinv_f32(int64_t n, const double* __restrict__ mask, const int
                            const double* __restrict__ A, float* __restrict__ dinv) {
   GS(i, n) dinv[i] = (float)((mask ? mask[i] : 1.0) / A[diagpos[i]]);
 }
+// A_dd is (scalar node-pair matrix) x I_3 up to the row scaling and the Dirichlet rows; its Jacobi-scaled form
+// D^-1 A_dd therefore needs ONE number per node pair, chat = c_rs / c_rr, plus a flag per Dirichlet row.
+__global__ void k_extract_chat(int64_t N2, const int64_t* __restrict__ nadj_ptr, const int32_t* __restrict__ nadj,
+                               const double* __restrict__ db, float* __restrict__ chat, uint8_t* __restrict__ rowflag,
+                               int32_t* __restrict__ flags) {
+  GS(r, N2) {
+    const int64_t a = nadj_ptr[r], b = nadj_ptr[r + 1];
+    int64_t ed = -1;
+    for (int64_t e = a; e < b; ++e) if (nadj[e] == r) ed = e;
+    // a row is "identity" (Dirichlet / ident_zeros) when its only entry is the diagonal
+    bool ident[3];
+    for (int i = 0; i < 3; ++i) {
+      bool off = false;
+      for (int64_t e = a; e < b; ++e) off |= (e != ed && db[3 * e + i] != 0.0);
+      ident[i] = !off;
+      rowflag[3 * r + i] = ident[i] ? 1 : 0;
+    }
+    int ref = -1;
+    for (int i = 0; i < 3; ++i) if (!ident[i] && ref < 0) ref = i;
+    for (int64_t e = a; e < b; ++e) {
+      if (ref < 0) { chat[e] = (e == ed) ? 1.f : 0.f; continue; }
+      const double c = db[3 * e + ref] / db[3 * ed + ref];
+      chat[e] = (float)c;
+      for (int i = 0; i < 3; ++i)       // the other free components must carry the same ratios
+        if (!ident[i] && fabs(db[3 * e + i] / db[3 * ed + i] - c) > 1e-9 * (fabs(c) + 1e-30) + 1e-12) atomicOr(&flags[1], 16);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_spmv_sc_f32(int64_t N2, const int64_t* __restrict__ nadj_ptr,
+                                                     const int32_t* __restrict__ nadj, const float* __restrict__ chat,
+                                                     const uint8_t* __restrict__ rowflag, const float* __restrict__ x,
+                                                     float* __restrict__ y) {
+  const int sub = threadIdx.x & 15;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t r = grp; r < N2; r += ngrp) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int64_t e = nadj_ptr[r] + sub; e < nadj_ptr[r + 1]; e += 16) {
+      const float* xs = x + 3 * (int64_t)nadj[e];
+      const float c = chat[e];
+      s0 += c * xs[0]; s1 += c * xs[1]; s2 += c * xs[2];
+    }
+    for (int off = 8; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
+    }
+    if (sub == 0) {
+      y[3 * r] = rowflag[3 * r] ? x[3 * r] : s0;
+      y[3 * r + 1] = rowflag[3 * r + 1] ? x[3 * r + 1] : s1;
+      y[3 * r + 2] = rowflag[3 * r + 2] ? x[3 * r + 2] : s2;
+    }
+  }
+}
+__global__ void k_scale_to_f32(int64_t n, const double* __restrict__ a, const float* __restrict__ s, float* __restrict__ b) {
+  GS(i, n) b[i] = (float)a[i] * s[i];
+}
+void launch_extract_chat(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
+                         float* chat, uint8_t* rowflag, int32_t* flags) {
+  hipLaunchKernelGGL(k_extract_chat, dim3(gridn(N2)), dim3(256), 0, st, N2, nadj_ptr, nadj, db, chat, rowflag, flags);
+}
+void launch_spmv_sc_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const float* chat,
+                        const uint8_t* rowflag, const float* x, float* y) {
+  int64_t blocks = (N2 + 15) / 16;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_spmv_sc_f32, dim3((unsigned)blocks), dim3(256), 0, st, N2, nadj_ptr, nadj, chat, rowflag, x, y);
+}
+void launch_scale_to_f32(hipStream_t st, int64_t n, const double* a, const float* s, float* b) {
+  hipLaunchKernelGGL(k_scale_to_f32, dim3(gridn(n)), dim3(256), 0, st, n, a, s, b);
+}
 void launch_spmv_db_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const float* db,
                         const float* x, float* y) {
   int64_t blocks = (N2 + 15) / 16;

@@ -301,7 +301,23 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
     launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Adv.p, dv, rd, td);
   }
   if (ctx->cheb_its_d > 0) {
-    if (ctx->dd_is_db && ctx->sweeps_fp32)
+    if (ctx->dd_is_scalar && ctx->sweeps_fp32) {
+      // Jacobi-scaled system  (D^-1 A_dd) dd = D^-1 td  with the one-number-per-node-pair operator
+      const int64_t n = n3;
+      float* F = reinterpret_cast<float*>(IW);
+      float *fr = F, *fd = F + n, *ft = F + 2 * n, *fx = F + 3 * n, *frhs = F + 4 * n;
+      launch_scale_to_f32(st, n, td, ctx->dd_dinv32.p, frhs);
+      const double lmax = ctx->lmax_d, lmin = lmax / ctx->cheb_kappa_d, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
+      double rho = 1.0 / sig;
+      launch_cheb_init_f32(st, n, frhs, ctx->ones32.p, (float)(1.0 / th), fx, fr, fd);
+      for (int k = 0; k < ctx->cheb_its_d; ++k) {
+        launch_spmv_sc_f32(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_chat.p, ctx->dd_rowflag.p, fd, ft);
+        const double rn = 1.0 / (2.0 * sig - rho);
+        launch_cheb_step_f32(st, n, ft, ctx->ones32.p, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
+        rho = rn;
+      }
+      launch_from_f32(st, n, fx, dd);
+    } else if (ctx->dd_is_db && ctx->sweeps_fp32)
       cheb_db_f32(ctx, ctx->dd_db32.p, ctx->dd_dinv32.p, td, dd, IW, ctx->cheb_its_d, ctx->lmax_d, ctx->cheb_kappa_d);
     else if (ctx->dd_is_db)
       cheb_solve_op(ctx, n3, [&](const double* in, double* out) { launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_db.p, in, out); },
@@ -395,7 +411,10 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
     if (!(wn > 0.0) || !std::isfinite(wn)) { ctx->err = "GCR breakdown (A M^-1 r vanished or is not finite)"; return FSI_ERR_LINEAR; }
     launch_scale(st, w, 1.0 / wn, n);
     launch_scale(st, z, 1.0 / wn, n);
-    const int slot = (int)(ctx->kry_m % ctx->kry_cap);   // space full: overwrite the oldest direction
+    // space full: the directions of the first solves (they resolve the hardest modes) stay; the newest ring of 64 rotates
+    const int64_t ring = std::min<int64_t>(64, ctx->kry_cap);
+    const int slot = ctx->kry_m < ctx->kry_cap ? (int)ctx->kry_m
+                                               : (int)(ctx->kry_cap - ring + (ctx->kry_m - ctx->kry_cap) % ring);
     launch_copy(st, ctx->KP.p + (int64_t)slot * n, z, n);
     launch_copy(st, ctx->KQ.p + (int64_t)slot * n, w, n);
     ctx->kry_m += 1;
@@ -512,6 +531,10 @@ int refresh_preconditioner(FsiCtx* ctx) {
       launch_extract_db(st, ctx->N2, npairs, ctx->nadj_ptr.p, ctx->rowptr3.p, ctx->Adv.p, ctx->adv_db.p, ctx->iflags.p, 1);
       HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
       ctx->adv_is_db = !(flags[1] & 8);
+      HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
+      launch_extract_chat(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_db.p, ctx->dd_chat.p, ctx->dd_rowflag.p, ctx->iflags.p);
+      HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
+      ctx->dd_is_scalar = ctx->dd_is_db && !(flags[1] & 16) && !getenv("FSI_NO_SCALAR_DD");
       launch_to_f32(st, 3 * npairs, ctx->dd_db.p, ctx->dd_db32.p);
       launch_to_f32(st, 3 * npairs, ctx->vv_db.p, ctx->vv_db32.p);
       launch_dinv_f32(st, 3 * ctx->N2, nullptr, ctx->diagpos3.p, ctx->Mdd.vals.p, ctx->dd_dinv32.p);
@@ -606,6 +629,7 @@ int fsi_destroy(FsiCtx* ctx) {
   for (auto* b : {&ctx->snode, &ctx->ss_cols, &ctx->sb_col, &ctx->sb_row, &ctx->sb_stride}) b->release();
   ctx->sb_ptr.release(); ctx->sb_src.release(); ctx->sb_vals.release(); ctx->sb_dinv.release();
   ctx->dd_db32.release(); ctx->vv_db32.release(); ctx->dd_dinv32.release(); ctx->vvf_dinv32.release();
+  ctx->dd_chat.release(); ctx->ones32.release(); ctx->dd_rowflag.release();
   for (auto* b : {&ctx->ss_rowptr, &ctx->ss_diagpos, &ctx->ss_src}) b->release();
   for (auto* b : {&ctx->node_solid, &ctx->vrank, &ctx->cols3, &ctx->cols_vp, &ctx->cols_pv, &ctx->cols_pp}) b->release();
   for (auto* b : {&ctx->rowptr3, &ctx->diagpos3, &ctx->rowptr_vp, &ctx->rowptr_pv, &ctx->rowptr_pp, &ctx->diagpos_pp}) b->release();
@@ -996,6 +1020,12 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
     HIPCHK(ctx->dd_db32.alloc(3 * nadj_total));
     HIPCHK(ctx->vv_db32.alloc(3 * nadj_total));
     HIPCHK(ctx->dd_dinv32.alloc(3 * N2));
+    HIPCHK(ctx->dd_chat.alloc(nadj_total));
+    HIPCHK(ctx->dd_rowflag.alloc(3 * N2));
+    {
+      std::vector<float> ones(3 * N2, 1.0f);
+      FSICHK(upload(ctx, ctx->ones32, ones));
+    }
     HIPCHK(ctx->vvf_dinv32.alloc(3 * N2));
     if (const char* e = getenv("FSI_SWEEPS_FP32")) ctx->sweeps_fp32 = atoi(e);
     HIPCHK(ctx->Avp.alloc(3 * padj_total));
@@ -1262,7 +1292,11 @@ int fsi_newton_solve(FsiCtx* ctx, const FsiNewtonOpts* o, FsiNewtonIter* iters, 
     launch_axpy(ctx->stream, ctx->U.p, o->lmbda, ctx->du.p, ctx->ndof);
     launch_bc_set(ctx->stream, ctx->U.p, ctx->bc_dofs.p, ctx->bc_vals.p, ctx->nbc);
     residual = bnorm;
-    FSICHK(norm2(ctx, ctx->du.p, &rel_res));
+    // "r (rel)": L2(Omega) function norm of the update, as dolfin.norm(Function, 'l2') in the reference's newtonsolver
+    HIPCHK(hipMemsetAsync(ctx->scratch.p + 4097, 0, sizeof(double), ctx->stream));
+    launch_l2norm(ctx->stream, ctx->C, elem_arrays(ctx), ctx->du.p, ctx->scratch.p + 4097);
+    FSICHK(host_scalar(ctx, ctx->scratch.p + 4097, &rel_res));
+    rel_res = std::sqrt(rel_res);
     iters[it] = FsiNewtonIter{residual, rel_res, rec ? 1 : 0, lit, lrr};
     it += 1;
     *n_iters = it;

@@ -137,6 +137,9 @@ struct FsiCtx {
   bool dd_is_db = false, adv_is_db = false;
   fsi::DevBuf<float> dd_db32, vv_db32, dd_dinv32, vvf_dinv32;   // FP32 copies for the Chebyshev sweeps
   int sweeps_fp32 = 1;
+  fsi::DevBuf<float> dd_chat, ones32;         // scalar form of the Jacobi-scaled A_dd (one ratio per node pair)
+  fsi::DevBuf<uint8_t> dd_rowflag;
+  bool dd_is_scalar = false;
   fsi::SubMat Mdd, Mvv, Ms;                  // A_dd, Avv~, sparsified Schur complement (ILU only)
   fsi::DevBuf<double> blk;                   // work vectors of the block preconditioner
   int64_t nS = 0;                            // solid (incl. interface) nodes; compact velocity block A_SS on them

@@ -25,6 +25,7 @@ hipError_t upload_tables();
 void launch_geometry(hipStream_t st, int64_t C, const double* coords, const int32_t* tet_vertices, double* geom);
 void launch_residual(hipStream_t st, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
                      const double* U1, double* F);
+void launch_l2norm(hipStream_t st, int64_t C, const ElemArrays& ea, const double* X, double* out);
 void launch_jacobian(hipStream_t st, int part, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
                      const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals);
 
@@ -100,6 +101,11 @@ void launch_extract_db(hipStream_t st, int64_t N2, int64_t npairs, const int64_t
                        const double* vals, double* db, int32_t* flags, int check);
 void launch_spmv_db(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
                     const double* x, double* y);
+void launch_extract_chat(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
+                         float* chat, uint8_t* rowflag, int32_t* flags);
+void launch_spmv_sc_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const float* chat,
+                        const uint8_t* rowflag, const float* x, float* y);
+void launch_scale_to_f32(hipStream_t st, int64_t n, const double* a, const float* s, float* b);
 void launch_spmv_db_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const float* db,
                         const float* x, float* y);
 void launch_to_f32(hipStream_t st, int64_t n, const double* a, float* b);
