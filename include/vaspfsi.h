@@ -54,8 +54,8 @@ typedef struct FsiParams {
   int32_t num_fluid_regions;
   const double* fluid_props;   /* [nf][2]  rho_f, mu_f                                                      */
   int32_t num_solid_regions;
-  const double* solid_props;   /* [ns][3]  rho_s, mu_s, lambda_s  (StVenantKirchoff)                        */
-  const int32_t* solid_models; /* [ns]     0 = StVenantKirchoff                                             */
+  const double* solid_props;   /* [ns][6]  rho_s, mu_s, lambda_s, C10, C01, C11 (the last three: MooneyRivlin)      */
+  const int32_t* solid_models; /* [ns]     0 = StVenantKirchoff, 1 = MooneyRivlin                           */
   double delta;                /* d_t = v penalty in the solid (turtleFSI solid.py: 1e7)                    */
   double laplace_alpha;        /* mesh-lifting coefficient ("constant": 1.0)                                */
 } FsiParams;

@@ -237,8 +237,11 @@ class FsiOracle:
         Rl = self.pack(np.einsum("cq,cqaj,cqij->cai", w, G, lap), test_v(val_l, grd_l), zero_p)
         return Rl, Rn
 
-    def _solid_residual(self, cells, rho, mu, lam, loc, loc1):
-        """turtleFSI solid.py with S = lambda tr(E) I + 2 mu E (StVenantKirchoff)."""
+    def _solid_residual(self, cells, rho, mu, lam, loc, loc1, model=0, C10=0.0, C01=0.0, C11=0.0):
+        """turtleFSI solid.py with S = lambda tr(E) I + 2 mu E (StVenantKirchoff), or the compressible Mooney-Rivlin
+        energy psi = C10 (I1b-3) + C01 (I2b-3) + C11 (I1b-3)(I2b-3) + K (J ln J - J + 1), K = lambda + 2 mu/3
+        (isochoric invariants; S = 2 dpsi/dC).  The reference's exact energy lives in the un-vendored turtleFSI and no
+        reference test pins a number for it: parity unpinned for this model."""
         k, th0, th1 = self.dt, self.theta, 1.0 - self.theta
         d, v, p = self.unpack(loc)
         d1, v1, _ = self.unpack(loc1)
@@ -248,6 +251,21 @@ class FsiOracle:
 
         def piola(g):
             F = I3 + g
+            if model == 1:
+                C = np.swapaxes(F, -1, -2) @ F
+                Ci, detC = _inv3(C)
+                J = _det3(F)
+                I1 = np.einsum("cqii->cq", C)
+                I2 = 0.5 * (I1 ** 2 - np.einsum("cqij,cqji->cq", C, C))
+                Jm23 = J ** (-2.0 / 3.0)
+                I1b, I2b = Jm23 * I1, Jm23 ** 2 * I2
+                a1 = (2.0 * (C10 + C11 * (I2b - 3.0)) * Jm23)[..., None, None]
+                a2 = (2.0 * (C01 + C11 * (I1b - 3.0)) * Jm23 ** 2)[..., None, None]
+                K = lam + 2.0 * mu / 3.0
+                S = (a1 * (I3 - (I1 / 3.0)[..., None, None] * Ci)
+                     + a2 * (I1[..., None, None] * I3 - C - (2.0 / 3.0) * I2[..., None, None] * Ci)
+                     + (K * np.log(J) * J)[..., None, None] * Ci)
+                return F @ S
             E = 0.5 * (np.swapaxes(F, -1, -2) @ F - I3)
             trE = np.einsum("cqii->cq", E)
             S = lam * trE[..., None, None] * I3 + 2.0 * mu * E
@@ -268,10 +286,14 @@ class FsiOracle:
             cells = np.nonzero((self.kind == 0) & (self.region == r))[0]
             if len(cells):
                 yield cells, (lambda c, a, b, rho=rho, mu=mu: self._fluid_residual(c, rho, mu, a, b))
-        for r, (rho, mu, lam) in enumerate(D["solid_props"]):
+        models = D.get("solid_models", [0] * len(D["solid_props"]))
+        for r, props in enumerate(D["solid_props"]):
+            rho, mu, lam = props[:3]
+            extra = dict(model=int(models[r]), C10=props[3], C01=props[4], C11=props[5]) if len(props) >= 6 else {}
             cells = np.nonzero((self.kind == 1) & (self.region == r))[0]
             if len(cells):
-                yield cells, (lambda c, a, b, rho=rho, mu=mu, lam=lam: self._solid_residual(c, rho, mu, lam, a, b))
+                yield cells, (lambda c, a, b, rho=rho, mu=mu, lam=lam, extra=extra:
+                              self._solid_residual(c, rho, mu, lam, a, b, **extra))
 
     def element_residuals(self, U, U1):
         """(R_linear, R_nonlinear): per-element vectors (C,64)."""

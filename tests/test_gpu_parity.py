@@ -243,3 +243,46 @@ def test_aneurysm_runs_and_prints_sane_flow_properties(tmp_path):
         vals = np.array([[float(x) for x in row] for row in m])
         assert np.all(np.isfinite(vals)) and np.all(vals >= 0)
     assert out.count("Solved for timestep") == 3
+
+
+def test_mooney_rivlin_matches_oracle(tmp_path):
+    """predeform problem (MooneyRivlin + Robin, theta = 1): residual and Jacobian of the HIP path vs the oracle."""
+    from oracle.fsi_oracle import FsiOracle
+    from vasp_amd.capi import HipBackend
+    case = prepare_case("predeform", GOLDEN / "cylinder" / "cylinder.h5", tmp_path, dt="0.01", T="0.02", theta="1.0")
+    ns, desc = case[0], case[1]
+    mesh = ns["mesh"]
+    o = FsiOracle(desc)
+    hb = HipBackend(desc)
+    rng = np.random.default_rng(7)
+    N2, h = mesh.num_nodes, mesh.hmin()
+    U, U1 = np.zeros(o.ndof), np.zeros(o.ndof)
+    U[:3 * N2] = 0.01 * h * rng.standard_normal(3 * N2)                  # a few per cent strain
+    U1[:3 * N2] = 0.9 * U[:3 * N2]
+    U[3 * N2:6 * N2] = 0.05 * rng.standard_normal(3 * N2)
+    U[6 * N2:] = rng.standard_normal(mesh.num_vertices)
+    g, P = boundary_data(case, 0.5)
+    hb.set_state("n", U); hb.set_state("n-1", U1); hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+    hb.assemble_residual()
+    b_ref = o.rhs(U, U1, P, g)
+    assert np.abs(hb.get_state("b") - b_ref).max() <= 1e-11 * np.abs(b_ref).max()
+    o.solver_setup(np.zeros(o.ndof), np.zeros(o.ndof))
+    A_ref = o.jacobian(U, U1)
+    hb.assemble_jacobian()
+    x = rng.standard_normal(o.ndof)
+    assert np.abs(hb.spmv(x) - A_ref @ x).max() <= 1e-10 * np.abs(A_ref @ x).max()
+    hb.close()
+
+
+def test_predeform_runs(tmp_path):
+    """REF tests/test_simulations.py:60-77: the predeform problem runs a few steps; printed flow properties are sane."""
+    import re
+    from vasp_amd import monolithic
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ns = monolithic.run(["-p", "predeform", "-dt", "0.01", "-T", "0.03", "--folder", str(tmp_path), "--sub-folder", "1",
+                             "--new-arguments", f"mesh_path={GOLDEN / 'cylinder' / 'cylinder.h5'}"], out=print)
+    out = buf.getvalue()
+    vals = np.array([[float(x) for x in row] for row in re.findall(r"Velocity \(mean, min, max\): (.*), (.*), (.*)", out)])
+    assert len(vals) == 4 and np.all(np.isfinite(vals)) and np.all(vals >= 0)
+    assert out.count("Solved for timestep") == 4 and ns["theta"] == 1.0

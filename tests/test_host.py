@@ -178,3 +178,17 @@ def test_aneurysm_problem_with_robin_condition(tmp_path):
     assert len(desc["pressure_facets"]) == 698 and ns["probe_points"].shape == (14, 3)
     lo, hi = ns["mesh"].coords.min(axis=0), ns["mesh"].coords.max(axis=0)
     assert np.all(ns["probe_points"] >= lo - 1e-3) and np.all(ns["probe_points"] <= hi + 1e-3)   # mm -> m [REF :157-158]
+
+
+def test_predeform_problem_mooney_rivlin(tmp_path):
+    # REF src/vasp/simulations/predeform.py:27-89 (theta = 1, lmbda = 0.5, dict-valued MooneyRivlin solid_properties)
+    from conftest import prepare_case
+    ns, desc, bc_values, pressure, hook = prepare_case("predeform", GOLDEN / "cylinder" / "cylinder.h5", tmp_path,
+                                                       dt="0.01", T="0.02", theta="1.0")
+    assert ns["lmbda"] == 0.5 and ns["theta"] == 1.0 and ns["save_deg"] == 1
+    assert desc["solid_models"] == [1] and desc["solid_props"][0][3:] == (0.0, 0.02e6, 1.8e6)
+    assert len(desc["robin_facets"]) > 0 and np.all(desc["robin_k"] == 1e5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ns["t"] = 0.55
+        hook("pre_solve")(**ns)
+    assert pressure.P == pytest.approx(0.5 * 11332.4)                    # half-way through the pressure ramp [0.2, 0.9]

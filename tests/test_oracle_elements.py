@@ -135,3 +135,26 @@ def test_pressure_load_integrates_to_P_times_area_normal():
     ax = np.argmax(np.ptp(mesh.coords, axis=0))
     radial[:, ax] = 0
     assert (np.einsum("ij,ij->i", o.pf_nA, radial) < 0).mean() > 0.95
+
+
+def test_mooney_rivlin_reduces_to_hooke_for_small_strain():
+    """psi = C10 (I1b-3) + C01 (I2b-3) + ... + K (J ln J - J + 1): for infinitesimal strain the stress is that of an
+    isotropic solid with shear modulus 2 (C10 + C01) and bulk modulus K = lambda + 2 mu / 3 (C11 enters at higher order)."""
+    m, desc = _two_tet_desc()
+    mu, lam, C10, C01 = 344827.6, 3103448.3, 1.0e5, 0.7e5
+    desc_mr = dict(desc, solid_props=[(1000.0, mu, lam, C10, C01, 3.0e6)], solid_models=[1])
+    G = 2 * (C10 + C01)
+    K = lam + 2 * mu / 3
+    desc_svk = dict(desc, solid_props=[(1000.0, G, K - 2 * G / 3)], solid_models=[0])
+    o_mr, o_svk = FsiOracle(desc_mr), FsiOracle(desc_svk)
+    rng = np.random.default_rng(5)
+    U = np.zeros(o_mr.ndof)
+    U[:3 * m.num_nodes] = 1e-9 * rng.standard_normal(3 * m.num_nodes)      # strain ~ 1e-6
+    z = np.zeros_like(U)
+    r_mr = o_mr.element_residuals(U, z)[1][1]                               # nonlinear part of the solid cell
+    r_svk = o_svk.element_residuals(U, z)[1][1]
+    assert np.abs(r_mr - r_svk).max() < 1e-4 * np.abs(r_svk).max()
+    # and its tangent (complex step) is symmetric in the v-test / d-trial block, as a hyperelastic tangent must be
+    Jn = o_mr.element_jacobians(U, z)[1][1]
+    Kvd = Jn[30:60, 0:30]
+    assert np.abs(Kvd - Kvd.T).max() < 1e-8 * np.abs(Kvd).max()

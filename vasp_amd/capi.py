@@ -139,7 +139,8 @@ class HipBackend:
         kind = np.ascontiguousarray(desc["cell_kind"], dtype=np.int32)
         region = np.ascontiguousarray(desc["cell_region"], dtype=np.int32)
         fprops = np.ascontiguousarray(np.asarray(desc["fluid_props"], dtype=np.float64).reshape(-1, 2))
-        sprops = np.ascontiguousarray(np.asarray(desc["solid_props"], dtype=np.float64).reshape(-1, 3))
+        sp_rows = [tuple(r) + (0.0,) * (6 - len(r)) for r in desc["solid_props"]]     # rho, mu, lambda[, C10, C01, C11]
+        sprops = np.ascontiguousarray(np.asarray(sp_rows, dtype=np.float64).reshape(-1, 6))
         smodels = np.ascontiguousarray(desc.get("solid_models", [0] * len(sprops)), dtype=np.int32)
         md = FsiMeshDesc(len(coords), int(desc["num_nodes"]), len(tet_nodes), _ptr(coords), _ptr(tet_nodes),
                          _ptr(kind), _ptr(region))

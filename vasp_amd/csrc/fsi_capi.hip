@@ -670,7 +670,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
     }
   }
   for (int r = 0; r < prm->num_solid_regions; ++r)
-    if (prm->solid_models && prm->solid_models[r] != 0) { ctx->err = "fsi_create: only StVenantKirchoff (0) is implemented"; return FSI_ERR_INVALID; }
+    if (prm->solid_models && (prm->solid_models[r] < 0 || prm->solid_models[r] > 1)) { ctx->err = "fsi_create: material model must be 0 (StVenantKirchoff) or 1 (MooneyRivlin)"; return FSI_ERR_INVALID; }
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) { ctx->err = "fsi_create: no such HIP device"; return FSI_ERR_DEVICE; }
@@ -684,10 +684,12 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   ctx->scheme = Scheme{prm->dt, prm->theta, 1.0 - prm->theta, prm->delta, prm->laplace_alpha};
   ctx->nfluid = prm->num_fluid_regions;
   ctx->nsolid = prm->num_solid_regions;
-  for (int r = 0; r < MAX_REGIONS; ++r) { ctx->fluid[r] = FluidProps{1.0, 1.0}; ctx->solid[r] = SolidProps{1.0, 1.0, 1.0}; }
+  for (int r = 0; r < MAX_REGIONS; ++r) { ctx->fluid[r] = FluidProps{1.0, 1.0}; ctx->solid[r] = SolidProps{1.0, 1.0, 1.0, 0, 0.0, 0.0, 0.0}; }
   for (int r = 0; r < ctx->nfluid; ++r) ctx->fluid[r] = FluidProps{prm->fluid_props[2 * r], prm->fluid_props[2 * r + 1]};
   for (int r = 0; r < ctx->nsolid; ++r)
-    ctx->solid[r] = SolidProps{prm->solid_props[3 * r], prm->solid_props[3 * r + 1], prm->solid_props[3 * r + 2]};
+    ctx->solid[r] = SolidProps{prm->solid_props[6 * r], prm->solid_props[6 * r + 1], prm->solid_props[6 * r + 2],
+                               prm->solid_models ? prm->solid_models[r] : 0, prm->solid_props[6 * r + 3],
+                               prm->solid_props[6 * r + 4], prm->solid_props[6 * r + 5]};
   ctx->h_coords.assign(mesh->coords, mesh->coords + 3 * V);
   ctx->h_tet_nodes.assign(mesh->tet_nodes, mesh->tet_nodes + 10 * C);
   const int32_t* tn = ctx->h_tet_nodes.data();

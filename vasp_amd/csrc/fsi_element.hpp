@@ -36,6 +36,11 @@ __host__ __device__ inline Dual operator*(double a, Dual b) { return Dual(a * b.
 __host__ __device__ inline Dual operator/(Dual a, double b) { return Dual(a.v / b, a.e / b); }
 __host__ __device__ inline Dual& operator+=(Dual& a, Dual b) { a.v += b.v; a.e += b.e; return a; }
 
+__host__ __device__ inline double dlog(double a) { return log(a); }
+__host__ __device__ inline Dual dlog(Dual a) { return Dual(log(a.v), a.e / a.v); }
+__host__ __device__ inline double dpow(double a, double p) { return pow(a, p); }
+__host__ __device__ inline Dual dpow(Dual a, double p) { const double q = pow(a.v, p - 1.0); return Dual(q * a.v, p * q * a.e); }
+
 __host__ __device__ inline double value_of(double a) { return a; }
 __host__ __device__ inline double value_of(Dual a) { return a.v; }
 __host__ __device__ inline double deriv_of(double) { return 0.0; }
@@ -87,7 +92,7 @@ __host__ __device__ inline T inv_det_F(const T g[3][3], T Fi[3][3]) {
 }
 
 struct FluidProps { double rho, mu; };
-struct SolidProps { double rho, mu, lam; };
+struct SolidProps { double rho, mu, lam; int model; double C10, C01, C11; };   // model: 0 StVenantKirchoff, 1 MooneyRivlin
 struct Scheme { double k, th0, th1, delta, alpha; };
 
 // turtleFSI fluid.py (+ laplace.py "constant") on a fluid cell.  `o` is the state at n-1 (plain doubles).
@@ -161,6 +166,53 @@ __host__ __device__ inline void piola_svk(const SolidProps& sp, const T g[3][3],
     for (int j = 0; j < 3; ++j) P[i][j] = F[i][0] * S[0][j] + F[i][1] * S[1][j] + F[i][2] * S[2][j];
 }
 
+// First Piola-Kirchhoff stress of a compressible Mooney-Rivlin solid (material_model "MooneyRivlin" with C10, C01, C11
+// [REF src/vasp/simulations/avf.py:77-80, predeform.py:71-72]):
+//   psi = C10 (I1b - 3) + C01 (I2b - 3) + C11 (I1b - 3)(I2b - 3) + K (J ln J - J + 1),   K = lambda + 2 mu / 3,
+// with the isochoric invariants I1b = J^-2/3 tr C, I2b = J^-4/3 (tr(C)^2 - tr(C^2))/2;  S = 2 dpsi/dC, P = F S.
+// The reference takes S from turtleFSI by automatic differentiation of its strain energy; that source is not in the
+// tree and the reference's tests pin no number for this model: parity unpinned.
+template <class T>
+__host__ __device__ inline void piola_mr(const SolidProps& sp, const T g[3][3], T P[3][3]) {
+  T F[3][3], C[3][3], Ci[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) F[i][j] = g[i][j] + (i == j ? 1.0 : 0.0);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C[i][j] = F[0][i] * F[0][j] + F[1][i] * F[1][j] + F[2][i] * F[2][j];
+  T Cm[3][3];                                      // C - I, so that inv_det_F (which inverts I + g) applies
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Cm[i][j] = C[i][j] - (i == j ? 1.0 : 0.0);
+  const T detC = inv_det_F(Cm, Ci);
+  T Fi[3][3];
+  const T J = inv_det_F(g, Fi);
+  (void)detC;
+  const T I1 = C[0][0] + C[1][1] + C[2][2];
+  T trC2 = T(0.0);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) trC2 = trC2 + C[i][j] * C[j][i];
+  const T I2 = 0.5 * (I1 * I1 - trC2);
+  const T Jm23 = dpow(J, -2.0 / 3.0), Jm43 = Jm23 * Jm23;
+  const T I1b = Jm23 * I1, I2b = Jm43 * I2;
+  const T a1 = 2.0 * (sp.C10 + sp.C11 * (I2b - 3.0)) * Jm23;
+  const T a2 = 2.0 * (sp.C01 + sp.C11 * (I1b - 3.0)) * Jm43;
+  const double K = sp.lam + 2.0 * sp.mu / 3.0;
+  const T vol = K * dlog(J) * J;
+  T S[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const double dij = (i == j) ? 1.0 : 0.0;
+      S[i][j] = a1 * (dij - (I1 * (1.0 / 3.0)) * Ci[i][j]) + a2 * (I1 * dij - C[i][j] - (I2 * (2.0 / 3.0)) * Ci[i][j]) +
+                vol * Ci[i][j];
+    }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) P[i][j] = F[i][0] * S[0][j] + F[i][1] * S[1][j] + F[i][2] * S[2][j];
+}
+template <class T>
+__host__ __device__ inline void piola(const SolidProps& sp, const T g[3][3], T P[3][3]) {
+  if (sp.model == 1) piola_mr<T>(sp, g, P);
+  else piola_svk<T>(sp, g, P);
+}
+
 // turtleFSI solid.py on a solid cell.
 template <class T, int PART>
 __host__ __device__ inline void solid_flux(const SolidProps& sp, const Scheme& sc, const Kin<T>& s,
@@ -173,13 +225,13 @@ __host__ __device__ inline void solid_flux(const SolidProps& sp, const Scheme& s
       out.dval[i] = (sc.delta * rk) * (s.d[i] - o.d[i]) - (sc.delta * sp.rho) * (sc.th0 * s.v[i] + sc.th1 * o.v[i]);
     }
     double P1[3][3];
-    piola_svk<double>(sp, o.gd, P1);
+    piola<double>(sp, o.gd, P1);
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) out.vgrd[i][j] = T(sc.th1 * P1[i][j]);
   }
   if (PART & PART_NONLINEAR) {
     T P[3][3];
-    piola_svk<T>(sp, s.gd, P);
+    piola<T>(sp, s.gd, P);
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) out.vgrd[i][j] = out.vgrd[i][j] + sc.th0 * P[i][j];
   }

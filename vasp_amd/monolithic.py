@@ -132,7 +132,8 @@ def build_description(mesh: FsiMesh, v: dict, bcs, F_solid_linear) -> dict:
         model = spp.get("material_model", "StVenantKirchoff")
         if model not in MATERIAL_IDS:
             raise NotImplementedError(f"material_model {model!r}")
-        solid_rows.append((float(spp["rho_s"]), float(spp.get("mu_s", 0.0)), float(spp.get("lambda_s", 0.0))))
+        solid_rows.append((float(spp["rho_s"]), float(spp.get("mu_s", 0.0)), float(spp.get("lambda_s", 0.0)),
+                           float(spp.get("C10", 0.0)), float(spp.get("C01", 0.0)), float(spp.get("C11", 0.0))))
     desc = dict(
         coords=mesh.coords, tets=mesh.tets, tet_nodes=mesh.tet_nodes, num_nodes=mesh.num_nodes,
         cell_kind=kind, cell_region=region,
