@@ -192,3 +192,43 @@ def test_predeform_problem_mooney_rivlin(tmp_path):
         ns["t"] = 0.55
         hook("pre_solve")(**ns)
     assert pressure.P == pytest.approx(0.5 * 11332.4)                    # half-way through the pressure ramp [0.2, 0.9]
+
+
+def test_avf_problem_two_solid_regions(tmp_path):
+    """REF src/vasp/simulations/avf.py: two MooneyRivlin regions, list-valued ids, tabulated inlets and pressure.
+    The reference tree holds neither the AVF mesh nor avf.csv, so the case is a synthetic tube whose downstream half
+    carries the vein ids (1002 / 1011 / 1022 / 1033)."""
+    import json
+    from conftest import prepare_case
+    from vasp_amd.mesh import FsiMesh
+    from vasp_amd.meshgen import generate
+    m = generate(6000)
+    x_c = m["coords"][m["tets"]].mean(axis=1)[:, 0]
+    x_f = m["coords"][m["facets"]].mean(axis=1)[:, 0]
+    cm, fm = m["cell_markers"].copy(), m["facet_markers"].copy()
+    mid = 0.008
+    cm[(cm == 2) & (x_c > mid)] = 1002
+    for a, b in ((11, 1011), (22, 1022), (33, 1033)):
+        fm[(fm == a) & (x_f > mid)] = b
+    mesh = FsiMesh.from_arrays(m["coords"], m["tets"], cm, m["facets"], fm)
+    mesh.write(tmp_path / "avf.h5")
+    (tmp_path / "avf_probe_point.json").write_text(json.dumps([[0.0, 0.0, 0.0], [16.0, 0.0, 0.0]]))       # mm
+    (tmp_path / "avf.csv").write_text("v_PA,v_DA,PV\n" + "\n".join(f"{0.3 + 0.01 * i},{0.1 + 0.005 * i},{9000 + 50 * i}" for i in range(20)))
+    ns, desc, bc_values, pressure, hook = prepare_case(
+        "avf", tmp_path / "avf.h5", tmp_path / "run", dt="0.0001", T="0.2", theta="0.501",
+        extra=(f"patient_data_path={tmp_path / 'avf.csv'}", "fsi_region=[0.008,0,0,0.006]"))
+    assert desc["solid_models"] == [1, 1] and desc["solid_props"][1][3:] == (0.0, 0.003e6, 0.538e6)
+    assert set(np.unique(desc["cell_region"][desc["cell_kind"] == 1])) == {0, 1}
+    b = ns["boundaries"]
+    assert (b == 1011).sum() > 0 and (b == 1022).sum() > 0 and (b == 22).sum() > 0       # relabel keeps both regions' ids
+    nf = (b == 22).sum() + (b == 1022).sum()
+    assert len(desc["pressure_facets"]) == nf                                             # both dS(fsi_id[k]) terms
+    assert len(desc["robin_facets"]) == (b == 33).sum() + (b == 1033).sum() and np.all(desc["robin_k"] == 1e5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ns["t"] = 0.1
+        hook("pre_solve")(**ns)
+    ramp = -0.5 * np.cos(np.pi / 0.15 * 0.05) + 0.5
+    assert pressure.P == pytest.approx(ns["p_out_bc_val"].interp_P[ns["p_out_bc_val"].number] * ramp)
+    g = np.zeros(mesh.num_dofs)
+    g[desc["bc_dofs"]] = bc_values()
+    assert np.abs(mesh.split(g)[1]).max() > 0                                              # inlets carry the table value

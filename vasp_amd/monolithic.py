@@ -143,10 +143,12 @@ def build_description(mesh: FsiMesh, v: dict, bcs, F_solid_linear) -> dict:
         dt=float(v["dt"]), theta=float(v["theta"]),
     )
     pterms = [tm for tm in F_solid_linear if isinstance(tm, SurfacePressureTerm)]
-    if len(pterms) > 1:
-        raise NotImplementedError("more than one surface-pressure term")
-    if pterms:
-        fids, plus = pterms[0].facets(mesh)
+    if any(tm.pressure is not pterms[0].pressure for tm in pterms):
+        raise NotImplementedError("surface-pressure terms with different pressure expressions")
+    if pterms:                                      # several dS(id) terms of one pressure (avf: both fsi ids) -> one facet list
+        parts = [tm.facets(mesh) for tm in pterms]
+        fids = np.concatenate([f for f, _ in parts])
+        plus = np.concatenate([c for _, c in parts])
         desc["pressure_facets"] = mesh.facet_nodes[fids]
         desc["pressure_facet_cell"] = plus
     rterms = [tm for tm in F_solid_linear if isinstance(tm, RobinTerm)]
@@ -219,8 +221,8 @@ def prepare(argv: Optional[List[str]] = None):
               t=float(ns["t"]), counter=int(ns["counter"]), _state=state)
     if ns.get("robin_bc"):
         ds_ids, k_s, c_s = _as_list(ns["ds_s_id"]), _as_list(ns["k_s"]), _as_list(ns["c_s"])
-        for i, marker in enumerate(ds_ids):
-            ns["F_solid_linear"] += RobinTerm(boundaries, marker, k_s[i], c_s[i])
+        for i, marker in enumerate(ds_ids):      # scalar k_s / c_s apply to every listed surface [REF avf.py:82-84]
+            ns["F_solid_linear"] += RobinTerm(boundaries, marker, k_s[i if len(k_s) > 1 else 0], c_s[i if len(c_s) > 1 else 0])
 
     upd = hook("initiate")(**ns)
     ns.update(upd or {})
