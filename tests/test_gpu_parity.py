@@ -286,3 +286,26 @@ def test_predeform_runs(tmp_path):
     vals = np.array([[float(x) for x in row] for row in re.findall(r"Velocity \(mean, min, max\): (.*), (.*), (.*)", out)])
     assert len(vals) == 4 and np.all(np.isfinite(vals)) and np.all(vals >= 0)
     assert out.count("Solved for timestep") == 4 and ns["theta"] == 1.0
+
+
+def test_offset_stenosis_five_steps_match_converged_golden(stenosis_case):
+    """The reference's known-answer case converged to 1e-11 on both sides: HIP path vs the oracle's committed run
+    (58 611 dofs, 5 steps, dt 0.01): velocity, displacement and pressure fields to 1e-6 relative."""
+    from vasp_amd.capi import HipBackend
+    ns, desc, bc_values, pressure, hook = stenosis_case
+    mesh = ns["mesh"]
+    gold = np.load(GOLDEN / "stenosis_tight.npz")["states"]
+    hb = HipBackend(desc, lin_rtol=1e-11)
+    N2 = mesh.num_nodes
+    for k in range(5):
+        g, P = boundary_data(stenosis_case, 0.01 * (k + 1))
+        hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+        hist = hb.newton_solve(counter=k, first_step_num=0, atol=1e-11, rtol=1e-14, max_it=50, lmbda=1.0, recompute=20,
+                               recompute_tstep=20)
+        assert hist[-1][0] < 1e-11
+        hb.shift()
+    U = hb.get_state("n")
+    for name, sl in (("d", slice(0, 3 * N2)), ("v", slice(3 * N2, 6 * N2)), ("p", slice(6 * N2, None))):
+        err = np.linalg.norm(U[sl] - gold[4][sl]) / np.linalg.norm(gold[4][sl])
+        assert err < 1e-6, (name, err)
+    hb.close()

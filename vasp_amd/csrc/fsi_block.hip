@@ -426,22 +426,36 @@ __global__ __launch_bounds__(256) void k_spmv_db_f32(int64_t N2, const int64_t* 
   for (int64_t r = grp; r < N2; r += ngrp) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int64_t e = nadj_ptr[r] + sub; e < nadj_ptr[r + 1]; e += 16) {
-      const float* xs = x + 3 * (int64_t)nadj[e];
+      const float4 xv = reinterpret_cast<const float4*>(x)[nadj[e]];
       const float* c = db + 3 * e;
-      s0 += c[0] * xs[0]; s1 += c[1] * xs[1]; s2 += c[2] * xs[2];
+      s0 += c[0] * xv.x; s1 += c[1] * xv.y; s2 += c[2] * xv.z;
     }
     for (int off = 8; off > 0; off >>= 1) {
       s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
     }
-    if (sub == 0) { y[3 * r] = s0; y[3 * r + 1] = s1; y[3 * r + 2] = s2; }
+    if (sub == 0) reinterpret_cast<float4*>(y)[r] = make_float4(s0, s1, s2, 0.f);
   }
 }
 __global__ void k_to_f32(int64_t n, const double* __restrict__ a, float* __restrict__ b) { GS(i, n) b[i] = (float)a[i]; }
-__global__ void k_from_f32(int64_t n, const float* __restrict__ a, double* __restrict__ b) { GS(i, n) b[i] = (double)a[i]; }
-// dinv[i] = mask[i] / A[diagpos[i]]  (mask may be null)
-__global__ void k_dinv_f32(int64_t n, const double* __restrict__ mask, const int64_t* __restrict__ diagpos,
-                           const double* __restrict__ A, float* __restrict__ dinv) {
-  GS(i, n) dinv[i] = (float)((mask ? mask[i] : 1.0) / A[diagpos[i]]);
+// node vectors: [3 per node] double  <->  [4 per node] float (pad = 0)
+__global__ void k_pad_to_f32(int64_t nn, const double* __restrict__ a, const float* __restrict__ scale4, float* __restrict__ b) {
+  GS(t, 4 * nn) {
+    const int64_t nd = t >> 2;
+    const int c = (int)(t & 3);
+    b[t] = c < 3 ? (float)a[3 * nd + c] * (scale4 ? scale4[t] : 1.f) : 0.f;
+  }
+}
+__global__ void k_unpad_from_f32(int64_t nn, const float* __restrict__ a, double* __restrict__ b) {
+  GS(t, 3 * nn) b[t] = (double)a[4 * (t / 3) + t % 3];
+}
+// dinv4[4 nd + c] = mask / A[diagpos[3 nd + c]], pad 0  (mask may be null; one4: write 1 instead of the inverse diagonal)
+__global__ void k_dinv_f32(int64_t nn, const double* __restrict__ mask, const int64_t* __restrict__ diagpos,
+                           const double* __restrict__ A, float* __restrict__ dinv4) {
+  GS(t, 4 * nn) {
+    const int64_t nd = t >> 2;
+    const int c = (int)(t & 3);
+    dinv4[t] = c < 3 ? (float)((mask ? mask[3 * nd + c] : 1.0) / A[diagpos[3 * nd + c]]) : 0.f;
+  }
 }
 // A_dd is (scalar node-pair matrix) x I_3 up to the row scaling and the Dirichlet rows; its Jacobi-scaled form
 // D^-1 A_dd therefore needs ONE number per node pair, chat = c_rs / c_rr, plus a flag per Dirichlet row.
@@ -481,23 +495,21 @@ __global__ __launch_bounds__(256) void k_spmv_sc_f32(int64_t N2, const int64_t* 
   for (int64_t r = grp; r < N2; r += ngrp) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int64_t e = nadj_ptr[r] + sub; e < nadj_ptr[r + 1]; e += 16) {
-      const float* xs = x + 3 * (int64_t)nadj[e];
+      const float4 xv = reinterpret_cast<const float4*>(x)[nadj[e]];
       const float c = chat[e];
-      s0 += c * xs[0]; s1 += c * xs[1]; s2 += c * xs[2];
+      s0 += c * xv.x; s1 += c * xv.y; s2 += c * xv.z;
     }
     for (int off = 8; off > 0; off >>= 1) {
       s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
     }
     if (sub == 0) {
-      y[3 * r] = rowflag[3 * r] ? x[3 * r] : s0;
-      y[3 * r + 1] = rowflag[3 * r + 1] ? x[3 * r + 1] : s1;
-      y[3 * r + 2] = rowflag[3 * r + 2] ? x[3 * r + 2] : s2;
+      const float4 xr = reinterpret_cast<const float4*>(x)[r];
+      reinterpret_cast<float4*>(y)[r] = make_float4(rowflag[3 * r] ? xr.x : s0, rowflag[3 * r + 1] ? xr.y : s1,
+                                                    rowflag[3 * r + 2] ? xr.z : s2, 0.f);
     }
   }
 }
-__global__ void k_scale_to_f32(int64_t n, const double* __restrict__ a, const float* __restrict__ s, float* __restrict__ b) {
-  GS(i, n) b[i] = (float)a[i] * s[i];
-}
+
 void launch_extract_chat(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
                          float* chat, uint8_t* rowflag, int32_t* flags) {
   hipLaunchKernelGGL(k_extract_chat, dim3(gridn(N2)), dim3(256), 0, st, N2, nadj_ptr, nadj, db, chat, rowflag, flags);
@@ -508,9 +520,7 @@ void launch_spmv_sc_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, con
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(k_spmv_sc_f32, dim3((unsigned)blocks), dim3(256), 0, st, N2, nadj_ptr, nadj, chat, rowflag, x, y);
 }
-void launch_scale_to_f32(hipStream_t st, int64_t n, const double* a, const float* s, float* b) {
-  hipLaunchKernelGGL(k_scale_to_f32, dim3(gridn(n)), dim3(256), 0, st, n, a, s, b);
-}
+
 void launch_spmv_db_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const float* db,
                         const float* x, float* y) {
   int64_t blocks = (N2 + 15) / 16;
@@ -518,9 +528,14 @@ void launch_spmv_db_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, con
   hipLaunchKernelGGL(k_spmv_db_f32, dim3((unsigned)blocks), dim3(256), 0, st, N2, nadj_ptr, nadj, db, x, y);
 }
 void launch_to_f32(hipStream_t st, int64_t n, const double* a, float* b) { hipLaunchKernelGGL(k_to_f32, dim3(gridn(n)), dim3(256), 0, st, n, a, b); }
-void launch_from_f32(hipStream_t st, int64_t n, const float* a, double* b) { hipLaunchKernelGGL(k_from_f32, dim3(gridn(n)), dim3(256), 0, st, n, a, b); }
-void launch_dinv_f32(hipStream_t st, int64_t n, const double* mask, const int64_t* diagpos, const double* A, float* dinv) {
-  hipLaunchKernelGGL(k_dinv_f32, dim3(gridn(n)), dim3(256), 0, st, n, mask, diagpos, A, dinv);
+void launch_pad_to_f32(hipStream_t st, int64_t nn, const double* a, const float* scale4, float* b) {
+  hipLaunchKernelGGL(k_pad_to_f32, dim3(gridn(4 * nn)), dim3(256), 0, st, nn, a, scale4, b);
+}
+void launch_unpad_from_f32(hipStream_t st, int64_t nn, const float* a, double* b) {
+  hipLaunchKernelGGL(k_unpad_from_f32, dim3(gridn(3 * nn)), dim3(256), 0, st, nn, a, b);
+}
+void launch_dinv_f32(hipStream_t st, int64_t nn, const double* mask, const int64_t* diagpos, const double* A, float* dinv4) {
+  hipLaunchKernelGGL(k_dinv_f32, dim3(gridn(4 * nn)), dim3(256), 0, st, nn, mask, diagpos, A, dinv4);
 }
 void launch_extract_db(hipStream_t st, int64_t N2, int64_t npairs, const int64_t* nadj_ptr, const int64_t* rowptr3,
                        const double* vals, double* db, int32_t* flags, int check) {
@@ -565,8 +580,8 @@ __global__ void k_sb_gather(int64_t nb, const int32_t* __restrict__ sb_row, cons
   }
 }
 __global__ void k_sb_dinv(int64_t nS, const int32_t* __restrict__ snode, const int64_t* __restrict__ diagpos3,
-                          const double* __restrict__ Avv, float* __restrict__ dinv) {
-  GS(t, 3 * nS) dinv[t] = (float)(1.0 / Avv[diagpos3[3 * (int64_t)snode[t / 3] + t % 3]]);
+                          const double* __restrict__ Avv, float* __restrict__ dinv4) {
+  GS(t, 4 * nS) dinv4[t] = (t & 3) < 3 ? (float)(1.0 / Avv[diagpos3[3 * (int64_t)snode[t >> 2] + (t & 3)]]) : 0.f;
 }
 __global__ __launch_bounds__(256) void k_spmv_sb(int64_t nS, const int64_t* __restrict__ sb_ptr,
                                                  const int32_t* __restrict__ sb_col, const float* __restrict__ vals,
@@ -577,9 +592,9 @@ __global__ __launch_bounds__(256) void k_spmv_sb(int64_t nS, const int64_t* __re
   for (int64_t i = grp; i < nS; i += ngrp) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int64_t b = sb_ptr[i] + sub; b < sb_ptr[i + 1]; b += 16) {
-      const float* xs = x + 3 * (int64_t)sb_col[b];
+      const float4 xv = reinterpret_cast<const float4*>(x)[sb_col[b]];      // vectors are float4 per node: one 16-B gather
       const float* a = vals + 9 * b;
-      const float x0 = xs[0], x1 = xs[1], x2 = xs[2];
+      const float x0 = xv.x, x1 = xv.y, x2 = xv.z;
       s0 += a[0] * x0 + a[1] * x1 + a[2] * x2;
       s1 += a[3] * x0 + a[4] * x1 + a[5] * x2;
       s2 += a[6] * x0 + a[7] * x1 + a[8] * x2;
@@ -587,7 +602,7 @@ __global__ __launch_bounds__(256) void k_spmv_sb(int64_t nS, const int64_t* __re
     for (int off = 8; off > 0; off >>= 1) {
       s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
     }
-    if (sub == 0) { y[3 * i] = s0; y[3 * i + 1] = s1; y[3 * i + 2] = s2; }
+    if (sub == 0) reinterpret_cast<float4*>(y)[i] = make_float4(s0, s1, s2, 0.f);
   }
 }
 __global__ void k_cheb_init_f32(int64_t n, const float* __restrict__ rhs, const float* __restrict__ dinv, float inv_theta,
@@ -603,18 +618,18 @@ __global__ void k_cheb_step_f32(int64_t n, const float* __restrict__ t, const fl
     d[i] = c1 * di + c2 * ri * dinv[i];
   }
 }
-__global__ void k_gather3_f32(int64_t nS, const int32_t* __restrict__ snode, const double* __restrict__ full, float* __restrict__ comp) {
-  GS(t, 3 * nS) comp[t] = (float)full[3 * (int64_t)snode[t / 3] + t % 3];
+__global__ void k_gather3_f32(int64_t nS, const int32_t* __restrict__ snode, const double* __restrict__ full, float* __restrict__ comp4) {
+  GS(t, 4 * nS) comp4[t] = (t & 3) < 3 ? (float)full[3 * (int64_t)snode[t >> 2] + (t & 3)] : 0.f;
 }
-__global__ void k_scatter3_f32(int64_t nS, const int32_t* __restrict__ snode, const float* __restrict__ comp, double* __restrict__ full) {
-  GS(t, 3 * nS) full[3 * (int64_t)snode[t / 3] + t % 3] = (double)comp[t];
+__global__ void k_scatter3_f32(int64_t nS, const int32_t* __restrict__ snode, const float* __restrict__ comp4, double* __restrict__ full) {
+  GS(t, 3 * nS) full[3 * (int64_t)snode[t / 3] + t % 3] = (double)comp4[4 * (t / 3) + t % 3];
 }
 void launch_sb_gather(hipStream_t st, int64_t nb, const int32_t* sb_row, const int64_t* sb_src, const int32_t* sb_stride,
                       const double* Avv, float* vals) {
   hipLaunchKernelGGL(k_sb_gather, dim3(gridn(nb)), dim3(256), 0, st, nb, sb_row, sb_src, sb_stride, Avv, vals);
 }
 void launch_sb_dinv(hipStream_t st, int64_t nS, const int32_t* snode, const int64_t* diagpos3, const double* Avv, float* dinv) {
-  hipLaunchKernelGGL(k_sb_dinv, dim3(gridn(3 * nS)), dim3(256), 0, st, nS, snode, diagpos3, Avv, dinv);
+  hipLaunchKernelGGL(k_sb_dinv, dim3(gridn(4 * nS)), dim3(256), 0, st, nS, snode, diagpos3, Avv, dinv);
 }
 void launch_spmv_sb(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
                     const float* x, float* y) {
@@ -629,7 +644,7 @@ void launch_cheb_step_f32(hipStream_t st, int64_t n, const float* t, const float
   hipLaunchKernelGGL(k_cheb_step_f32, dim3(gridn(n)), dim3(256), 0, st, n, t, dinv, c1, c2, x, r, d);
 }
 void launch_gather3_f32(hipStream_t st, int64_t nS, const int32_t* snode, const double* full, float* comp) {
-  hipLaunchKernelGGL(k_gather3_f32, dim3(gridn(3 * nS)), dim3(256), 0, st, nS, snode, full, comp);
+  hipLaunchKernelGGL(k_gather3_f32, dim3(gridn(4 * nS)), dim3(256), 0, st, nS, snode, full, comp);
 }
 void launch_scatter3_f32(hipStream_t st, int64_t nS, const int32_t* snode, const float* comp, double* full) {
   hipLaunchKernelGGL(k_scatter3_f32, dim3(gridn(3 * nS)), dim3(256), 0, st, nS, snode, comp, full);

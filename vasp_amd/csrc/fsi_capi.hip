@@ -200,11 +200,11 @@ void schur_apply(FsiCtx* ctx, const double* in, double* out, double* w3) {
 // FP32 Chebyshev sweeps on a component-diagonal node-block matrix; dinv carries the Jacobi scaling and the mask
 void cheb_db_f32(FsiCtx* ctx, const float* db, const float* dinv, const double* rhs, double* x, double* W, int its,
                  double lmax, double kappa) {
-  const int64_t n = 3 * ctx->N2;
+  const int64_t n = 4 * ctx->N2;                 // float4 per node
   hipStream_t st = ctx->stream;
-  float* F = reinterpret_cast<float*>(W);
+  float* F = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(W) + 15) & ~uintptr_t(15));   // float4 loads
   float *fr = F, *fd = F + n, *ft = F + 2 * n, *fx = F + 3 * n, *frhs = F + 4 * n;
-  launch_to_f32(st, n, rhs, frhs);
+  launch_pad_to_f32(st, ctx->N2, rhs, nullptr, frhs);
   const double lmin = lmax / kappa, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
   double rho = 1.0 / sig;
   launch_cheb_init_f32(st, n, frhs, dinv, (float)(1.0 / th), fx, fr, fd);
@@ -217,7 +217,7 @@ void cheb_db_f32(FsiCtx* ctx, const float* db, const float* dinv, const double* 
     launch_cheb_step_f32(st, n, ft, dinv, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
     rho = rn;
   }
-  launch_from_f32(st, n, fx, x);
+  launch_unpad_from_f32(st, ctx->N2, fx, x);
 }
 
 // z = M^-1 r with the approximate block factorisation (see fsi_block.hip):  (v,p) by SIMPLE with the d-eliminated
@@ -227,15 +227,15 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   hipStream_t st = ctx->stream;
   double* W = ctx->blk.p;
   double *rd = W, *rv = W + n3, *rp = W + 2 * n3, *vs = W + 3 * n3, *tp = W + 4 * n3, *dp = W + 5 * n3, *dv = W + 6 * n3,
-         *td = W + 7 * n3, *dd = W + 8 * n3, *IW = W + 9 * n3, *w3 = W + 17 * n3;
+         *td = W + 7 * n3, *dd = W + 8 * n3, *IW = W + 9 * n3, *w3 = W + 19 * n3;     // IW: 10 vectors; its first 4 hold the (FP32, float4-padded) sweep work
   launch_split(st, N2, V, r, rd, rv, rp);
   // velocity predictor: block Gauss-Seidel solid (elasticity-dominated, many cheap sweeps) -> fluid interior (mass-dominated)
   {
-    double *xs = IW + 3 * n3, *xf = IW + 4 * n3, *rhs2 = IW + 5 * n3;
-    double *cs_rhs = IW + 6 * n3, *cs_x = IW + 7 * n3;            // compact solid vectors (3 nS <= n3)
+    double *xs = IW + 4 * n3, *xf = IW + 5 * n3, *rhs2 = IW + 6 * n3;
+    double *cs_rhs = IW + 7 * n3, *cs_x = IW + 8 * n3;            // compact solid vectors (3 nS <= n3)
     if (ctx->solid_fp32) {
-      const int64_t n = 3 * ctx->nS;
-      float* F = reinterpret_cast<float*>(IW);
+      const int64_t n = 4 * ctx->nS;               // float4 per solid node
+      float* F = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(IW) + 15) & ~uintptr_t(15));   // float4 loads
       float *fr = F, *fd = F + n, *ft = F + 2 * n, *fx = F + 3 * n, *frhs = F + 4 * n;
       launch_gather3_f32(st, ctx->nS, ctx->snode.p, rv, frhs);
       const double lmax = ctx->lmax_s, lmin = lmax / ctx->cheb_kappa_s, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
@@ -303,10 +303,10 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   if (ctx->cheb_its_d > 0) {
     if (ctx->dd_is_scalar && ctx->sweeps_fp32) {
       // Jacobi-scaled system  (D^-1 A_dd) dd = D^-1 td  with the one-number-per-node-pair operator
-      const int64_t n = n3;
-      float* F = reinterpret_cast<float*>(IW);
+      const int64_t n = 4 * N2;
+      float* F = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(IW) + 15) & ~uintptr_t(15));   // float4 loads
       float *fr = F, *fd = F + n, *ft = F + 2 * n, *fx = F + 3 * n, *frhs = F + 4 * n;
-      launch_scale_to_f32(st, n, td, ctx->dd_dinv32.p, frhs);
+      launch_pad_to_f32(st, N2, td, ctx->dd_dinv32.p, frhs);
       const double lmax = ctx->lmax_d, lmin = lmax / ctx->cheb_kappa_d, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
       double rho = 1.0 / sig;
       launch_cheb_init_f32(st, n, frhs, ctx->ones32.p, (float)(1.0 / th), fx, fr, fd);
@@ -316,7 +316,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         launch_cheb_step_f32(st, n, ft, ctx->ones32.p, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
         rho = rn;
       }
-      launch_from_f32(st, n, fx, dd);
+      launch_unpad_from_f32(st, N2, fx, dd);
     } else if (ctx->dd_is_db && ctx->sweeps_fp32)
       cheb_db_f32(ctx, ctx->dd_db32.p, ctx->dd_dinv32.p, td, dd, IW, ctx->cheb_its_d, ctx->lmax_d, ctx->cheb_kappa_d);
     else if (ctx->dd_is_db)
@@ -537,8 +537,8 @@ int refresh_preconditioner(FsiCtx* ctx) {
       ctx->dd_is_scalar = ctx->dd_is_db && !(flags[1] & 16) && !getenv("FSI_NO_SCALAR_DD");
       launch_to_f32(st, 3 * npairs, ctx->dd_db.p, ctx->dd_db32.p);
       launch_to_f32(st, 3 * npairs, ctx->vv_db.p, ctx->vv_db32.p);
-      launch_dinv_f32(st, 3 * ctx->N2, nullptr, ctx->diagpos3.p, ctx->Mdd.vals.p, ctx->dd_dinv32.p);
-      launch_dinv_f32(st, 3 * ctx->N2, ctx->mask_f.p, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->vvf_dinv32.p);
+      launch_dinv_f32(st, ctx->N2, nullptr, ctx->diagpos3.p, ctx->Mdd.vals.p, ctx->dd_dinv32.p);
+      launch_dinv_f32(st, ctx->N2, ctx->mask_f.p, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->vvf_dinv32.p);
     }
     launch_gather_vals(st, (int64_t)ctx->ss_vals.n, ctx->ss_src.p, ctx->Mvv.vals.p, ctx->ss_vals.p);
     launch_sb_gather(st, ctx->sb_nblocks, ctx->sb_row.p, ctx->sb_src.p, ctx->sb_stride.p, ctx->Mvv.vals.p, ctx->sb_vals.p);
@@ -548,7 +548,7 @@ int refresh_preconditioner(FsiCtx* ctx) {
                          ctx->Mvv.vals.p, ctx->diagpos3.p, ctx->mask_f.p, ctx->blk.p, &ctx->lmax_f));
     FSICHK(power_lmax(ctx, CsrRef{3 * ctx->N2, ctx->rowptr3.p, ctx->cols3.p, ctx->Mdd.vals.p, ctx->diagpos3.p}, nullptr,
                       ctx->blk.p, &ctx->lmax_d));
-    FSICHK(power_lmax_op(ctx, ctx->V, [&](const double* in, double* o) { schur_apply(ctx, in, o, ctx->blk.p + 17 * 3 * ctx->N2); },
+    FSICHK(power_lmax_op(ctx, ctx->V, [&](const double* in, double* o) { schur_apply(ctx, in, o, ctx->blk.p + 19 * 3 * ctx->N2); },
                          ctx->s_vals.p, ctx->s_diagpos.p, nullptr, ctx->blk.p, &ctx->lmax_p));
     for (SubMat* M : {&ctx->Mdd, &ctx->Ms}) {
       if ((M == &ctx->Mdd && ctx->cheb_its_d > 0) || (M == &ctx->Ms && ctx->cheb_its_p > 0)) continue;   // Jacobi-Chebyshev: no factors
@@ -961,7 +961,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
         FSICHK(upload(ctx, ctx->sb_row, sb_row));
         FSICHK(upload(ctx, ctx->sb_stride, sb_stride));
         HIPCHK(ctx->sb_vals.alloc(9 * sb_col.size()));
-        HIPCHK(ctx->sb_dinv.alloc(3 * nS));
+        HIPCHK(ctx->sb_dinv.alloc(4 * nS));
         if (const char* e = getenv("FSI_SOLID_FP32")) ctx->solid_fp32 = atoi(e);
       }
       FSICHK(upload(ctx, ctx->snode, snode));
@@ -1021,14 +1021,15 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
     HIPCHK(ctx->adv_db.alloc(3 * nadj_total));
     HIPCHK(ctx->dd_db32.alloc(3 * nadj_total));
     HIPCHK(ctx->vv_db32.alloc(3 * nadj_total));
-    HIPCHK(ctx->dd_dinv32.alloc(3 * N2));
+    HIPCHK(ctx->dd_dinv32.alloc(4 * N2));
     HIPCHK(ctx->dd_chat.alloc(nadj_total));
     HIPCHK(ctx->dd_rowflag.alloc(3 * N2));
     {
-      std::vector<float> ones(3 * N2, 1.0f);
+      std::vector<float> ones(4 * N2, 1.0f);
+      for (int64_t i = 0; i < N2; ++i) ones[4 * i + 3] = 0.0f;
       FSICHK(upload(ctx, ctx->ones32, ones));
     }
-    HIPCHK(ctx->vvf_dinv32.alloc(3 * N2));
+    HIPCHK(ctx->vvf_dinv32.alloc(4 * N2));
     if (const char* e = getenv("FSI_SWEEPS_FP32")) ctx->sweeps_fp32 = atoi(e);
     HIPCHK(ctx->Avp.alloc(3 * padj_total));
     HIPCHK(ctx->Apv.alloc(rowptr_pv[V]));
@@ -1073,7 +1074,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
       FSICHK(upload(ctx, ctx->s_cols, s_cols));
       HIPCHK(ctx->s_vals.alloc(s_cols.size()));
     }
-    HIPCHK(ctx->blk.alloc((size_t)18 * 3 * N2));
+    HIPCHK(ctx->blk.alloc((size_t)20 * 3 * N2 + 16));
   }
   HIPCHK(hipMemsetAsync(ctx->A_pre.p, 0, ctx->nnz * sizeof(double), ctx->stream));
   HIPCHK(ctx->iflags.alloc(n + 16));

@@ -105,11 +105,11 @@ void launch_extract_chat(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, co
                          float* chat, uint8_t* rowflag, int32_t* flags);
 void launch_spmv_sc_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const float* chat,
                         const uint8_t* rowflag, const float* x, float* y);
-void launch_scale_to_f32(hipStream_t st, int64_t n, const double* a, const float* s, float* b);
 void launch_spmv_db_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const float* db,
                         const float* x, float* y);
 void launch_to_f32(hipStream_t st, int64_t n, const double* a, float* b);
-void launch_from_f32(hipStream_t st, int64_t n, const float* a, double* b);
+void launch_pad_to_f32(hipStream_t st, int64_t nn, const double* a, const float* scale4, float* b);
+void launch_unpad_from_f32(hipStream_t st, int64_t nn, const float* a, double* b);
 void launch_dinv_f32(hipStream_t st, int64_t n, const double* mask, const int64_t* diagpos, const double* A, float* dinv);
 void launch_sb_gather(hipStream_t st, int64_t nb, const int32_t* sb_row, const int64_t* sb_src, const int32_t* sb_stride,
                       const double* Avv, float* vals);
