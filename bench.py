@@ -146,10 +146,15 @@ def main():
         sweeps = tm["inner_vv_iters"] * (ns_cheb[0] / max(1, ns_cheb[0] + ns_cheb[1]))     # solid-block SpMV launches
         ss_avg = tm["solid_spmv_ms"] / max(1, tm["solid_spmv_calls"])
         db_avg = tm["db_spmv_ms"] / max(1, tm["db_spmv_calls"])
-        db_launches = tm["inner_dd_iters"] + tm["inner_vv_iters"] * (ns_cheb[1] / max(1, ns_cheb[0] + ns_cheb[1]))
+        f_launches = tm["inner_vv_iters"] * (ns_cheb[1] / max(1, ns_cheb[0] + ns_cheb[1]))
+        db_launches = f_launches + (0 if tm["disp_scalar"] else tm["inner_dd_iters"])
+        sc_avg = tm["sc_spmv_ms"] / max(1, tm["sc_spmv_calls"])
+        sc_launches = tm["inner_dd_iters"] if tm["disp_scalar"] else 0
         kernels = {
-            "k_spmv_db_f32 (displacement / fluid velocity block, FP32 component-diagonal node blocks, Chebyshev sweeps; avg from sampled HIP events)":
-                (db_avg * db_launches, int(db_launches), tm["db_pairs"] * 16.0 + tm["db_nodes"] * 32.0),
+            "k_spmv_sc_f32 (displacement block sweeps: one FP32 ratio per node pair, float4 vectors; avg from sampled HIP events)":
+                (sc_avg * sc_launches, int(sc_launches), tm["db_pairs"] * 8.0 + tm["db_nodes"] * 43.0),
+            "k_spmv_db_f32 (fluid velocity block sweeps, FP32 component-diagonal node blocks; avg from sampled HIP events)":
+                (db_avg * db_launches, int(db_launches), tm["db_pairs"] * 16.0 + tm["db_nodes"] * 40.0),
             # (time attributed in the timed region [ms], launches, algorithmic bytes per launch, avg launch [ms])
             ("k_spmv_sb (solid velocity block, FP32 3x3 block-CSR, Chebyshev sweeps; avg from sampled HIP events)"
              if solid_fp32 else "k_spmv<1> (solid velocity block, CSR f64, Chebyshev sweeps; avg from sampled HIP events)"):

@@ -139,6 +139,15 @@ int fsi_get_matrix(FsiCtx* ctx, int64_t* rowptr, int64_t* cols, double* vals);
 /* y = A x with the device SpMV (user layout in/out). */
 int fsi_spmv(FsiCtx* ctx, const double* x, double* y);
 
+/* ---- per-step diagnostics of post_solve on the device --------------------------------------------------- */
+/* Replaces: peval / print_probe_points / print_solid_probe_points [REF src/vasp/simulations/simulation_common.py:157-222].
+ * Points are located once on the host (cell + barycentric coordinates, -1 = outside: the reference's +inf sentinel is
+ * the caller's business); out[i] = d_x d_y d_z v_x v_y v_z p of dvp_["n"] at point i (P2 / P1 interpolation). */
+int fsi_probe(FsiCtx* ctx, int64_t n, const int32_t* cells, const double* bary, double* out);
+/* Replaces: the DG0 projections of calculate_and_print_flow_properties (:253-317) and compute_minimum_jacobian (:320-348):
+ * out[0..3] = mean, min, max over the cells of the cell-mean |v|, and min over the cells of the cell-mean det(I + grad d). */
+int fsi_flow_stats(FsiCtx* ctx, double* out);
+
 /* ---- timing of the device kernels (HIP events on the solver stream) ---------------------------------- */
 typedef struct FsiTimers {
   double residual_ms;  int64_t residual_calls;
@@ -156,6 +165,8 @@ typedef struct FsiTimers {
   int64_t solid_nnz;     int64_t solid_rows;         /* size of that block                                            */
   double db_spmv_ms;     int64_t db_spmv_calls;      /* sampled launches of the FP32 component-diagonal SpMV          */
   int64_t db_pairs;      int64_t db_nodes;           /* node pairs / nodes of that structure                          */
+  double sc_spmv_ms;     int64_t sc_spmv_calls;      /* sampled launches of the scalar-ratio displacement SpMV        */
+  int64_t disp_scalar;                               /* 1 if the displacement sweeps use that kernel                  */
 } FsiTimers;
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
 

@@ -309,3 +309,31 @@ def test_offset_stenosis_five_steps_match_converged_golden(stenosis_case):
         err = np.linalg.norm(U[sl] - gold[4][sl]) / np.linalg.norm(gold[4][sl])
         assert err < 1e-6, (name, err)
     hb.close()
+
+
+def test_device_diagnostics_match_host(cylinder_case):
+    """fsi_probe / fsi_flow_stats (post_solve diagnostics on the device) vs the numpy versions of simulation_common."""
+    from vasp_amd.capi import HipBackend
+    from vasp_amd.fem import MixedFunction
+    from vasp_amd.simulation_common import dg0_jacobian, dg0_velocity_magnitude
+    ns, desc = cylinder_case[0], cylinder_case[1]
+    mesh = ns["mesh"]
+    U = np.load(GOLDEN / "cylinder_tight.npz")["states"][2].copy()
+    U[:3 * mesh.num_nodes] *= 1e3                                     # make det(I + grad d) visibly different from 1
+    hb = HipBackend(desc)
+    hb.set_state("n", U)
+    d, v, p = mesh.split(U)
+    vm = dg0_velocity_magnitude(mesh, v)
+    jm = dg0_jacobian(mesh, d)
+    mean, mn, mx, minj = hb.flow_stats()
+    assert np.isclose(mean, vm.mean(), rtol=1e-12) and np.isclose(mn, vm.min(), rtol=1e-10, atol=1e-300)
+    assert np.isclose(mx, vm.max(), rtol=1e-12) and np.isclose(minj, jm.min(), rtol=1e-12)
+    pts = mesh.cell_midpoints()[::101] + 1e-6
+    cells, bary = mesh.locate(pts)
+    out = hb.probe(cells, bary)
+    f = MixedFunction(mesh, U)
+    for i, x in enumerate(pts):
+        assert np.allclose(out[i, 0:3], f.sub(0)(x), rtol=1e-12, atol=1e-300)
+        assert np.allclose(out[i, 3:6], f.sub(1)(x), rtol=1e-12, atol=1e-300)
+        assert np.isclose(out[i, 6], f.sub(2)(x), rtol=1e-12, atol=1e-300)
+    hb.close()

@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "fsi_set_pressure_facets", "fsi_set_interface_pressure", "fsi_set_robin_facets", "fsi_solver_setup",
     "fsi_assemble_residual", "fsi_assemble_jacobian", "fsi_solve", "fsi_newton_solve", "fsi_shift",
     "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_get_matrix", "fsi_spmv",
-    "fsi_get_timers", "fsi_set_linear_solver", "fsi_set_chebyshev",
+    "fsi_get_timers", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats",
 )
 
 
@@ -58,7 +58,8 @@ class FsiTimers(C.Structure):
                 ("inner_vv_iters", C.c_int64), ("inner_schur_iters", C.c_int64), ("inner_dd_iters", C.c_int64),
                 ("precond_applies", C.c_int64), ("solid_spmv_ms", C.c_double), ("solid_spmv_calls", C.c_int64),
                 ("solid_nnz", C.c_int64), ("solid_rows", C.c_int64), ("db_spmv_ms", C.c_double),
-                ("db_spmv_calls", C.c_int64), ("db_pairs", C.c_int64), ("db_nodes", C.c_int64)]
+                ("db_spmv_calls", C.c_int64), ("db_pairs", C.c_int64), ("db_nodes", C.c_int64),
+                ("sc_spmv_ms", C.c_double), ("sc_spmv_calls", C.c_int64), ("disp_scalar", C.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -109,6 +110,8 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_spmv.argtypes = [vp, vp, vp]
     lib.fsi_get_timers.argtypes = [vp, C.POINTER(FsiTimers), C.c_int]
     lib.fsi_set_linear_solver.argtypes = [vp, i32, dbl, i32]
+    lib.fsi_probe.argtypes = [vp, i64, vp, vp, vp]
+    lib.fsi_flow_stats.argtypes = [vp, vp]
     lib.fsi_set_chebyshev.argtypes = [vp, i32, dbl, i32, dbl, i32, dbl, i32, dbl]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
@@ -270,6 +273,20 @@ class HipBackend:
         self._check(self.lib.fsi_set_chebyshev(self.ctx, int(its_solid), float(kappa_solid), int(its_fluid),
                                                float(kappa_fluid), int(its_schur), float(kappa_schur), int(its_disp),
                                                float(kappa_disp)))
+
+    def probe(self, cells, bary):
+        """(n,7) array d(3) v(3) p of dvp_["n"] at located points (cells (n,), barycentric (n,4))."""
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        bary = np.ascontiguousarray(bary, dtype=np.float64)
+        out = np.empty((len(cells), 7))
+        self._check(self.lib.fsi_probe(self.ctx, len(cells), _ptr(cells), _ptr(bary), _ptr(out)))
+        return out
+
+    def flow_stats(self):
+        """(mean, min, max of the cell-mean |v|, min of the cell-mean det(I + grad d)) of dvp_["n"]."""
+        out = np.empty(4)
+        self._check(self.lib.fsi_flow_stats(self.ctx, _ptr(out)))
+        return tuple(out)
 
     def timers(self, reset=False) -> dict:
         t = FsiTimers()

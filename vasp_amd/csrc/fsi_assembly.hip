@@ -193,6 +193,82 @@ __global__ __launch_bounds__(64) void k_l2norm(ElemArrays ea, const double* __re
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   if (lane == 0) unsafeAtomicAdd(out, s);
 }
+// ---------------------------------------------------------------------------------------------------------
+// per-step diagnostics of post_solve [REF src/vasp/simulations/simulation_common.py:253-348]: per cell the DG0
+// projection (= quadrature mean) of |v| and of det(I + grad d); and point evaluation of (d, v, p) at located probes
+// [REF :157-222].  cellvals: [2][C].
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_cell_stats(ElemArrays ea, const double* __restrict__ X, int64_t C,
+                                                   double* __restrict__ cellvals) {
+  const int64_t c = blockIdx.x;
+  const int lane = threadIdx.x;
+  __shared__ double sU[NLOC], sJ[10];
+  sU[lane] = X[ea.cell_dofs[c * NLOC + lane]];
+  if (lane < 10) sJ[lane] = ea.geom[c * 10 + lane];
+  __syncthreads();
+  double sv = 0.0, sj = 0.0;
+  if (lane < NQ) {
+    Kin<double> k;
+    interpolate(sU, sJ, lane, k);
+    const double w = 6.0 * c_qw[lane];                       // weights sum to 1/6: cell mean
+    sv = w * sqrt(k.v[0] * k.v[0] + k.v[1] * k.v[1] + k.v[2] * k.v[2]);
+    double Fi[3][3];
+    sj = w * inv_det_F<double>(k.gd, Fi);
+  }
+  for (int off = 32; off > 0; off >>= 1) { sv += __shfl_xor(sv, off, 64); sj += __shfl_xor(sj, off, 64); }
+  if (lane == 0) { cellvals[c] = sv; cellvals[C + c] = sj; }
+}
+// out[0..3] = sum, min, max of a[0..n) ; out[4] = min of b[0..n).  One block; n up to a few million.
+__global__ __launch_bounds__(1024) void k_stats_reduce(int64_t n, const double* __restrict__ a, const double* __restrict__ b,
+                                                       double* __restrict__ out) {
+  __shared__ double ssum[1024], smin[1024], smax[1024], sminb[1024];
+  double s = 0.0, mn = 1e300, mx = -1e300, mb = 1e300;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double v = a[i];
+    s += v; mn = fmin(mn, v); mx = fmax(mx, v); mb = fmin(mb, b[i]);
+  }
+  ssum[threadIdx.x] = s; smin[threadIdx.x] = mn; smax[threadIdx.x] = mx; sminb[threadIdx.x] = mb;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      ssum[threadIdx.x] += ssum[threadIdx.x + off];
+      smin[threadIdx.x] = fmin(smin[threadIdx.x], smin[threadIdx.x + off]);
+      smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + off]);
+      sminb[threadIdx.x] = fmin(sminb[threadIdx.x], sminb[threadIdx.x + off]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = ssum[0]; out[1] = smin[0]; out[2] = smax[0]; out[3] = sminb[0]; }
+}
+// probes: out[i][0..6] = d(3), v(3), p at barycentric coordinates bary[i][4] of cell cells[i] (P2 / P1 interpolation)
+__global__ void k_probe(int64_t n, ElemArrays ea, const int32_t* __restrict__ cells, const double* __restrict__ bary,
+                        const double* __restrict__ X, double* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t c = cells[i];
+  const double* l = bary + 4 * i;
+  double N[10];
+  for (int a = 0; a < 4; ++a) N[a] = l[a] * (2.0 * l[a] - 1.0);
+  const int E[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
+  for (int e = 0; e < 6; ++e) N[4 + e] = 4.0 * l[E[e][0]] * l[E[e][1]];
+  const int32_t* dofs = ea.cell_dofs + c * NLOC;
+  for (int f = 0; f < 6; ++f) {
+    double s = 0.0;
+    for (int a = 0; a < 10; ++a) s += N[a] * X[dofs[f * 10 + a]];
+    out[7 * i + f] = s;
+  }
+  double p = 0.0;
+  for (int a = 0; a < 4; ++a) p += l[a] * X[dofs[60 + a]];
+  out[7 * i + 6] = p;
+}
+void launch_cell_stats(hipStream_t st, int64_t C, const ElemArrays& ea, const double* X, double* cellvals, double* out) {
+  hipLaunchKernelGGL(k_cell_stats, dim3((unsigned)C), dim3(64), 0, st, ea, X, C, cellvals);
+  hipLaunchKernelGGL(k_stats_reduce, dim3(1), dim3(1024), 0, st, C, cellvals, cellvals + C, out);
+}
+void launch_probe(hipStream_t st, int64_t n, const ElemArrays& ea, const int32_t* cells, const double* bary, const double* X,
+                  double* out) {
+  hipLaunchKernelGGL(k_probe, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, ea, cells, bary, X, out);
+}
 void launch_l2norm(hipStream_t st, int64_t C, const ElemArrays& ea, const double* X, double* out) {
   hipLaunchKernelGGL(k_l2norm, dim3((unsigned)C), dim3(64), 0, st, ea, X, out);
 }

@@ -311,7 +311,10 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
       double rho = 1.0 / sig;
       launch_cheb_init_f32(st, n, frhs, ctx->ones32.p, (float)(1.0 / th), fx, fr, fd);
       for (int k = 0; k < ctx->cheb_its_d; ++k) {
+        const bool timed = k < 4 && ctx->sc_ev0[0];
+        if (timed) (void)hipEventRecord(ctx->sc_ev0[k], st);
         launch_spmv_sc_f32(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_chat.p, ctx->dd_rowflag.p, fd, ft);
+        if (timed) { (void)hipEventRecord(ctx->sc_ev1[k], st); ctx->sc_samples_pending = k + 1; }
         const double rn = 1.0 / (2.0 * sig - rho);
         launch_cheb_step_f32(st, n, ft, ctx->ones32.p, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
         rho = rn;
@@ -333,6 +336,14 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   }
   launch_merge(st, N2, V, dd, dv, dp, z);
   ctx->inner_calls += 1;
+  if (ctx->sc_samples_pending > 0) {      // sampled launch durations of the scalar-ratio displacement SpMV
+    (void)hipEventSynchronize(ctx->sc_ev1[ctx->sc_samples_pending - 1]);
+    for (int k = 0; k < ctx->sc_samples_pending; ++k) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ctx->sc_ev0[k], ctx->sc_ev1[k]) == hipSuccess) { ctx->t_sc.ms += ms; ctx->t_sc.calls += 1; }
+    }
+    ctx->sc_samples_pending = 0;
+  }
   if (ctx->db_samples_pending > 0) {      // sampled launch durations of the FP32 component-diagonal SpMV
     (void)hipEventSynchronize(ctx->db_ev1[ctx->db_samples_pending - 1]);
     for (int k = 0; k < ctx->db_samples_pending; ++k) {
@@ -559,6 +570,19 @@ int refresh_preconditioner(FsiCtx* ctx) {
       if (flags[1] & 1) { ctx->err = "ILU(0): a row has more than 1024 entries"; return FSI_ERR_INVALID; }
       if (flags[1] & 2) ctx->pivot_warnings += 1;      // pivot replaced by 1: the inner solve stays approximate
     }
+    // self-test: a Chebyshev interval that misses the top of a spectrum (non-normal blocks at rough states) blows up;
+    // widen the intervals until one application to a rippled vector stays finite and bounded
+    ctx->prec_bad = false;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+      launch_mask_ripple(st, ctx->ndof, nullptr, ctx->tmp1.p);
+      FSICHK(precondition_block(ctx, ctx->tmp1.p, ctx->tmp2.p));
+      double zin = 0.0, zout = 0.0;
+      FSICHK(norm2(ctx, ctx->tmp1.p, &zin));
+      FSICHK(norm2(ctx, ctx->tmp2.p, &zout));
+      if (std::isfinite(zout) && zout < 1e8 * zin) break;
+      if (attempt == 7) { ctx->prec_bad = true; break; }      // reported by fsi_solve: assembling such a Jacobian is legal
+      ctx->lmax_s *= 1.6; ctx->lmax_f *= 1.6; ctx->lmax_p *= 1.6; ctx->lmax_d *= 1.6;
+    }
     return FSI_OK;
   }
   if (!ctx->LU.p) HIPCHK(ctx->LU.alloc(ctx->nnz));
@@ -623,6 +647,7 @@ int fsi_destroy(FsiCtx* ctx) {
   for (auto* b : i64) b->release();
   ctx->enbr.release();
   ctx->epnbr.release();
+  ctx->cellvals.release();
   for (auto* b : {&ctx->Adv, &ctx->Avp, &ctx->Apv, &ctx->App, &ctx->blk, &ctx->Mdd.vals, &ctx->Mdd.LU, &ctx->Mvv.vals,
                   &ctx->Mvv.LU, &ctx->Ms.vals, &ctx->Ms.LU, &ctx->mask_s, &ctx->mask_f, &ctx->ss_vals, &ctx->dd_db, &ctx->vv_db, &ctx->adv_db, &ctx->s_vals}) b->release();
   ctx->s_rowptr.release(); ctx->s_diagpos.release(); ctx->s_cols.release();
@@ -635,6 +660,7 @@ int fsi_destroy(FsiCtx* ctx) {
   for (auto* b : {&ctx->rowptr3, &ctx->diagpos3, &ctx->rowptr_vp, &ctx->rowptr_pv, &ctx->rowptr_pp, &ctx->diagpos_pp}) b->release();
   for (int k = 0; k < 8; ++k) { if (ctx->ss_ev0[k]) (void)hipEventDestroy(ctx->ss_ev0[k]); if (ctx->ss_ev1[k]) (void)hipEventDestroy(ctx->ss_ev1[k]); }
   for (int k = 0; k < 8; ++k) { if (ctx->db_ev0[k]) (void)hipEventDestroy(ctx->db_ev0[k]); if (ctx->db_ev1[k]) (void)hipEventDestroy(ctx->db_ev1[k]); }
+  for (int k = 0; k < 4; ++k) { if (ctx->sc_ev0[k]) (void)hipEventDestroy(ctx->sc_ev0[k]); if (ctx->sc_ev1[k]) (void)hipEventDestroy(ctx->sc_ev1[k]); }
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -972,6 +998,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
       HIPCHK(ctx->ss_vals.alloc(ss_cols.size()));
       for (int k = 0; k < 8; ++k) { HIPCHK(hipEventCreate(&ctx->ss_ev0[k])); HIPCHK(hipEventCreate(&ctx->ss_ev1[k])); }
       for (int k = 0; k < 8; ++k) { HIPCHK(hipEventCreate(&ctx->db_ev0[k])); HIPCHK(hipEventCreate(&ctx->db_ev1[k])); }
+      for (int k = 0; k < 4; ++k) { HIPCHK(hipEventCreate(&ctx->sc_ev0[k])); HIPCHK(hipEventCreate(&ctx->sc_ev1[k])); }
       FSICHK(upload(ctx, ctx->mask_s, ms));
       FSICHK(upload(ctx, ctx->mask_f, mf));
       if (const char* e = getenv("FSI_CHEB_S")) ctx->cheb_its_s = atoi(e);
@@ -1252,6 +1279,7 @@ int fsi_assemble_jacobian(FsiCtx* ctx) {
 int fsi_solve(FsiCtx* ctx, double lin_rtol, int32_t lin_max_it, int32_t lin_solver, int32_t* iters, double* relres) {
   if (!ctx) return FSI_ERR_INVALID;
   if (!ctx->have_jacobian) { ctx->err = "fsi_solve: no Jacobian assembled"; return FSI_ERR_INVALID; }
+  if (ctx->precond == 0 && ctx->prec_bad) { ctx->err = "block preconditioner: Chebyshev sweeps diverge on this Jacobian"; return FSI_ERR_LINEAR; }
   HIPCHK(hipSetDevice(ctx->device));
   launch_mul(ctx->stream, ctx->bs.p, ctx->rowscale.p, ctx->b.p, ctx->ndof);
   int it = 0;
@@ -1396,6 +1424,39 @@ int fsi_spmv(FsiCtx* ctx, const double* x, double* y) {
   return FSI_OK;
 }
 
+int fsi_probe(FsiCtx* ctx, int64_t n, const int32_t* cells, const double* bary, double* out) {
+  if (!ctx || n < 0 || (n > 0 && (!cells || !bary || !out))) return FSI_ERR_INVALID;
+  if (n == 0) return FSI_OK;
+  for (int64_t i = 0; i < n; ++i)
+    if (cells[i] < 0 || cells[i] >= ctx->C) { ctx->err = "fsi_probe: cell out of range (locate the points first)"; return FSI_ERR_INVALID; }
+  HIPCHK(hipSetDevice(ctx->device));
+  DevBuf<int32_t> dc;
+  DevBuf<double> db, dout;
+  HIPCHK(dc.alloc(n)); HIPCHK(db.alloc(4 * n)); HIPCHK(dout.alloc(7 * n));
+  HIPCHK(hipMemcpyAsync(dc.p, cells, n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(db.p, bary, 4 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  launch_probe(ctx->stream, n, elem_arrays(ctx), dc.p, db.p, ctx->U.p, dout.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, dout.p, 7 * n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  dc.release(); db.release(); dout.release();
+  return FSI_OK;
+}
+
+int fsi_flow_stats(FsiCtx* ctx, double* out) {
+  if (!ctx || !out) return FSI_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->cellvals.p) HIPCHK(ctx->cellvals.alloc(2 * ctx->C + 8));
+  double* res = ctx->cellvals.p + 2 * ctx->C;
+  launch_cell_stats(ctx->stream, ctx->C, elem_arrays(ctx), ctx->U.p, ctx->cellvals.p, res);
+  HIPCHK(hipGetLastError());
+  double h[4];
+  HIPCHK(hipMemcpyAsync(h, res, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  out[0] = h[0] / (double)ctx->C; out[1] = h[1]; out[2] = h[2]; out[3] = h[3];
+  return FSI_OK;
+}
+
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
   if (!ctx || !out) return FSI_ERR_INVALID;
   *out = FsiTimers{ctx->t_res.ms,  ctx->t_res.calls,  ctx->t_jac.ms,   ctx->t_jac.calls,   ctx->t_fac.ms, ctx->t_fac.calls,
@@ -1403,9 +1464,10 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
                    ctx->t_ortho.calls, ctx->t_kry.ms, ctx->t_kry.calls, ctx->kry_iters,
                    ctx->inner_its[0], ctx->inner_its[1], ctx->inner_its[2], ctx->inner_calls,
                    ctx->t_ss.ms, ctx->t_ss.calls, ctx->solid_fp32 ? 9 * ctx->sb_nblocks : (int64_t)ctx->ss_vals.n, 3 * ctx->nS,
-                   ctx->t_db.ms, ctx->t_db.calls, (int64_t)ctx->dd_db.n / 3, ctx->N2};
+                   ctx->t_db.ms, ctx->t_db.calls, (int64_t)ctx->dd_db.n / 3, ctx->N2, ctx->t_sc.ms, ctx->t_sc.calls,
+                   (int64_t)(ctx->dd_is_scalar && ctx->sweeps_fp32)};
   if (reset) {
-    for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_kry, &ctx->t_ss, &ctx->t_db}) {
+    for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_kry, &ctx->t_ss, &ctx->t_db, &ctx->t_sc}) {
       t->ms = 0.0;
       t->calls = 0;
     }

@@ -104,6 +104,7 @@ struct FsiCtx {
   // vectors (solver ordering)
   fsi::DevBuf<double> U, U1, F, b, du, bs, tmp1, tmp2, tmp3, tmp4, tmp5, tmp6, tmp7;
   fsi::DevBuf<double> scratch;               // reductions
+  fsi::DevBuf<double> cellvals;              // per-cell diagnostics (fsi_flow_stats)
   fsi::DevBuf<int32_t> iflags;               // device-side error / counters
 
   // boundary data
@@ -122,6 +123,7 @@ struct FsiCtx {
   // field blocks for the block preconditioner (fsi_block.hip)
   int precond = 0;                           // 0 = field-split block preconditioner, 1 = monolithic multicolour ILU(0)
   bool have_monolithic_lu = false;
+  bool prec_bad = false;                     // the preconditioner self-test failed on the current Jacobian
   fsi::DevBuf<int32_t> node_solid;           // [N2] by rank
   fsi::DevBuf<int32_t> vrank;                // [V] rank of the node of pressure position q
   fsi::DevBuf<int64_t> rowptr3, diagpos3;    // 3x3-blocked node structure (A_dd, Avv~, A_dv)
@@ -172,6 +174,9 @@ struct FsiCtx {
   fsi::PhaseTimer t_db;
   hipEvent_t db_ev0[8] = {}, db_ev1[8] = {};
   int db_samples_pending = 0;
+  fsi::PhaseTimer t_sc;
+  hipEvent_t sc_ev0[4] = {}, sc_ev1[4] = {};
+  int sc_samples_pending = 0;
   int64_t kry_iters = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 

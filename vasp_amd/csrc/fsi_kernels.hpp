@@ -25,6 +25,9 @@ hipError_t upload_tables();
 void launch_geometry(hipStream_t st, int64_t C, const double* coords, const int32_t* tet_vertices, double* geom);
 void launch_residual(hipStream_t st, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
                      const double* U1, double* F);
+void launch_cell_stats(hipStream_t st, int64_t C, const ElemArrays& ea, const double* X, double* cellvals, double* out);
+void launch_probe(hipStream_t st, int64_t n, const ElemArrays& ea, const int32_t* cells, const double* bary, const double* X,
+                  double* out);
 void launch_l2norm(hipStream_t st, int64_t C, const ElemArrays& ea, const double* X, double* out);
 void launch_jacobian(hipStream_t st, int part, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
                      const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals);

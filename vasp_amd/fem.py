@@ -141,8 +141,9 @@ class FormTerms(list):
 class Function:
     """A view of one field (d, v or p) of a monolithic state vector, with point evaluation."""
 
-    def __init__(self, mesh: FsiMesh, fld: int, nodal: np.ndarray):
+    def __init__(self, mesh: FsiMesh, fld: int, nodal: np.ndarray, backend=None):
         self.mesh, self.field, self.nodal = mesh, fld, nodal
+        self.backend = backend          # the time-step kernel holding the same state on the device (or None)
         self._allow_extrapolation = False
 
     def get_allow_extrapolation(self):
@@ -170,8 +171,8 @@ class Function:
 class MixedFunction:
     """``dvp_["n"]``: the monolithic vector with ``sub(i, deepcopy=True)`` → ``Function``."""
 
-    def __init__(self, mesh: FsiMesh, vector: np.ndarray):
-        self.mesh, self._x = mesh, vector
+    def __init__(self, mesh: FsiMesh, vector: np.ndarray, backend=None):
+        self.mesh, self._x, self.backend = mesh, vector, backend
 
     def vector(self) -> np.ndarray:
         return self._x
@@ -179,4 +180,4 @@ class MixedFunction:
     def sub(self, i: int, deepcopy: bool = False) -> Function:
         parts = self.mesh.split(self._x)
         arr = parts[i].copy() if deepcopy else parts[i]
-        return Function(self.mesh, (FIELD_D, FIELD_V, FIELD_P)[i], arr)
+        return Function(self.mesh, (FIELD_D, FIELD_V, FIELD_P)[i], arr, backend=self.backend)

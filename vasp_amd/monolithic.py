@@ -240,6 +240,8 @@ def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_ba
     backend = backend_factory(desc)
     ns["backend"] = backend
     mesh = ns["mesh"]
+    if hasattr(backend, "flow_stats"):            # per-step diagnostics of post_solve run on the device
+        ns["dvp_"]["n"].backend = backend
     if ns.get("restart_folder"):                  # --restart-folder: resume from Checkpoint/ of an earlier run
         ck = Path(str(ns["restart_folder"])) / "Checkpoint"
         meta = json.loads((ck / "default_variables.json").read_text())

@@ -36,9 +36,35 @@ def peval(f, x):
         return np.inf * np.ones(f.value_shape())
 
 
+def _device_probe(f, probe_points):
+    """(values (n,7) or None, located mask): probes evaluated by the time-step kernel (fsi_probe) at points located
+    once on the host; points outside the mesh keep the reference's +inf sentinel."""
+    backend = getattr(f, "backend", None)
+    if backend is None or not hasattr(backend, "probe"):
+        return None, None
+    mesh = f.mesh
+    pts = np.atleast_2d(np.asarray(probe_points, dtype=float))
+    key = pts.tobytes()
+    cache = getattr(mesh, "_probe_cache", {})
+    if key not in cache:
+        cache[key] = mesh.locate(pts)
+        mesh._probe_cache = cache
+    cells, bary = cache[key]
+    ok = cells >= 0
+    vals = np.full((len(pts), 7), np.inf)
+    if ok.any():
+        vals[ok] = backend.probe(cells[ok], bary[ok])
+    return vals, ok
+
+
 def print_probe_points(v, p, probe_points) -> None:
     v.set_allow_extrapolation(False)
     p.set_allow_extrapolation(False)
+    vals, _ = _device_probe(v, probe_points)
+    if vals is not None:
+        for i, r in enumerate(vals):
+            print(f"Probe Point {i}: Velocity: ({r[3]}, {r[4]}, {r[5]}) | Pressure: {r[6]}")
+        return
     for i, point in enumerate(probe_points):
         x = [float(c) for c in np.asarray(point).tolist()]
         u_eval = peval(v, x)
@@ -48,6 +74,11 @@ def print_probe_points(v, p, probe_points) -> None:
 
 def print_solid_probe_points(d, probe_points) -> None:
     d.set_allow_extrapolation(False)
+    vals, _ = _device_probe(d, probe_points)
+    if vals is not None:
+        for i, r in enumerate(vals):
+            print(f"Probe Point {i}: Displacement: {float(r[0]), float(r[1]), float(r[2])}")
+        return
     for i, point in enumerate(probe_points):
         d_eval = peval(d, [float(c) for c in np.asarray(point).tolist()])
         print(f"Probe Point {i}: Displacement: {float(d_eval[0]), float(d_eval[1]), float(d_eval[2])}")
@@ -92,9 +123,13 @@ def inlet_flux(mesh: FsiMesh, v_nodal: np.ndarray, dsi) -> float:
 
 
 def calculate_and_print_flow_properties(dt, mesh, v, inlet_area, mu_f, rho_f, n, dsi, local_rhs=False) -> None:
-    V_vector = dg0_velocity_magnitude(mesh, v.nodal)
     flow_rate_inlet = abs(inlet_flux(mesh, v.nodal, dsi))
-    v_mean, v_min, v_max = V_vector.mean(), V_vector.min(), V_vector.max()
+    backend = getattr(v, "backend", None)
+    if backend is not None and hasattr(backend, "flow_stats"):      # DG0 projection of |v| on the device (fsi_flow_stats)
+        v_mean, v_min, v_max, _ = backend.flow_stats()
+    else:
+        V_vector = dg0_velocity_magnitude(mesh, v.nodal)
+        v_mean, v_min, v_max = V_vector.mean(), V_vector.min(), V_vector.max()
     h_min = mesh.hmin()
     diam_inlet = np.sqrt(4 * inlet_area / np.pi)
     Re_mean, Re_min, Re_max = (rho_f * vv * diam_inlet / mu_f for vv in (v_mean, v_min, v_max))
@@ -108,7 +143,11 @@ def calculate_and_print_flow_properties(dt, mesh, v, inlet_area, mu_f, rho_f, n,
 
 
 def compute_minimum_jacobian(mesh, d, local_rhs=False) -> float:
-    min_jacobian = float(np.min(dg0_jacobian(mesh, d.nodal)))
+    backend = getattr(d, "backend", None)
+    if backend is not None and hasattr(backend, "flow_stats"):
+        min_jacobian = float(backend.flow_stats()[3])
+    else:
+        min_jacobian = float(np.min(dg0_jacobian(mesh, d.nodal)))
     print(f"Minimum Jacobian: {min_jacobian}")
     if min_jacobian <= 0:
         print("Warning: Negative Jacobian detected.")
