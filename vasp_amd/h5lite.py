@@ -370,9 +370,7 @@ class _Writer:
         # symbol nodes (<= 2*LEAF_K entries each)
         cap = 2 * self.LEAF_K
         chunks = [names[i:i + cap] for i in range(0, len(names), cap)] or [[]]
-        if len(chunks) > 2 * self.INTERNAL_K:
-            raise H5Error("too many group members for a single-level B-tree")
-        snods = []
+        entries = []                      # (address, heap offset of the largest name below it)
         for ch in chunks:
             pos = self._alloc(8 + 40 * cap)
             body = b"SNOD" + struct.pack("<BxH", 1, len(ch))
@@ -383,16 +381,30 @@ class _Writer:
                 else:
                     body += struct.pack("<QQII16x", name_off[n], child_addr[n], 0, 0)
             self._put(pos, body)
-            snods.append((pos, ch))
-        # B-tree leaf-level node
-        bt = self._alloc(24 + (2 * self.INTERNAL_K + 1) * 8 + 2 * self.INTERNAL_K * 8)
-        body = b"TREE" + struct.pack("<BBHQQ", 0, 0, len(snods) if names else 0, UNDEF, UNDEF)
-        body += struct.pack("<Q", 0)
-        for pos, ch in snods:
-            if not ch:
-                continue
-            body += struct.pack("<QQ", pos, name_off[ch[-1]])
-        self._put(bt, body)
+            if ch:
+                entries.append((pos, name_off[ch[-1]]))
+        # B-tree over the symbol nodes: as many levels as needed (<= 2*INTERNAL_K children per node)
+        fan = 2 * self.INTERNAL_K
+        node_size = 24 + (fan + 1) * 8 + fan * 8
+        level = 0
+        while True:
+            groups = [entries[i:i + fan] for i in range(0, len(entries), fan)] or [[]]
+            addrs = [self._alloc(node_size) for _ in groups]
+            nxt, left_key = [], 0
+            for j, grp in enumerate(groups):
+                left = addrs[j - 1] if j > 0 else UNDEF
+                right = addrs[j + 1] if j + 1 < len(groups) else UNDEF
+                body = b"TREE" + struct.pack("<BBHQQ", 0, level, len(grp), left, right) + struct.pack("<Q", left_key)
+                for addr, key in grp:
+                    body += struct.pack("<QQ", addr, key)
+                self._put(addrs[j], body)
+                if grp:
+                    left_key = grp[-1][1]
+                    nxt.append((addrs[j], left_key))
+            if len(groups) == 1:
+                bt = addrs[0]
+                break
+            entries, level = nxt, level + 1
         g._bt_heap = (bt, heap_addr)
         msgs = [_message(0x0011, struct.pack("<QQ", bt, heap_addr))]
         for k, v in g.attrs.items():

@@ -277,10 +277,14 @@ def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_ba
         ns.update(upd or {})
         if ns.get("checkpoint_step") and ns["counter"] % int(ns["checkpoint_step"]) == 0:
             checkpoint(ns["checkpoint_folder"], mesh, state["n"], ns["default_variables"], t, ns["counter"])
+            if viz is not None:
+                viz.flush()
         if viz is not None and ns["counter"] % int(ns["save_step"]) == 0:
             viz.write(state["n"], t)
         ns["counter"] += 1
         out("Solved for timestep %d, t = %.4f in %.1f s" % (ns["counter"], t, _time.perf_counter() - t0))
+    if viz is not None:
+        viz.flush()
     ns["time_loop_seconds"] = _time.perf_counter() - t_loop
     ns["newton_iterations"] = total_newton
     hook("finished")(**ns)

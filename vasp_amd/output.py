@@ -56,6 +56,8 @@ class VisualizationWriter:
             self.topology = mesh.tets.astype(np.int64)
         self.frames = {name: [] for name, _, _ in FIELDS}
         self.times = []
+        self.flush_every = 20       # the libhdf5-free writer emits whole files: do it every few frames, and at the end
+        self._dirty = False
 
     def write(self, state: np.ndarray, t: float) -> None:
         d, v, p = self.mesh.split(state)
@@ -69,7 +71,15 @@ class VisualizationWriter:
         self.times.append(float(t))
         for (name, _, att), val in zip(FIELDS, vals):
             self.frames[name].append(np.ascontiguousarray(val, dtype=np.float64).reshape(N, -1).copy())
-            self._flush(name, att)
+        self._dirty = True
+        if len(self.times) <= 3 or len(self.times) % self.flush_every == 0:
+            self.flush()
+
+    def flush(self) -> None:
+        if self._dirty:
+            for name, _, att in FIELDS:
+                self._flush(name, att)
+            self._dirty = False
 
     def _flush(self, name: str, att: str) -> None:
         root, meshg, zero, inner = Group(), Group(), Group(), Group()
