@@ -146,15 +146,23 @@ def main():
         sweeps = tm["inner_vv_iters"] * (ns_cheb[0] / max(1, ns_cheb[0] + ns_cheb[1]))     # solid-block SpMV launches
         ss_avg = tm["solid_spmv_ms"] / max(1, tm["solid_spmv_calls"])
         db_avg = tm["db_spmv_ms"] / max(1, tm["db_spmv_calls"])
+        scalar, tiled = bool(tm["disp_scalar"] & 1), bool(tm["disp_scalar"] & 2)
         f_launches = tm["inner_vv_iters"] * (ns_cheb[1] / max(1, ns_cheb[0] + ns_cheb[1]))
-        db_launches = f_launches + (0 if tm["disp_scalar"] else tm["inner_dd_iters"])
+        db_launches = f_launches + (0 if scalar else tm["inner_dd_iters"])
         sc_avg = tm["sc_spmv_ms"] / max(1, tm["sc_spmv_calls"])
-        sc_launches = tm["inner_dd_iters"] if tm["disp_scalar"] else 0
+        sc_launches = tm["inner_dd_iters"] if scalar else 0
+        # per launch: values (+ 2-byte LDS index or 4-byte column) per pair, the vector once (tiled: once per tile
+        # entry, 16 B + 4 B index), row pointers, flags and the float4 result per node
+        sc_bytes = (tm["db_pairs"] * 6.0 + tm["tile_entries"] * 20.0 + tm["db_nodes"] * 27.0) if tiled else \
+                   (tm["db_pairs"] * 8.0 + tm["db_nodes"] * 43.0)
+        dbf_bytes = (tm["db_pairs"] * 14.0 + tm["tile_entries"] * 20.0 + tm["db_nodes"] * 24.0) if tiled else \
+                    (tm["db_pairs"] * 16.0 + tm["db_nodes"] * 40.0)
         kernels = {
-            "k_spmv_sc_f32 (displacement block sweeps: one FP32 ratio per node pair, float4 vectors; avg from sampled HIP events)":
-                (sc_avg * sc_launches, int(sc_launches), tm["db_pairs"] * 8.0 + tm["db_nodes"] * 43.0),
-            "k_spmv_db_f32 (fluid velocity block sweeps, FP32 component-diagonal node blocks; avg from sampled HIP events)":
-                (db_avg * db_launches, int(db_launches), tm["db_pairs"] * 16.0 + tm["db_nodes"] * 40.0),
+            ("k_spmv_tiled_f32<1>" if tiled else "k_spmv_sc_f32") + " (displacement block sweeps: one FP32 ratio per node pair"
+            + (", neighbour vector entries staged in LDS" if tiled else "") + "; avg from sampled HIP events)":
+                (sc_avg * sc_launches, int(sc_launches), sc_bytes),
+            ("k_spmv_tiled_f32<3>" if tiled else "k_spmv_db_f32") + " (fluid velocity block sweeps, FP32 component-diagonal node blocks; avg from sampled HIP events)":
+                (db_avg * db_launches, int(db_launches), dbf_bytes),
             # (time attributed in the timed region [ms], launches, algorithmic bytes per launch, avg launch [ms])
             ("k_spmv_sb (solid velocity block, FP32 3x3 block-CSR, Chebyshev sweeps; avg from sampled HIP events)"
              if solid_fp32 else "k_spmv<1> (solid velocity block, CSR f64, Chebyshev sweeps; avg from sampled HIP events)"):

@@ -166,7 +166,8 @@ typedef struct FsiTimers {
   double db_spmv_ms;     int64_t db_spmv_calls;      /* sampled launches of the FP32 component-diagonal SpMV          */
   int64_t db_pairs;      int64_t db_nodes;           /* node pairs / nodes of that structure                          */
   double sc_spmv_ms;     int64_t sc_spmv_calls;      /* sampled launches of the scalar-ratio displacement SpMV        */
-  int64_t disp_scalar;                               /* 1 if the displacement sweeps use that kernel                  */
+  int64_t disp_scalar;                               /* bit 0: displacement sweeps use that kernel; bit 1: LDS-tiled  */
+  int64_t tile_entries;                              /* total length of the per-tile distinct-neighbour lists         */
 } FsiTimers;
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
 

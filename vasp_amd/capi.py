@@ -59,7 +59,7 @@ class FsiTimers(C.Structure):
                 ("precond_applies", C.c_int64), ("solid_spmv_ms", C.c_double), ("solid_spmv_calls", C.c_int64),
                 ("solid_nnz", C.c_int64), ("solid_rows", C.c_int64), ("db_spmv_ms", C.c_double),
                 ("db_spmv_calls", C.c_int64), ("db_pairs", C.c_int64), ("db_nodes", C.c_int64),
-                ("sc_spmv_ms", C.c_double), ("sc_spmv_calls", C.c_int64), ("disp_scalar", C.c_int64)]
+                ("sc_spmv_ms", C.c_double), ("sc_spmv_calls", C.c_int64), ("disp_scalar", C.c_int64), ("tile_entries", C.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -510,6 +510,60 @@ __global__ __launch_bounds__(256) void k_spmv_sc_f32(int64_t N2, const int64_t* 
   }
 }
 
+// ---- LDS-tiled variants: a workgroup owns TILE_NODES consecutive nodes; the vector entries of all their neighbours
+// (a few thousand distinct nodes in mesh order) are gathered ONCE into LDS, the node-pair loop then reads 16-byte
+// entries from LDS through 2-byte local indices.  HBM per pair: value(s) + 2 B instead of value(s) + 4 B + a 16-B
+// gather that the L1/L2 have to serve.
+static constexpr int TILE_NODES = 256;
+static constexpr int TILE_LIMIT = 4096;          // distinct neighbour nodes per tile (64 KB of LDS as float4)
+template <int NV>     // NV = 1: one ratio per pair (displacement block), NV = 3: component-diagonal values (fluid velocity block)
+__global__ __launch_bounds__(256) void k_spmv_tiled_f32(int64_t N2, const int64_t* __restrict__ nadj_ptr,
+                                                        const float* __restrict__ vals, const uint16_t* __restrict__ ploc,
+                                                        const int64_t* __restrict__ tile_uptr, const int32_t* __restrict__ ulist,
+                                                        const uint8_t* __restrict__ rowflag, const float* __restrict__ x,
+                                                        float* __restrict__ y) {
+  extern __shared__ float4 sx[];                 // max over the tiles of their distinct-neighbour count (<= TILE_LIMIT)
+  const int64_t tile = blockIdx.x;
+  const int64_t u0 = tile_uptr[tile], nu = tile_uptr[tile + 1] - u0;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (int64_t i = threadIdx.x; i < nu; i += 256) sx[i] = x4[ulist[u0 + i]];
+  __syncthreads();
+  const int sub = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int64_t r0 = tile * TILE_NODES, r1 = (r0 + TILE_NODES < N2) ? r0 + TILE_NODES : N2;
+  for (int64_t r = r0 + g; r < r1; r += 16) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int64_t e = nadj_ptr[r] + sub; e < nadj_ptr[r + 1]; e += 16) {
+      const float4 xv = sx[ploc[e]];
+      if (NV == 1) { const float c = vals[e]; s0 += c * xv.x; s1 += c * xv.y; s2 += c * xv.z; }
+      else { const float* c = vals + 3 * e; s0 += c[0] * xv.x; s1 += c[1] * xv.y; s2 += c[2] * xv.z; }
+    }
+    for (int off = 8; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
+    }
+    if (sub == 0) {
+      if (rowflag) {
+        const float4 xr = x4[r];
+        reinterpret_cast<float4*>(y)[r] = make_float4(rowflag[3 * r] ? xr.x : s0, rowflag[3 * r + 1] ? xr.y : s1,
+                                                      rowflag[3 * r + 2] ? xr.z : s2, 0.f);
+      } else {
+        reinterpret_cast<float4*>(y)[r] = make_float4(s0, s1, s2, 0.f);
+      }
+    }
+  }
+}
+void launch_spmv_tiled_f32(hipStream_t st, int nv, int64_t N2, int max_nu, const int64_t* nadj_ptr, const float* vals,
+                           const uint16_t* ploc, const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag,
+                           const float* x, float* y) {
+  const unsigned tiles = (unsigned)((N2 + TILE_NODES - 1) / TILE_NODES);
+  const size_t lds = (size_t)max_nu * sizeof(float4);
+  if (nv == 1)
+    hipLaunchKernelGGL(k_spmv_tiled_f32<1>, dim3(tiles), dim3(256), lds, st, N2, nadj_ptr, vals, ploc, tile_uptr, ulist, rowflag, x, y);
+  else
+    hipLaunchKernelGGL(k_spmv_tiled_f32<3>, dim3(tiles), dim3(256), lds, st, N2, nadj_ptr, vals, ploc, tile_uptr, ulist, rowflag, x, y);
+}
+int tile_nodes() { return TILE_NODES; }
+int tile_limit() { return TILE_LIMIT; }
+
 void launch_extract_chat(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
                          float* chat, uint8_t* rowflag, int32_t* flags) {
   hipLaunchKernelGGL(k_extract_chat, dim3(gridn(N2)), dim3(256), 0, st, N2, nadj_ptr, nadj, db, chat, rowflag, flags);

@@ -211,7 +211,10 @@ void cheb_db_f32(FsiCtx* ctx, const float* db, const float* dinv, const double* 
   for (int k = 0; k < its; ++k) {
     const bool timed = k < 4 && ctx->db_ev0[0] && ctx->db_samples_pending < 8;
     if (timed) (void)hipEventRecord(ctx->db_ev0[ctx->db_samples_pending], st);
-    launch_spmv_db_f32(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, db, fd, ft);
+    if (ctx->tiled)
+      launch_spmv_tiled_f32(st, 3, ctx->N2, ctx->tile_max_nu, ctx->nadj_ptr.p, db, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p, nullptr, fd, ft);
+    else
+      launch_spmv_db_f32(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, db, fd, ft);
     if (timed) { (void)hipEventRecord(ctx->db_ev1[ctx->db_samples_pending], st); ctx->db_samples_pending += 1; }
     const double rn = 1.0 / (2.0 * sig - rho);
     launch_cheb_step_f32(st, n, ft, dinv, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
@@ -313,7 +316,11 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
       for (int k = 0; k < ctx->cheb_its_d; ++k) {
         const bool timed = k < 4 && ctx->sc_ev0[0];
         if (timed) (void)hipEventRecord(ctx->sc_ev0[k], st);
-        launch_spmv_sc_f32(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_chat.p, ctx->dd_rowflag.p, fd, ft);
+        if (ctx->tiled)
+          launch_spmv_tiled_f32(st, 1, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_chat.p, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
+                                ctx->dd_rowflag.p, fd, ft);
+        else
+          launch_spmv_sc_f32(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_chat.p, ctx->dd_rowflag.p, fd, ft);
         if (timed) { (void)hipEventRecord(ctx->sc_ev1[k], st); ctx->sc_samples_pending = k + 1; }
         const double rn = 1.0 / (2.0 * sig - rho);
         launch_cheb_step_f32(st, n, ft, ctx->ones32.p, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
@@ -655,6 +662,7 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->sb_ptr.release(); ctx->sb_src.release(); ctx->sb_vals.release(); ctx->sb_dinv.release();
   ctx->dd_db32.release(); ctx->vv_db32.release(); ctx->dd_dinv32.release(); ctx->vvf_dinv32.release();
   ctx->dd_chat.release(); ctx->ones32.release(); ctx->dd_rowflag.release();
+  ctx->tile_ploc.release(); ctx->tile_uptr.release(); ctx->tile_ulist.release();
   for (auto* b : {&ctx->ss_rowptr, &ctx->ss_diagpos, &ctx->ss_src}) b->release();
   for (auto* b : {&ctx->node_solid, &ctx->vrank, &ctx->cols3, &ctx->cols_vp, &ctx->cols_pv, &ctx->cols_pp}) b->release();
   for (auto* b : {&ctx->rowptr3, &ctx->diagpos3, &ctx->rowptr_vp, &ctx->rowptr_pv, &ctx->rowptr_pp, &ctx->diagpos_pp}) b->release();
@@ -740,6 +748,40 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
     if (other[x] != other[y]) return other[x] < other[y];
     return x < y;
   });
+  {   // default numbering: P2 nodes along a Morton (Z-order) curve through their coordinates - spatially compact runs of
+      // consecutive nodes are what the gathers of every SpMV, the element scatters and the LDS tiles live on
+    const char* e = getenv("FSI_ORDER");
+    const bool morton = !(e && (e[0] == 'c' || e[0] == 'C' || e[0] == 'm' || e[0] == 'M'));   // colour / mesh keep `base`
+    if (morton) {
+      double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+      for (int64_t v = 0; v < V; ++v)
+        for (int i = 0; i < 3; ++i) { lo[i] = std::min(lo[i], mesh->coords[3 * v + i]); hi[i] = std::max(hi[i], mesh->coords[3 * v + i]); }
+      double span = 0.0;
+      for (int i = 0; i < 3; ++i) span = std::max(span, hi[i] - lo[i]);
+      if (!(span > 0.0)) span = 1.0;
+      auto spread = [](uint64_t x) {          // 21 bits -> every third bit
+        x &= 0x1fffff;
+        x = (x | x << 32) & 0x1f00000000ffffull;
+        x = (x | x << 16) & 0x1f0000ff0000ffull;
+        x = (x | x << 8) & 0x100f00f00f00f00full;
+        x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+        x = (x | x << 2) & 0x1249249249249249ull;
+        return x;
+      };
+      std::vector<uint64_t> code(N2);
+      for (int64_t nd = 0; nd < N2; ++nd) {
+        uint64_t c = 0;
+        for (int i = 0; i < 3; ++i) {
+          const double x = nd < V ? mesh->coords[3 * nd + i]
+                                  : 0.5 * (mesh->coords[3 * (int64_t)owner[nd] + i] + mesh->coords[3 * (int64_t)other[nd] + i]);
+          const uint64_t q = (uint64_t)std::min(2097151.0, std::max(0.0, (x - lo[i]) / span * 2097151.0));
+          c |= spread(q) << i;
+        }
+        code[nd] = c;
+      }
+      std::sort(base.begin(), base.end(), [&](int32_t a, int32_t b) { return code[a] != code[b] ? code[a] < code[b] : a < b; });
+    }
+  }
   for (int64_t r = 0; r < N2; ++r) base_rank[base[r]] = (int32_t)r;
 
   // ---- node graph (node ids), sorted unique pairs ---------------------------------------------------------------
@@ -1051,6 +1093,34 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
     HIPCHK(ctx->dd_dinv32.alloc(4 * N2));
     HIPCHK(ctx->dd_chat.alloc(nadj_total));
     HIPCHK(ctx->dd_rowflag.alloc(3 * N2));
+    {   // LDS tiles of the node graph: per tile of consecutive nodes the sorted distinct column nodes + local indices
+      const int TN = tile_nodes(), LIM = tile_limit();
+      const int64_t ntiles = (N2 + TN - 1) / TN;
+      std::vector<int64_t> uptr(ntiles + 1, 0);
+      std::vector<int32_t> ulist;
+      std::vector<uint16_t> ploc(nadj_total);
+      std::vector<int32_t> tmpu;
+      bool ok = !getenv("FSI_NO_TILES");
+      for (int64_t t = 0; t < ntiles && ok; ++t) {
+        const int64_t r0 = t * TN, r1 = std::min<int64_t>(N2, r0 + TN);
+        const int64_t e0 = ctx->h_nadj_ptr[r0], e1 = ctx->h_nadj_ptr[r1];
+        tmpu.assign(ctx->h_nadj.begin() + e0, ctx->h_nadj.begin() + e1);
+        std::sort(tmpu.begin(), tmpu.end());
+        tmpu.erase(std::unique(tmpu.begin(), tmpu.end()), tmpu.end());
+        if ((int64_t)tmpu.size() > LIM) { ok = false; break; }
+        ctx->tile_max_nu = std::max<int>(ctx->tile_max_nu, (int)tmpu.size());
+        for (int64_t e = e0; e < e1; ++e)
+          ploc[e] = (uint16_t)(std::lower_bound(tmpu.begin(), tmpu.end(), ctx->h_nadj[e]) - tmpu.begin());
+        ulist.insert(ulist.end(), tmpu.begin(), tmpu.end());
+        uptr[t + 1] = (int64_t)ulist.size();
+      }
+      ctx->tiled = ok;
+      if (ok) {
+        FSICHK(upload(ctx, ctx->tile_uptr, uptr));
+        FSICHK(upload(ctx, ctx->tile_ulist, ulist));
+        FSICHK(upload(ctx, ctx->tile_ploc, ploc));
+      }
+    }
     {
       std::vector<float> ones(4 * N2, 1.0f);
       for (int64_t i = 0; i < N2; ++i) ones[4 * i + 3] = 0.0f;
@@ -1465,7 +1535,7 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
                    ctx->inner_its[0], ctx->inner_its[1], ctx->inner_its[2], ctx->inner_calls,
                    ctx->t_ss.ms, ctx->t_ss.calls, ctx->solid_fp32 ? 9 * ctx->sb_nblocks : (int64_t)ctx->ss_vals.n, 3 * ctx->nS,
                    ctx->t_db.ms, ctx->t_db.calls, (int64_t)ctx->dd_db.n / 3, ctx->N2, ctx->t_sc.ms, ctx->t_sc.calls,
-                   (int64_t)(ctx->dd_is_scalar && ctx->sweeps_fp32)};
+                   (int64_t)(ctx->dd_is_scalar && ctx->sweeps_fp32) + (ctx->tiled ? 2 : 0), (int64_t)ctx->tile_ulist.n};
   if (reset) {
     for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_kry, &ctx->t_ss, &ctx->t_db, &ctx->t_sc}) {
       t->ms = 0.0;

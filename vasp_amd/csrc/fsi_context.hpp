@@ -142,6 +142,11 @@ struct FsiCtx {
   fsi::DevBuf<float> dd_chat, ones32;         // scalar form of the Jacobi-scaled A_dd (one ratio per node pair)
   fsi::DevBuf<uint8_t> dd_rowflag;
   bool dd_is_scalar = false;
+  int tile_max_nu = 0;
+  bool tiled = false;                        // LDS-tiled sweep kernels usable (every tile's neighbour set fits the LDS tile)
+  fsi::DevBuf<uint16_t> tile_ploc;           // [pairs] local index of the pair's column node in its tile's list
+  fsi::DevBuf<int64_t> tile_uptr;            // [tiles+1]
+  fsi::DevBuf<int32_t> tile_ulist;           // distinct neighbour nodes of each tile, ascending
   fsi::SubMat Mdd, Mvv, Ms;                  // A_dd, Avv~, sparsified Schur complement (ILU only)
   fsi::DevBuf<double> blk;                   // work vectors of the block preconditioner
   int64_t nS = 0;                            // solid (incl. interface) nodes; compact velocity block A_SS on them
