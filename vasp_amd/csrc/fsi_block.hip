@@ -522,25 +522,54 @@ __global__ __launch_bounds__(256) void k_spmv_tiled_f32(int64_t N2, const int64_
                                                         const int64_t* __restrict__ tile_uptr, const int32_t* __restrict__ ulist,
                                                         const uint8_t* __restrict__ rowflag, const float* __restrict__ x,
                                                         float* __restrict__ y) {
-  extern __shared__ float4 sx[];                 // max over the tiles of their distinct-neighbour count (<= TILE_LIMIT)
+  extern __shared__ __attribute__((aligned(16))) float4 sx[];   // max over the tiles of their distinct-neighbour count
+  __shared__ __attribute__((aligned(16))) int64_t sptr[TILE_NODES + 2];   // size a multiple of 16 B: keeps the dynamic base aligned
   const int64_t tile = blockIdx.x;
   const int64_t u0 = tile_uptr[tile], nu = tile_uptr[tile + 1] - u0;
   const float4* x4 = reinterpret_cast<const float4*>(x);
+  const int64_t r0 = tile * TILE_NODES;
+  const int nrows = (int)((r0 + TILE_NODES < N2 ? r0 + TILE_NODES : N2) - r0);
   for (int64_t i = threadIdx.x; i < nu; i += 256) sx[i] = x4[ulist[u0 + i]];
+  for (int i = threadIdx.x; i <= nrows; i += 256) sptr[i] = nadj_ptr[r0 + i];
   __syncthreads();
   const int sub = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int64_t r0 = tile * TILE_NODES, r1 = (r0 + TILE_NODES < N2) ? r0 + TILE_NODES : N2;
-  for (int64_t r = r0 + g; r < r1; r += 16) {
+  // the node loop is software-pipelined: the (value, local index) pairs of the group's NEXT node are in flight while
+  // the current node is multiplied and reduced - the loop is bound by load latency, not by bytes
+  float cv[2][NV], nv_[2][NV];
+  int cl[2], nl[2];
+  auto prefetch = [&](int i, float (&v)[2][NV], int (&l)[2]) {
+    const int64_t e0 = sptr[i], e1 = sptr[i + 1];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int64_t e = e0 + sub + 16 * k;
+      const bool in = e < e1;
+      l[k] = in ? (int)ploc[e] : 0;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) v[k][c] = in ? vals[NV * e + c] : 0.f;
+    }
+  };
+  int i = g;
+  if (i < nrows) prefetch(i, cv, cl);
+  while (i < nrows) {
+    const int ni = i + 16;
+    if (ni < nrows) prefetch(ni, nv_, nl);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int64_t e = nadj_ptr[r] + sub; e < nadj_ptr[r + 1]; e += 16) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float4 xv = sx[cl[k]];
+      if (NV == 1) { s0 += cv[k][0] * xv.x; s1 += cv[k][0] * xv.y; s2 += cv[k][0] * xv.z; }
+      else { s0 += cv[k][0] * xv.x; s1 += cv[k][NV > 1 ? 1 : 0] * xv.y; s2 += cv[k][NV > 2 ? 2 : 0] * xv.z; }
+    }
+    for (int64_t e = sptr[i] + sub + 32; e < sptr[i + 1]; e += 16) {      // rows with more than 32 pairs
       const float4 xv = sx[ploc[e]];
       if (NV == 1) { const float c = vals[e]; s0 += c * xv.x; s1 += c * xv.y; s2 += c * xv.z; }
-      else { const float* c = vals + 3 * e; s0 += c[0] * xv.x; s1 += c[1] * xv.y; s2 += c[2] * xv.z; }
+      else { const float* c = vals + NV * e; s0 += c[0] * xv.x; s1 += c[NV > 1 ? 1 : 0] * xv.y; s2 += c[NV > 2 ? 2 : 0] * xv.z; }
     }
     for (int off = 8; off > 0; off >>= 1) {
       s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
     }
     if (sub == 0) {
+      const int64_t r = r0 + i;
       if (rowflag) {
         const float4 xr = x4[r];
         reinterpret_cast<float4*>(y)[r] = make_float4(rowflag[3 * r] ? xr.x : s0, rowflag[3 * r + 1] ? xr.y : s1,
@@ -549,6 +578,13 @@ __global__ __launch_bounds__(256) void k_spmv_tiled_f32(int64_t N2, const int64_
         reinterpret_cast<float4*>(y)[r] = make_float4(s0, s1, s2, 0.f);
       }
     }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      cl[k] = nl[k];
+#pragma unroll
+      for (int c = 0; c < NV; ++c) cv[k][c] = nv_[k][c];
+    }
+    i = ni;
   }
 }
 void launch_spmv_tiled_f32(hipStream_t st, int nv, int64_t N2, int max_nu, const int64_t* nadj_ptr, const float* vals,
