@@ -714,6 +714,82 @@ __global__ void k_gather3_f32(int64_t nS, const int32_t* __restrict__ snode, con
 __global__ void k_scatter3_f32(int64_t nS, const int32_t* __restrict__ snode, const float* __restrict__ comp4, double* __restrict__ full) {
   GS(t, 3 * nS) full[3 * (int64_t)snode[t / 3] + t % 3] = (double)comp4[4 * (t / 3) + t % 3];
 }
+// ---- 3x3 node-block Jacobi scaling for the solid sweeps: D_b^-1 per solid node (elasticity couples the components
+// of a node as strongly as neighbouring nodes; scaling by the block roughly sixths the condition number) ---------------
+__global__ void k_sb_binv(int64_t nS, const int32_t* __restrict__ snode, const int64_t* __restrict__ diagpos3,
+                          const double* __restrict__ Avv, float* __restrict__ binv12, double* __restrict__ binv9) {
+  GS(i, nS) {
+    const int64_t r = snode[i];
+    double a[3][3];
+    for (int c = 0; c < 3; ++c) {
+      const double* row = Avv + (diagpos3[3 * r + c] - c);       // start of the diagonal 3x3 block in row c
+      for (int j = 0; j < 3; ++j) a[c][j] = row[j];
+    }
+    const double c00 = a[1][1] * a[2][2] - a[1][2] * a[2][1], c01 = a[0][2] * a[2][1] - a[0][1] * a[2][2],
+                 c02 = a[0][1] * a[1][2] - a[0][2] * a[1][1], c10 = a[1][2] * a[2][0] - a[1][0] * a[2][2],
+                 c11 = a[0][0] * a[2][2] - a[0][2] * a[2][0], c12 = a[0][2] * a[1][0] - a[0][0] * a[1][2],
+                 c20 = a[1][0] * a[2][1] - a[1][1] * a[2][0], c21 = a[0][1] * a[2][0] - a[0][0] * a[2][1],
+                 c22 = a[0][0] * a[1][1] - a[0][1] * a[1][0];
+    const double det = a[0][0] * c00 + a[0][1] * c10 + a[0][2] * c20;
+    const double q = 1.0 / det;
+    const double inv[3][3] = {{c00 * q, c01 * q, c02 * q}, {c10 * q, c11 * q, c12 * q}, {c20 * q, c21 * q, c22 * q}};
+    for (int c = 0; c < 3; ++c) {
+      for (int j = 0; j < 3; ++j) { binv9[9 * i + 3 * c + j] = inv[c][j]; binv12[12 * i + 4 * c + j] = (float)inv[c][j]; }
+      binv12[12 * i + 4 * c + 3] = 0.f;
+    }
+  }
+}
+__global__ void k_block_scale_d(int64_t nS, const double* __restrict__ binv9, double* __restrict__ y) {
+  GS(i, nS) {
+    const double* b = binv9 + 9 * i;
+    const double y0 = y[3 * i], y1 = y[3 * i + 1], y2 = y[3 * i + 2];
+    y[3 * i] = b[0] * y0 + b[1] * y1 + b[2] * y2;
+    y[3 * i + 1] = b[3] * y0 + b[4] * y1 + b[5] * y2;
+    y[3 * i + 2] = b[6] * y0 + b[7] * y1 + b[8] * y2;
+  }
+}
+__device__ inline float4 bmul(const float* __restrict__ b12, float4 v) {
+  const float4 r0 = reinterpret_cast<const float4*>(b12)[0], r1 = reinterpret_cast<const float4*>(b12)[1],
+               r2 = reinterpret_cast<const float4*>(b12)[2];
+  return make_float4(r0.x * v.x + r0.y * v.y + r0.z * v.z, r1.x * v.x + r1.y * v.y + r1.z * v.z,
+                     r2.x * v.x + r2.y * v.y + r2.z * v.z, 0.f);
+}
+__global__ void k_cheb_init_b3(int64_t nS, const float* __restrict__ rhs, const float* __restrict__ binv12, float inv_theta,
+                               float* __restrict__ x, float* __restrict__ r, float* __restrict__ d) {
+  GS(i, nS) {
+    const float4 ri = reinterpret_cast<const float4*>(rhs)[i];
+    const float4 z = bmul(binv12 + 12 * i, ri);
+    reinterpret_cast<float4*>(x)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(r)[i] = ri;
+    reinterpret_cast<float4*>(d)[i] = make_float4(z.x * inv_theta, z.y * inv_theta, z.z * inv_theta, 0.f);
+  }
+}
+__global__ void k_cheb_step_b3(int64_t nS, const float* __restrict__ t, const float* __restrict__ binv12, float c1, float c2,
+                               float* __restrict__ x, float* __restrict__ r, float* __restrict__ d) {
+  GS(i, nS) {
+    const float4 di = reinterpret_cast<float4*>(d)[i], ti = reinterpret_cast<const float4*>(t)[i];
+    float4 ri = reinterpret_cast<float4*>(r)[i], xi = reinterpret_cast<float4*>(x)[i];
+    ri.x -= ti.x; ri.y -= ti.y; ri.z -= ti.z;
+    xi.x += di.x; xi.y += di.y; xi.z += di.z;
+    const float4 z = bmul(binv12 + 12 * i, ri);
+    reinterpret_cast<float4*>(x)[i] = xi;
+    reinterpret_cast<float4*>(r)[i] = ri;
+    reinterpret_cast<float4*>(d)[i] = make_float4(c1 * di.x + c2 * z.x, c1 * di.y + c2 * z.y, c1 * di.z + c2 * z.z, 0.f);
+  }
+}
+void launch_sb_binv(hipStream_t st, int64_t nS, const int32_t* snode, const int64_t* diagpos3, const double* Avv,
+                    float* binv12, double* binv9) {
+  hipLaunchKernelGGL(k_sb_binv, dim3(gridn(nS)), dim3(256), 0, st, nS, snode, diagpos3, Avv, binv12, binv9);
+}
+void launch_block_scale_d(hipStream_t st, int64_t nS, const double* binv9, double* y) {
+  hipLaunchKernelGGL(k_block_scale_d, dim3(gridn(nS)), dim3(256), 0, st, nS, binv9, y);
+}
+void launch_cheb_init_b3(hipStream_t st, int64_t nS, const float* rhs, const float* binv12, float inv_theta, float* x, float* r, float* d) {
+  hipLaunchKernelGGL(k_cheb_init_b3, dim3(gridn(nS)), dim3(256), 0, st, nS, rhs, binv12, inv_theta, x, r, d);
+}
+void launch_cheb_step_b3(hipStream_t st, int64_t nS, const float* t, const float* binv12, float c1, float c2, float* x, float* r, float* d) {
+  hipLaunchKernelGGL(k_cheb_step_b3, dim3(gridn(nS)), dim3(256), 0, st, nS, t, binv12, c1, c2, x, r, d);
+}
 void launch_sb_gather(hipStream_t st, int64_t nb, const int32_t* sb_row, const int64_t* sb_src, const int32_t* sb_stride,
                       const double* Avv, float* vals) {
   hipLaunchKernelGGL(k_sb_gather, dim3(gridn(nb)), dim3(256), 0, st, nb, sb_row, sb_src, sb_stride, Avv, vals);

@@ -243,14 +243,17 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
       launch_gather3_f32(st, ctx->nS, ctx->snode.p, rv, frhs);
       const double lmax = ctx->lmax_s, lmin = lmax / ctx->cheb_kappa_s, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
       double rho = 1.0 / sig;
-      launch_cheb_init_f32(st, n, frhs, ctx->sb_dinv.p, (float)(1.0 / th), fx, fr, fd);
+      const bool bj = ctx->solid_block_jacobi != 0;
+      if (bj) launch_cheb_init_b3(st, ctx->nS, frhs, ctx->sb_binv12.p, (float)(1.0 / th), fx, fr, fd);
+      else launch_cheb_init_f32(st, n, frhs, ctx->sb_dinv.p, (float)(1.0 / th), fx, fr, fd);
       for (int k = 0; k < ctx->cheb_its_s; ++k) {
         const bool timed = k < 8 && ctx->ss_ev0[0];
         if (timed) (void)hipEventRecord(ctx->ss_ev0[k], st);
         launch_spmv_sb(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_col.p, ctx->sb_vals.p, fd, ft);
         if (timed) (void)hipEventRecord(ctx->ss_ev1[k], st);
         const double rn = 1.0 / (2.0 * sig - rho);
-        launch_cheb_step_f32(st, n, ft, ctx->sb_dinv.p, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
+        if (bj) launch_cheb_step_b3(st, ctx->nS, ft, ctx->sb_binv12.p, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
+        else launch_cheb_step_f32(st, n, ft, ctx->sb_dinv.p, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
         rho = rn;
       }
       ctx->ss_samples_pending = ctx->ss_ev0[0] ? std::min(8, ctx->cheb_its_s) : 0;
@@ -561,7 +564,26 @@ int refresh_preconditioner(FsiCtx* ctx) {
     launch_gather_vals(st, (int64_t)ctx->ss_vals.n, ctx->ss_src.p, ctx->Mvv.vals.p, ctx->ss_vals.p);
     launch_sb_gather(st, ctx->sb_nblocks, ctx->sb_row.p, ctx->sb_src.p, ctx->sb_stride.p, ctx->Mvv.vals.p, ctx->sb_vals.p);
     launch_sb_dinv(st, ctx->nS, ctx->snode.p, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->sb_dinv.p);
-    FSICHK(power_lmax(ctx, ss_ref(ctx), nullptr, ctx->blk.p, &ctx->lmax_s));
+    launch_sb_binv(st, ctx->nS, ctx->snode.p, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->sb_binv12.p, ctx->sb_binv9.p);
+    if (ctx->solid_block_jacobi && ctx->solid_fp32) {      // largest eigenvalue of D_b^-1 A_SS (power iteration, as power_lmax_op)
+      const CsrRef M = ss_ref(ctx);
+      double *x = ctx->blk.p, *y = ctx->blk.p + M.n, lam = 1.0;
+      launch_mask_ripple(st, M.n, nullptr, x);
+      for (int k = 0; k < 40; ++k) {
+        launch_spmv(st, M.n, M.rowptr, M.cols, M.vals, x, y, SPMV_SOLID_BLOCK);
+        launch_block_scale_d(st, ctx->nS, ctx->sb_binv9.p, y);
+        double xx = 0.0, yy = 0.0;
+        FSICHK(dot_n(ctx, x, x, M.n, &xx));
+        FSICHK(dot_n(ctx, y, y, M.n, &yy));
+        if (!(xx > 0.0) || !(yy > 0.0) || !std::isfinite(yy)) break;
+        lam = std::sqrt(yy / xx);
+        launch_copy(st, x, y, M.n);
+        launch_scale(st, x, 1.0 / std::sqrt(yy), M.n);
+      }
+      ctx->lmax_s = 1.2 * lam;
+    } else {
+      FSICHK(power_lmax(ctx, ss_ref(ctx), nullptr, ctx->blk.p, &ctx->lmax_s));
+    }
     FSICHK(power_lmax_op(ctx, 3 * ctx->N2, [&](const double* in, double* o) { launch_spmv_db(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->vv_db.p, in, o); },
                          ctx->Mvv.vals.p, ctx->diagpos3.p, ctx->mask_f.p, ctx->blk.p, &ctx->lmax_f));
     FSICHK(power_lmax(ctx, CsrRef{3 * ctx->N2, ctx->rowptr3.p, ctx->cols3.p, ctx->Mdd.vals.p, ctx->diagpos3.p}, nullptr,
@@ -660,6 +682,7 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->s_rowptr.release(); ctx->s_diagpos.release(); ctx->s_cols.release();
   for (auto* b : {&ctx->snode, &ctx->ss_cols, &ctx->sb_col, &ctx->sb_row, &ctx->sb_stride}) b->release();
   ctx->sb_ptr.release(); ctx->sb_src.release(); ctx->sb_vals.release(); ctx->sb_dinv.release();
+  ctx->sb_binv12.release(); ctx->sb_binv9.release();
   ctx->dd_db32.release(); ctx->vv_db32.release(); ctx->dd_dinv32.release(); ctx->vvf_dinv32.release();
   ctx->dd_chat.release(); ctx->ones32.release(); ctx->dd_rowflag.release();
   ctx->tile_ploc.release(); ctx->tile_uptr.release(); ctx->tile_ulist.release();
@@ -1030,6 +1053,9 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
         FSICHK(upload(ctx, ctx->sb_stride, sb_stride));
         HIPCHK(ctx->sb_vals.alloc(9 * sb_col.size()));
         HIPCHK(ctx->sb_dinv.alloc(4 * nS));
+        HIPCHK(ctx->sb_binv12.alloc(12 * nS));
+        HIPCHK(ctx->sb_binv9.alloc(9 * nS));
+        if (const char* e = getenv("FSI_SOLID_BJ")) ctx->solid_block_jacobi = atoi(e);
         if (const char* e = getenv("FSI_SOLID_FP32")) ctx->solid_fp32 = atoi(e);
       }
       FSICHK(upload(ctx, ctx->snode, snode));

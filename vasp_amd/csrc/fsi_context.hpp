@@ -158,6 +158,9 @@ struct FsiCtx {
   fsi::DevBuf<int32_t> sb_col, sb_row, sb_stride;
   fsi::DevBuf<float> sb_vals, sb_dinv;
   int solid_fp32 = 1;
+  int solid_block_jacobi = 1;                // 3x3 node-block scaling of the solid sweeps (FSI_SOLID_BJ=0: point Jacobi)
+  fsi::DevBuf<float> sb_binv12;
+  fsi::DevBuf<double> sb_binv9;
   fsi::DevBuf<double> mask_s, mask_f;        // [3 N2] 1 on velocity dofs of solid (incl. interface) / fluid-interior nodes
   int cheb_its_s = 300, cheb_its_f = 20, cheb_its_p = 40, cheb_its_d = 60;     // Chebyshev sweeps on the solid / fluid part of the velocity block
   double cheb_kappa_s = 1e4, cheb_kappa_f = 100.0, cheb_kappa_p = 100.0, lmax_s = 1.0, lmax_f = 1.0, lmax_p = 1.0, cheb_kappa_d = 1000.0, lmax_d = 1.0;

@@ -119,6 +119,11 @@ void launch_to_f32(hipStream_t st, int64_t n, const double* a, float* b);
 void launch_pad_to_f32(hipStream_t st, int64_t nn, const double* a, const float* scale4, float* b);
 void launch_unpad_from_f32(hipStream_t st, int64_t nn, const float* a, double* b);
 void launch_dinv_f32(hipStream_t st, int64_t n, const double* mask, const int64_t* diagpos, const double* A, float* dinv);
+void launch_sb_binv(hipStream_t st, int64_t nS, const int32_t* snode, const int64_t* diagpos3, const double* Avv,
+                    float* binv12, double* binv9);
+void launch_block_scale_d(hipStream_t st, int64_t nS, const double* binv9, double* y);
+void launch_cheb_init_b3(hipStream_t st, int64_t nS, const float* rhs, const float* binv12, float inv_theta, float* x, float* r, float* d);
+void launch_cheb_step_b3(hipStream_t st, int64_t nS, const float* t, const float* binv12, float c1, float c2, float* x, float* r, float* d);
 void launch_sb_gather(hipStream_t st, int64_t nb, const int32_t* sb_row, const int64_t* sb_src, const int32_t* sb_stride,
                       const double* Avv, float* vals);
 void launch_sb_dinv(hipStream_t st, int64_t nS, const int32_t* snode, const int64_t* diagpos3, const double* Avv, float* dinv);
