@@ -127,6 +127,30 @@ int fsi_newton_solve(FsiCtx* ctx, const FsiNewtonOpts* opts, FsiNewtonIter* iter
 /* dvp_["n-1"] <- dvp_["n"] (the reference's vector shift after each step). */
 int fsi_shift(FsiCtx* ctx);
 
+/* ---- element partition across GPUs (one context per GPU) --------------------------------- */
+/* Replaces: the MPI-parallel dolfin path of `mpirun -np N turtleFSI ...` (ghost updates of PETSc vectors,
+ * MPI sums inside the Krylov solver and in norm(); the reference's own MPI use at this boundary:
+ * src/vasp/simulations/simulation_common.py:213-220).  The context holds the cells that touch a node it owns
+ * (owned cells first in FsiMeshDesc, then the ghost layer); rows of nodes owned elsewhere ("ghost" dofs) are
+ * carried as identity rows and are refreshed from their owner once per Krylov iteration.  The library packs
+ * `send_dofs` into `sendbuf_dev`, calls `halo_exchange` and unpacks `recvbuf_dev` into `ghost_dofs`; both buffers
+ * are device memory owned by the caller (length n_send / n_ghost doubles), the callbacks are the caller's transport
+ * (RCCL through torch.distributed in vasp_amd/partition.py).  Callbacks return 0 on success. */
+typedef struct FsiComm {
+  void* user;
+  int (*allreduce_sum)(void* user, double* host_vals, int32_t n);   /* in place, over all ranks                   */
+  int (*halo_exchange)(void* user);                                 /* sendbuf_dev -> the peers' recvbuf_dev       */
+} FsiComm;
+/* dofs are user-layout dofs of this context.  num_owned_cells: cells [0, num_owned_cells) are counted in the
+ * L2(Omega) norm of the Newton update by this rank.  ghost_dofs: every dof owned elsewhere (refreshed by the halo
+ * exchange, zero in residual-type vectors); identity_dofs: the subset whose rows are incomplete here (the outermost
+ * node layer).  With overlap layers (ghost rows that are complete) the preconditioner is restricted additive Schwarz:
+ * the residual is refreshed into the overlap before the local solve, the owners' part of the result is kept.
+ * Call before the first Jacobian assembly. */
+int fsi_set_partition(FsiCtx* ctx, int64_t num_owned_cells, int64_t n_ghost, const int64_t* ghost_dofs,
+                      int64_t n_identity, const int64_t* identity_dofs, int64_t n_send, const int64_t* send_dofs,
+                      double* sendbuf_dev, double* recvbuf_dev, const FsiComm* comm);
+
 /* ---- state / introspection (checkpoint, restart, parity dumps) --------------------------------------- */
 /* which: 0 = dvp_["n"], 1 = dvp_["n-1"], 2 = last rhs b, 3 = last update du.  User layout, length ndof. */
 int fsi_get_state(FsiCtx* ctx, int which, double* out);

@@ -1,0 +1,90 @@
+"""Element-partitioned time step on the GPU: two and three ranks share the one card of the test box
+(host-staged gloo transport; on a multi-GPU node the same lists go over RCCL) and must reproduce the single-context
+solution of the same problem - the partition changes the preconditioner, not the linear systems."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+STEPS = 3
+# Newton driven to round-off (6 quasi-Newton iterations with 1e-12 linear solves), so that the comparison is not limited by
+# where the stopping test happens to cut the two runs
+NEWTON = dict(atol=1e-15, rtol=1e-16, max_it=6, lmbda=1.0, recompute=20, recompute_tstep=20)
+
+
+def _time_steps(backend, ns, bc_values, pressure, hook):
+    import contextlib
+    import io
+    hist_all, t = [], 0.0
+    for k in range(STEPS):
+        t += 0.001
+        with contextlib.redirect_stdout(io.StringIO()):
+            ns["t"] = t
+            hook("pre_solve")(**ns)
+        backend.set_dirichlet_values(bc_values())
+        backend.set_interface_pressure(float(pressure.P))
+        hist_all.append(backend.newton_solve(counter=k, first_step_num=0, **NEWTON))
+        backend.shift()
+    return hist_all
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import tempfile
+    import torch.distributed as dist
+    from conftest import prepare_case
+    from vasp_amd.partition import DistBackend
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ns, desc, bc_values, pressure, hook = prepare_case("cylinder", GOLDEN / "cylinder" / "cylinder.h5", tempfile.mkdtemp(),
+                                                        T="0.003")
+    db = DistBackend(desc, dist, device=0, lin_rtol=1e-12)
+    hist = _time_steps(db, ns, bc_values, pressure, hook)
+    x = db.get_state("n")
+    b_norm = db.assemble_residual()                     # residual norm of the final state (an all-reduced sum over owners)
+    if rank == 0:
+        q.put((x, hist, b_norm))
+    dist.barrier()
+    db.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_steps_match_single_context(world, tmp_path):
+    import torch.multiprocessing as mp
+    from conftest import prepare_case
+    from vasp_amd.capi import HipBackend
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    x_part, hist_part, b_part = q.get(timeout=900)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+
+    ns, desc, bc_values, pressure, hook = prepare_case("cylinder", GOLDEN / "cylinder" / "cylinder.h5", tmp_path, T="0.003")
+    hb = HipBackend(desc, device=0, lin_rtol=1e-12)
+    hist_one = _time_steps(hb, ns, bc_values, pressure, hook)
+    x_one = hb.get_state("n")
+    b_one = hb.assemble_residual()
+    hb.close()
+
+    mesh = ns["mesh"]
+    for name, a, b in zip("dvp", mesh.split(x_part), mesh.split(x_one)):
+        assert np.abs(a - b).max() <= 1e-8 * np.abs(b).max(), name       # FP64 tolerance on the converged fields
+    r_part = np.array([it[0] for h in hist_part for it in h])
+    r_one = np.array([it[0] for h in hist_one for it in h])
+    big = r_one > 1e-6 * r_one.max()
+    assert np.allclose(r_part[big], r_one[big], rtol=1e-5)             # the same residual norms (sums over the owners)
+    assert b_part == pytest.approx(b_one, rel=1e-4, abs=1e-10 * r_one.max())
+    print("krylov iterations per Newton iteration:", world, "ranks", [it[3] for h in hist_part for it in h], "single",
+          [it[3] for h in hist_one for it in h])

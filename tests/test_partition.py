@@ -1,0 +1,153 @@
+"""Element partition of the monolithic problem across ranks: ownership, ghost layer, halo lists and the
+oracle-level statement of why the scheme is exact - owned rows assembled from the local cells equal the global rows.
+The N > 1 exchange itself runs here over gloo with two ranks (the same lists drive RCCL on the GPUs)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from vasp_amd.partition import Partition, node_dofs, node_owners
+
+
+@pytest.mark.parametrize("world,overlap", [(2, 0), (3, 1), (5, 2)])
+def test_ownership_and_ghost_layer(stenosis_case, world, overlap):
+    ns, desc, *_ = stenosis_case
+    mesh = ns["mesh"]
+    parts = [Partition(desc, r, world, overlap=overlap) for r in range(world)]
+    owner = parts[0].owner
+    assert np.array_equal(owner, node_owners(mesh.node_coords, world))          # node coordinates rebuilt from tet_nodes
+    counts = np.bincount(owner, minlength=world)
+    assert counts.max() - counts.min() <= 1
+    assert sum(p.num_owned_cells for p in parts) == mesh.num_cells               # every cell counted once in the L2 norm
+    seen = np.zeros(mesh.num_dofs, dtype=int)
+    for p in parts:
+        tn = mesh.tet_nodes
+        touching = (owner[tn] == p.rank).any(axis=1)
+        if overlap == 0:
+            assert np.array_equal(np.sort(p.cells), np.nonzero(touching)[0])      # exactly the cells of the owned nodes
+        else:
+            assert touching[p.cells].sum() == touching.sum() and len(p.cells) > touching.sum()
+        # complete rows: every cell of such a node is local; owned nodes always are
+        n_cells_global = np.bincount(tn.ravel(), minlength=mesh.num_nodes)
+        n_cells_local = np.bincount(tn[p.cells].ravel(), minlength=mesh.num_nodes)
+        comp = p.nodes[p.complete_local]
+        assert np.array_equal(n_cells_local[comp], n_cells_global[comp]) and p.complete_local[p.owned_local].all()
+        assert set(p.identity_dofs) <= set(p.ghost_dofs)
+        assert p.nv == (p.nodes < mesh.num_vertices).sum() and np.all(np.diff(p.nodes) > 0)
+        ld = p.local_desc
+        assert np.array_equal(p.nodes[ld["tet_nodes"]], tn[p.cells])
+        assert np.all(np.diff(ld["tet_nodes"][:, :4], axis=1) > 0)                # vertex part of the rows ascending
+        assert np.allclose(ld["coords"], mesh.coords[p.nodes[:p.nv]])
+        seen[p.owned_global_dofs()] += 1
+        assert np.array_equal(p.l2g_dofs[p.ghost_dofs] >= 0, np.ones(len(p.ghost_dofs), bool))
+        assert not p.owned_dof_mask[p.ghost_dofs].any() and p.owned_dof_mask[p.send_dofs].all()
+        assert len(np.unique(p.ghost_dofs)) == len(p.ghost_dofs) == (~p.owned_dof_mask).sum()
+        for q, nodes in p.send_nodes.items():                                      # what r sends to q is what q expects from r
+            assert np.array_equal(nodes, parts[q].recv_nodes[p.rank])
+            assert p.send_counts[q] == parts[q].recv_counts[p.rank] == len(node_dofs(p.g2l[nodes], p.n2, p.nv))
+        assert len(p.send_nodes) <= (2 if overlap < 2 else 4)                     # slabs: the nearest neighbours only
+    assert np.all(seen == 1)                                                       # every dof has exactly one owner
+
+
+def test_boundary_data_restriction(stenosis_case):
+    ns, desc, bc_values, *_ = stenosis_case
+    g = bc_values()
+    x = np.random.default_rng(0).standard_normal(ns["mesh"].num_dofs)
+    for r in range(3):
+        p = Partition(desc, r, 3)
+        ld = p.local_desc
+        assert np.array_equal(p.l2g_dofs[ld["bc_dofs"]], desc["bc_dofs"][p.bc_sel])
+        inside = p.g2l[_dof_nodes(desc["bc_dofs"], p.N2)] >= 0
+        assert np.array_equal(np.nonzero(inside)[0], p.bc_sel) and len(g[p.bc_sel]) == len(ld["bc_dofs"])
+        assert np.array_equal(p.restrict(x), x[p.l2g_dofs])
+        if "pressure_facets" in ld:
+            assert np.array_equal(p.nodes[ld["pressure_facets"]][:, :3] < p.V, np.ones((len(ld["pressure_facets"]), 3), bool))
+            assert np.array_equal(p.cells[ld["pressure_facet_cell"]],
+                                  np.asarray(desc["pressure_facet_cell"])[_complete(p, desc["pressure_facets"]).any(axis=1)])
+
+
+def _complete(p, global_nodes):
+    """True where a global node is local to p with a completely assembled row (owned, or inside the overlap)."""
+    loc = p.g2l[np.asarray(global_nodes)]
+    return (loc >= 0) & p.complete_local[np.maximum(loc, 0)]
+
+
+def _dof_nodes(dofs, N2):
+    dofs = np.asarray(dofs)
+    return np.where(dofs < 6 * N2, (dofs % (3 * N2)) // 3, dofs - 6 * N2)
+
+
+def test_owned_rows_of_the_local_assembly_are_the_global_rows(cylinder_case):
+    """The exactness argument of the partition, checked with the oracle: residual and Jacobian rows of owned dofs
+    assembled from the local cells alone equal the corresponding rows of the global assembly."""
+    from oracle.fsi_oracle import FsiOracle
+    ns, desc, bc_values, pressure, hook = cylinder_case
+    og = FsiOracle(desc)
+    rng = np.random.default_rng(1)
+    h = ns["mesh"].hmin()
+    U = np.concatenate([0.02 * h * rng.standard_normal(3 * og.N2 if hasattr(og, "N2") else 3 * ns["mesh"].num_nodes),
+                        0.1 * rng.standard_normal(3 * ns["mesh"].num_nodes), rng.standard_normal(ns["mesh"].num_vertices)])
+    U1 = 0.9 * U
+    g = bc_values()
+    bg = og.rhs(U, U1, 3.0, g)
+    og.solver_setup(np.zeros(og.ndof), np.zeros(og.ndof))
+    Ag = og.jacobian(U, U1).tocsr()
+    for r in range(2):
+        p = Partition(desc, r, 2)
+        ol = FsiOracle(p.local_desc)
+        bl = ol.rhs(p.restrict(U), p.restrict(U1), 3.0, g[p.bc_sel])
+        own3 = np.repeat(p.complete_local, 3)
+        own = np.concatenate([own3, own3, p.complete_local[:p.nv]])               # owned rows and the overlap's ghost rows
+        assert own.sum() > p.owned_dof_mask.sum()
+        assert np.abs(bl[own] - bg[p.l2g_dofs][own]).max() <= 1e-12 * np.abs(bg).max()
+        ol.solver_setup(np.zeros(ol.ndof), np.zeros(ol.ndof))
+        Al = ol.jacobian(p.restrict(U), p.restrict(U1)).tocsr()
+        sub = Ag[p.l2g_dofs][:, p.l2g_dofs]
+        rows = np.nonzero(own)[0]
+        assert abs(Al[rows] - sub[rows]).max() <= 1e-10 * abs(Ag).max()
+        # ... and an owned row has no entry outside the local dofs: nothing is missing from the local SpMV
+        assert Ag[p.l2g_dofs[rows]].getnnz() == sub[rows].getnnz()
+
+
+def _halo_worker(rank, world, port, mesh_path, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from conftest import prepare_case
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _, desc, *_ = prepare_case("cylinder", mesh_path, tempfile.mkdtemp())
+    p = Partition(desc, rank, world)
+    x = np.random.default_rng(7).standard_normal(6 * p.N2 + p.V)             # the same global vector on every rank
+    xl = p.restrict(x)
+    xl[~p.owned_dof_mask] = 0.0                                                # ghosts unknown before the exchange
+    send = torch.from_numpy(xl[p.send_dofs])
+    recv = torch.empty(len(p.ghost_dofs), dtype=torch.float64)
+    dist.all_to_all_single(recv, send, p.recv_counts, p.send_counts)
+    xl[p.ghost_dofs] = recv.numpy()
+    err = float(np.abs(xl - p.restrict(x)).max())
+    part = torch.tensor([float(np.dot(xl[p.owned_dof_mask], xl[p.owned_dof_mask]))], dtype=torch.float64)
+    dist.all_reduce(part)                                                      # a dot over owned entries + all-reduce
+    q.put((rank, err, float(part.item()), float(np.dot(x, x))))
+    dist.destroy_process_group()
+
+
+def test_halo_exchange_over_gloo_two_ranks():
+    import torch.multiprocessing as mp
+    from conftest import GOLDEN
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_halo_worker, args=(r, 2, port, GOLDEN / "cylinder" / "cylinder.h5", q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for _, err, dot_all, dot_ref in res:
+        assert err == 0.0                                                      # ghosts now hold their owners' values
+        assert dot_all == pytest.approx(dot_ref, rel=1e-13)

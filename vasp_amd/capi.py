@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "fsi_set_pressure_facets", "fsi_set_interface_pressure", "fsi_set_robin_facets", "fsi_solver_setup",
     "fsi_assemble_residual", "fsi_assemble_jacobian", "fsi_solve", "fsi_newton_solve", "fsi_shift",
     "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_get_matrix", "fsi_spmv",
-    "fsi_get_timers", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats",
+    "fsi_get_timers", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
 )
 
 
@@ -113,6 +113,7 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_probe.argtypes = [vp, i64, vp, vp, vp]
     lib.fsi_flow_stats.argtypes = [vp, vp]
     lib.fsi_set_chebyshev.argtypes = [vp, i32, dbl, i32, dbl, i32, dbl, i32, dbl]
+    lib.fsi_set_partition.argtypes = [vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("fsi_last_error", "fsi_num_dofs", "fsi_matrix_nnz"):

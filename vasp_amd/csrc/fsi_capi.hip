@@ -83,6 +83,53 @@ int norm2(FsiCtx* ctx, const double* x, double* out) {
   return FSI_OK;
 }
 
+// ---- element partition: sums over ranks, owner -> ghost refresh (fsi_set_partition) -----------------------------------
+int allreduce(FsiCtx* ctx, double* v, int n) {
+  if (!ctx->part) return FSI_OK;
+  ctx->allreduce_calls += 1;
+  if (ctx->comm.allreduce_sum(ctx->comm.user, v, n) != 0) { ctx->err = "allreduce callback failed"; return FSI_ERR_DEVICE; }
+  return FSI_OK;
+}
+// dot / norm over all ranks; the operands carry zeros in their ghost entries, so the local sums add up
+int gdot(FsiCtx* ctx, const double* x, const double* y, double* out) {
+  FSICHK(dot(ctx, x, y, out));
+  return allreduce(ctx, out, 1);
+}
+int gnorm2(FsiCtx* ctx, const double* x, double* out) {
+  FSICHK(gdot(ctx, x, x, out));
+  *out = std::sqrt(*out);
+  return FSI_OK;
+}
+int halo_update(FsiCtx* ctx, double* x) {
+  if (!ctx->part) return FSI_OK;
+  ctx->halo_calls += 1;
+  if (ctx->nsend) launch_gather(ctx->stream, ctx->sendbuf, x, ctx->send_idx.p, ctx->nsend);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->comm.halo_exchange(ctx->comm.user) != 0) { ctx->err = "halo_exchange callback failed"; return FSI_ERR_DEVICE; }
+  if (ctx->nghost) launch_scatter(ctx->stream, x, ctx->recvbuf, ctx->ghost_idx.p, ctx->nghost);
+  return FSI_OK;
+}
+void zero_ghost(FsiCtx* ctx, double* x) {
+  if (ctx->part && ctx->nghost) launch_bc_set(ctx->stream, x, ctx->ghost_idx.p, ctx->ghost_zero.p, ctx->nghost);
+}
+// coefficients of launch_multi_dot (device, m doubles) summed over ranks
+int allreduce_hcoef(FsiCtx* ctx, int m) {
+  if (!ctx->part || m <= 0) return FSI_OK;
+  std::vector<double> h(m);
+  HIPCHK(hipMemcpyAsync(h.data(), ctx->hcoef.p, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  FSICHK(allreduce(ctx, h.data(), m));
+  HIPCHK(hipMemcpyAsync(ctx->hcoef.p, h.data(), m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return FSI_OK;
+}
+int rebuild_matrix_bc(FsiCtx* ctx) {
+  std::vector<int32_t> m(ctx->h_bc);
+  m.insert(m.end(), ctx->h_ident.begin(), ctx->h_ident.end());
+  ctx->nmbc = (int64_t)m.size();
+  return upload(ctx, ctx->mbc_dofs, m);
+}
+
 // ---- inner solves of the block preconditioner: BiCGStab on one field block, ILU(0)-preconditioned ----------------------
 // W holds 8 work vectors of length M.n.  Never fails: on breakdown it returns what it has (the outer method is flexible).
 template <class Apply>
@@ -396,7 +443,7 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
   launch_copy(st, r, rhs, n);
   launch_fill(st, x, n, 0.0);
   double bnorm = 0.0, rnorm = 0.0;
-  FSICHK(norm2(ctx, r, &bnorm));
+  FSICHK(gnorm2(ctx, r, &bnorm));
   *iters = 0;
   if (bnorm == 0.0) { *relres = 0.0; return FSI_OK; }
   if (!std::isfinite(bnorm)) { ctx->err = "non-finite right-hand side"; return FSI_ERR_LINEAR; }
@@ -404,30 +451,44 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
   if (m > 0) {   // projection on the recycled space
     Phase ph(ctx, &ctx->t_ortho);
     launch_multi_dot(st, ctx->KQ.p, n, m, r, ctx->scratch.p, ctx->hcoef.p);
+    FSICHK(allreduce_hcoef(ctx, m));
     launch_multi_axpy(st, ctx->KP.p, n, m, ctx->hcoef.p, +1.0, x);
     launch_multi_axpy(st, ctx->KQ.p, n, m, ctx->hcoef.p, -1.0, r);
   }
-  FSICHK(norm2(ctx, r, &rnorm));
+  FSICHK(gnorm2(ctx, r, &rnorm));
   while (rnorm > rtol * bnorm && *iters < max_it) {
-    FSICHK(precondition(ctx, r, z));
+    if (ctx->part && ctx->nident < ctx->nghost) {
+      // restricted additive Schwarz: the local solve sees the residual on its overlap (complete ghost rows), zero on the
+      // outermost layer; below, the owners' part of the result replaces whatever the overlap produced
+      double* rin = ctx->tmp4.p;
+      launch_copy(st, rin, r, n);
+      FSICHK(halo_update(ctx, rin));
+      if (ctx->nident) launch_bc_set(st, rin, ctx->ident_idx.p, ctx->ghost_zero.p, ctx->nident);
+      FSICHK(precondition(ctx, rin, z));
+    } else {
+      FSICHK(precondition(ctx, r, z));
+    }
+    FSICHK(halo_update(ctx, z));      // partitioned: the preconditioner is rank-local (additive Schwarz on the ghost layer)
     FSICHK(spmv(ctx, z, w));
+    zero_ghost(ctx, w);               // ghost rows are identity rows; residual-type vectors carry zeros there
     m = (int)std::min<int64_t>(ctx->kry_m, ctx->kry_cap);
     double wn = 0.0;
     if (m > 0) {
       Phase ph(ctx, &ctx->t_ortho);
       // classical Gram-Schmidt; a second pass only when the first one cancelled most of w (Daniel et al. criterion)
       double w0 = 0.0;
-      FSICHK(norm2(ctx, w, &w0));
+      FSICHK(gnorm2(ctx, w, &w0));
       for (int pass = 0; pass < 2; ++pass) {
         launch_multi_dot(st, ctx->KQ.p, n, m, w, ctx->scratch.p, ctx->hcoef.p);
+        FSICHK(allreduce_hcoef(ctx, m));
         launch_multi_axpy(st, ctx->KQ.p, n, m, ctx->hcoef.p, -1.0, w);
         launch_multi_axpy(st, ctx->KP.p, n, m, ctx->hcoef.p, -1.0, z);
-        FSICHK(norm2(ctx, w, &wn));
+        FSICHK(gnorm2(ctx, w, &wn));
         if (wn > 0.5 * w0) break;
         w0 = wn;
       }
     } else {
-      FSICHK(norm2(ctx, w, &wn));
+      FSICHK(gnorm2(ctx, w, &wn));
     }
     if (!(wn > 0.0) || !std::isfinite(wn)) { ctx->err = "GCR breakdown (A M^-1 r vanished or is not finite)"; return FSI_ERR_LINEAR; }
     launch_scale(st, w, 1.0 / wn, n);
@@ -440,10 +501,11 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
     launch_copy(st, ctx->KQ.p + (int64_t)slot * n, w, n);
     ctx->kry_m += 1;
     double alpha = 0.0;
-    FSICHK(dot(ctx, w, r, &alpha));
+    FSICHK(gdot(ctx, w, r, &alpha));
     launch_axpy(st, x, alpha, z, n);
     launch_axpy(st, r, -alpha, w, n);
-    FSICHK(norm2(ctx, r, &rnorm));
+    FSICHK(gnorm2(ctx, r, &rnorm));
+    if (getenv("FSI_DEBUG_GCR") && (*iters % 10 == 0)) { fprintf(stderr, "[gcr] it %d relres %.3e\n", *iters, rnorm / bnorm); fflush(stderr); }
     *iters += 1;
     ctx->kry_iters += 1;
   }
@@ -674,6 +736,7 @@ int fsi_destroy(FsiCtx* ctx) {
   for (auto* b : i32) b->release();
   DevBuf<int64_t>* i64[] = {&ctx->nadj_ptr, &ctx->padj_ptr, &ctx->rowptr, &ctx->diagpos, &ctx->rb_pos};
   for (auto* b : i64) b->release();
+  ctx->ghost_idx.release(); ctx->ident_idx.release(); ctx->send_idx.release(); ctx->mbc_dofs.release(); ctx->ghost_zero.release();
   ctx->enbr.release();
   ctx->epnbr.release();
   ctx->cellvals.release();
@@ -1223,6 +1286,8 @@ int fsi_set_dirichlet(FsiCtx* ctx, int64_t n, const int64_t* dofs) {
     s[i] = ctx->h_user2solver[dofs[i]];
   }
   ctx->nbc = n;
+  ctx->h_bc = s;
+  FSICHK(rebuild_matrix_bc(ctx));
   FSICHK(upload(ctx, ctx->bc_dofs, s));
   HIPCHK(ctx->bc_vals.alloc(n));
   if (n) HIPCHK(hipMemset(ctx->bc_vals.p, 0, n * sizeof(double)));
@@ -1232,6 +1297,52 @@ int fsi_set_dirichlet(FsiCtx* ctx, int64_t n, const int64_t* dofs) {
 int fsi_set_dirichlet_values(FsiCtx* ctx, int64_t n, const double* values) {
   if (!ctx || n != ctx->nbc || (n > 0 && !values)) { if (ctx) ctx->err = "fsi_set_dirichlet_values: size mismatch"; return FSI_ERR_INVALID; }
   if (n) HIPCHK(hipMemcpy(ctx->bc_vals.p, values, n * sizeof(double), hipMemcpyHostToDevice));
+  return FSI_OK;
+}
+
+int fsi_set_partition(FsiCtx* ctx, int64_t num_owned_cells, int64_t n_ghost, const int64_t* ghost_dofs,
+                      int64_t n_identity, const int64_t* identity_dofs, int64_t n_send, const int64_t* send_dofs,
+                      double* sendbuf_dev, double* recvbuf_dev, const FsiComm* comm) {
+  if (!ctx) return FSI_ERR_INVALID;
+  if (!comm || !comm->allreduce_sum || !comm->halo_exchange || num_owned_cells < 0 || num_owned_cells > ctx->C ||
+      n_ghost < 0 || n_send < 0 || n_identity < 0 || n_identity > n_ghost || (n_ghost > 0 && (!ghost_dofs || !recvbuf_dev)) ||
+      (n_identity > 0 && !identity_dofs) || (n_send > 0 && (!send_dofs || !sendbuf_dev))) {
+    ctx->err = "fsi_set_partition: bad arguments";
+    return FSI_ERR_INVALID;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  std::vector<int32_t> g(n_ghost), idn(n_identity), sd(n_send);
+  std::vector<uint8_t> is_ghost(ctx->ndof, 0);
+  for (int64_t i = 0; i < n_ghost; ++i) {
+    if (ghost_dofs[i] < 0 || ghost_dofs[i] >= ctx->ndof || is_ghost[ghost_dofs[i]]) { ctx->err = "fsi_set_partition: ghost dof out of range or repeated"; return FSI_ERR_INVALID; }
+    is_ghost[ghost_dofs[i]] = 1;
+    g[i] = ctx->h_user2solver[ghost_dofs[i]];
+  }
+  for (int64_t i = 0; i < n_identity; ++i) {
+    if (identity_dofs[i] < 0 || identity_dofs[i] >= ctx->ndof || !is_ghost[identity_dofs[i]]) { ctx->err = "fsi_set_partition: identity dof is not a ghost dof"; return FSI_ERR_INVALID; }
+    idn[i] = ctx->h_user2solver[identity_dofs[i]];
+  }
+  for (int64_t i = 0; i < n_send; ++i) {
+    if (send_dofs[i] < 0 || send_dofs[i] >= ctx->ndof || is_ghost[send_dofs[i]]) { ctx->err = "fsi_set_partition: send dof out of range or not owned"; return FSI_ERR_INVALID; }
+    sd[i] = ctx->h_user2solver[send_dofs[i]];
+  }
+  ctx->h_ident = idn;
+  ctx->nghost = n_ghost;
+  ctx->nident = n_identity;
+  ctx->nsend = n_send;
+  ctx->C_owned = num_owned_cells;
+  FSICHK(upload(ctx, ctx->ghost_idx, g));
+  FSICHK(upload(ctx, ctx->ident_idx, idn));
+  FSICHK(upload(ctx, ctx->send_idx, sd));
+  HIPCHK(ctx->ghost_zero.alloc(n_ghost));
+  if (n_ghost) HIPCHK(hipMemset(ctx->ghost_zero.p, 0, n_ghost * sizeof(double)));
+  FSICHK(rebuild_matrix_bc(ctx));
+  ctx->sendbuf = sendbuf_dev;
+  ctx->recvbuf = recvbuf_dev;
+  ctx->comm = *comm;
+  ctx->part = true;
+  ctx->have_jacobian = false;
+  ctx->kry_m = 0;
   return FSI_OK;
 }
 
@@ -1344,10 +1455,11 @@ int fsi_assemble_residual(FsiCtx* ctx, double* norm) {
                           ctx->scheme.th1, ctx->U.p, ctx->U1.p, ctx->F.p);
     launch_negate(ctx->stream, ctx->b.p, ctx->F.p, ctx->ndof);
     launch_bc_rhs(ctx->stream, ctx->b.p, ctx->U.p, ctx->bc_dofs.p, ctx->bc_vals.p, ctx->nbc);
+    zero_ghost(ctx, ctx->b.p);
     HIPCHK(hipGetLastError());
   }
   double nrm = 0.0;
-  FSICHK(norm2(ctx, ctx->b.p, &nrm));
+  FSICHK(gnorm2(ctx, ctx->b.p, &nrm));
   if (norm) *norm = nrm;
   return FSI_OK;
 }
@@ -1361,8 +1473,8 @@ int fsi_assemble_jacobian(FsiCtx* ctx) {
     launch_jacobian(ctx->stream, PART_NONLINEAR, ctx->C, elem_arrays(ctx), elem_params(ctx), ctx->U.p, ctx->U1.p,
                     ctx->rowptr.p, ctx->nadj_ptr.p, ctx->A.p);
     if (getenv("FSI_DEBUG")) { HIPCHK(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[fsi] jacobian kernel done\n"); fflush(stderr); }
-    launch_matrix_finish(ctx->stream, ctx->ndof, ctx->rowptr.p, ctx->diagpos.p, ctx->A.p, ctx->A_pre.p, ctx->bc_dofs.p,
-                         ctx->nbc, ctx->rowscale.p, ctx->iflags.p + 16);
+    launch_matrix_finish(ctx->stream, ctx->ndof, ctx->rowptr.p, ctx->diagpos.p, ctx->A.p, ctx->A_pre.p, ctx->mbc_dofs.p,
+                         ctx->nmbc, ctx->rowscale.p, ctx->iflags.p + 16);
     HIPCHK(hipGetLastError());
     if (getenv("FSI_DEBUG")) { HIPCHK(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[fsi] matrix finish done\n"); fflush(stderr); }
   }
@@ -1377,6 +1489,7 @@ int fsi_solve(FsiCtx* ctx, double lin_rtol, int32_t lin_max_it, int32_t lin_solv
   if (!ctx->have_jacobian) { ctx->err = "fsi_solve: no Jacobian assembled"; return FSI_ERR_INVALID; }
   if (ctx->precond == 0 && ctx->prec_bad) { ctx->err = "block preconditioner: Chebyshev sweeps diverge on this Jacobian"; return FSI_ERR_LINEAR; }
   HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->part && lin_solver == 1) { ctx->err = "fsi_solve: the partitioned path runs GCR only (lin_solver 0)"; return FSI_ERR_INVALID; }
   launch_mul(ctx->stream, ctx->bs.p, ctx->rowscale.p, ctx->b.p, ctx->ndof);
   int it = 0;
   double rr = 0.0;
@@ -1421,8 +1534,10 @@ int fsi_newton_solve(FsiCtx* ctx, const FsiNewtonOpts* o, FsiNewtonIter* iters, 
     residual = bnorm;
     // "r (rel)": L2(Omega) function norm of the update, as dolfin.norm(Function, 'l2') in the reference's newtonsolver
     HIPCHK(hipMemsetAsync(ctx->scratch.p + 4097, 0, sizeof(double), ctx->stream));
-    launch_l2norm(ctx->stream, ctx->C, elem_arrays(ctx), ctx->du.p, ctx->scratch.p + 4097);
+    if ((ctx->part ? ctx->C_owned : ctx->C) > 0)
+      launch_l2norm(ctx->stream, ctx->part ? ctx->C_owned : ctx->C, elem_arrays(ctx), ctx->du.p, ctx->scratch.p + 4097);
     FSICHK(host_scalar(ctx, ctx->scratch.p + 4097, &rel_res));
+    FSICHK(allreduce(ctx, &rel_res, 1));
     rel_res = std::sqrt(rel_res);
     iters[it] = FsiNewtonIter{residual, rel_res, rec ? 1 : 0, lit, lrr};
     it += 1;

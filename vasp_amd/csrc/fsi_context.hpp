@@ -120,6 +120,18 @@ struct FsiCtx {
   fsi::DevBuf<double> rb_val;
   fsi::DevBuf<int64_t> rb_pos;               // position in the CSR values
 
+  // element partition (fsi_set_partition): ghost rows, halo lists, the caller's transport
+  bool part = false;
+  int64_t C_owned = 0, nghost = 0, nsend = 0;
+  std::vector<int32_t> h_bc, h_ident;        // solver indices
+  int64_t nident = 0;                        // ghost dofs with incomplete rows (outermost layer): identity rows
+  fsi::DevBuf<int32_t> ghost_idx, ident_idx, send_idx, mbc_dofs;   // mbc = Dirichlet + identity rows of the matrix
+  int64_t nmbc = 0;
+  fsi::DevBuf<double> ghost_zero;
+  double *sendbuf = nullptr, *recvbuf = nullptr;
+  FsiComm comm{};
+  int64_t halo_calls = 0, allreduce_calls = 0;
+
   // field blocks for the block preconditioner (fsi_block.hip)
   int precond = 0;                           // 0 = field-split block preconditioner, 1 = monolithic multicolour ILU(0)
   bool have_monolithic_lu = false;

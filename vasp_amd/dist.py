@@ -1,14 +1,14 @@
 """Rank bookkeeping for multi-GPU runs (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm).
 
-This round the time-step kernel runs as independent replicas, one problem per rank: there is no
-data-path collective, only the measurement protocol of bench.py - barrier, max of the per-rank wall time, sum of the
-units of work."""
+The data path of N > 1 (element partition, halo exchange, all-reduces) is vasp_amd/partition.py; this module holds
+the process-group set-up and the measurement protocol of bench.py - barrier, max of the per-rank wall time, sum of
+the units of work."""
 from __future__ import annotations
 
 import os
 
 
-def init_from_env(prefer_gpu: bool = True):
+def init_from_env(prefer_gpu: bool = True, backend=None):
     """(rank, local_rank, world, dist-or-None) from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*."""
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -20,7 +20,8 @@ def init_from_env(prefer_gpu: bool = True):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     if not dist.is_initialized():
-        dist.init_process_group("nccl" if (prefer_gpu and torch.cuda.is_available()) else "gloo", rank=rank, world_size=world)
+        backend = backend or ("nccl" if (prefer_gpu and torch.cuda.is_available()) else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world, dist
 
 

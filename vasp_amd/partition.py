@@ -1,0 +1,319 @@
+"""Element partition of one monolithic FSI problem across the GPUs of a node.
+
+Counterpart of what DOLFIN/PETSc do when the reference runs as ``mpirun -np N turtleFSI -p offset_stenosis ...``
+(mesh distributed by cells, ghosted vectors, MPI sums in the Krylov solver and in ``norm``; the reference's own MPI
+reductions at this boundary are in REF src/vasp/simulations/simulation_common.py:213-220).
+
+Layout chosen for one process per GPU over RCCL/xGMI:
+
+* **nodes have owners**: P2 nodes are cut into ``world`` slabs of equal node count along the longest axis of the
+  mesh (vessel-like domains: the cut surfaces are cross-sections, every rank has at most two neighbours, and each
+  neighbour pair has its own xGMI link);
+* **a rank holds every cell that touches a node it owns**, grown by ``overlap`` further node layers (its owned cells
+  first, then the ghost cells), so the rows of owned nodes - and of the ghost nodes inside the overlap - are assembled
+  completely on the device without any exchange; only the outermost node layer is carried as identity rows;
+* per Krylov iteration there are **two owner->ghost refreshes** (the residual into the overlap, the preconditioned
+  direction back; pairwise exchanges of ~10^4-10^5 doubles per neighbour) and a handful of scalar all-reduces; the
+  block preconditioner is rank-local (restricted additive Schwarz on the overlap) and needs nothing else from the
+  other ranks;
+* the host keeps the whole mesh on every rank (a few hundred MB at 1 M tets): hooks, Dirichlet data and post-processing
+  see the global problem, the device sees the local one.
+
+Everything in ``Partition`` is plain numpy (tested on CPU, 2 gloo ranks); ``DistBackend`` binds it to ``libvaspfsi.so``
+through ``fsi_set_partition`` and moves the halo with ``torch.distributed`` (backend "nccl" = RCCL on the GPUs; "gloo"
+with host staging only for rehearsals with several ranks on one card).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+
+
+def node_owners(node_coords: np.ndarray, world: int) -> np.ndarray:
+    """Owner rank of every P2 node: ``world`` slabs of equal node count along the longest axis (ties by node id)."""
+    n = len(node_coords)
+    axis = int(np.argmax(np.ptp(node_coords, axis=0)))
+    order = np.argsort(node_coords[:, axis], kind="stable")
+    owner = np.empty(n, dtype=np.int32)
+    owner[order] = (np.arange(n, dtype=np.int64) * world // n).astype(np.int32)
+    return owner
+
+
+def _p2_node_coords(desc: dict) -> np.ndarray:
+    """Coordinates of the P2 nodes (vertices, then edge midpoints) from coords + tet_nodes alone."""
+    from .mesh import TET_EDGES
+    coords = np.asarray(desc["coords"], dtype=np.float64)
+    tn = np.asarray(desc["tet_nodes"], dtype=np.int64)
+    V, N2 = len(coords), int(desc["num_nodes"])
+    out = np.empty((N2, 3))
+    out[:V] = coords
+    for e in range(6):                                   # edge node 4+e sits between local vertices TET_EDGES[e]
+        a, b = tn[:, TET_EDGES[e, 0]], tn[:, TET_EDGES[e, 1]]
+        out[tn[:, 4 + e]] = 0.5 * (coords[a] + coords[b])
+    return out
+
+
+def node_dofs(nodes: np.ndarray, n2: int, nv: int) -> np.ndarray:
+    """User-layout dofs carried by P2 ``nodes`` of a mesh with n2 nodes / nv vertices: d (node-major), v, then p of the
+    vertices among them.  Sender and receiver apply this to the same node sequence in their own numbering."""
+    nodes = np.asarray(nodes, dtype=np.int64)
+    d = (3 * nodes[:, None] + np.arange(3)).ravel()
+    return np.concatenate([d, 3 * n2 + d, 6 * n2 + nodes[nodes < nv]])
+
+
+def local_sets(owner: np.ndarray, tn: np.ndarray, rank: int, overlap: int):
+    """(local cells, nodes with complete rows, local nodes) of ``rank`` as boolean masks: the cells touching an owned
+    node, grown by ``overlap`` further node layers; rows are complete for the nodes all of whose cells are local."""
+    n2 = len(owner)
+    inner = owner == rank
+    cells = inner[tn].any(axis=1)
+    for _ in range(int(overlap)):
+        inner = np.zeros(n2, dtype=bool)
+        inner[tn[cells]] = True
+        cells = inner[tn].any(axis=1)
+    nodes = np.zeros(n2, dtype=bool)
+    nodes[tn[cells]] = True
+    return cells, inner, nodes
+
+
+class Partition:
+    """The part of a global problem description (``monolithic.build_description``) that one rank holds."""
+
+    def __init__(self, desc: dict, rank: int, world: int, owner: Optional[np.ndarray] = None, overlap: int = 1):
+        self.rank, self.world, self.overlap = int(rank), int(world), int(overlap)
+        tn = np.asarray(desc["tet_nodes"], dtype=np.int64)
+        V, N2, Cg = len(desc["coords"]), int(desc["num_nodes"]), len(tn)
+        self.V, self.N2 = V, N2
+        self.owner = node_owners(_p2_node_coords(desc), world) if owner is None else np.asarray(owner, dtype=np.int32)
+        sets = {q: local_sets(self.owner, tn, q, overlap) for q in range(world)}   # every rank derives all lists
+        local, inner, node_mask = sets[rank]
+        cell_owner = self.owner[tn[:, 0]]                                    # a cell is counted by the owner of its first vertex
+        owned_cells = np.nonzero(local & (cell_owner == rank))[0]
+        ghost_cells = np.nonzero(local & (cell_owner != rank))[0]
+        self.cells = np.concatenate([owned_cells, ghost_cells])              # global ids, owned first
+        self.num_owned_cells = len(owned_cells)
+        self.nodes = np.nonzero(node_mask)[0]                                # local -> global (vertices first: ids < V)
+        self.nv = int(np.searchsorted(self.nodes, V))
+        self.n2 = len(self.nodes)
+        self.g2l = -np.ones(N2, dtype=np.int64)
+        self.g2l[self.nodes] = np.arange(self.n2)
+        self.cell_g2l = -np.ones(Cg, dtype=np.int64)
+        self.cell_g2l[self.cells] = np.arange(len(self.cells))
+        self.ndof = 6 * self.n2 + self.nv
+        self.owned_local = self.owner[self.nodes] == rank                    # (n2,) bool
+        self.complete_local = inner[self.nodes]                              # rows assembled completely from the local cells
+
+        # ---- halo lists: rank q receives its non-owned local nodes from their owners, ascending by global node id
+        self.recv_nodes: Dict[int, np.ndarray] = {}                         # owner p -> global nodes I receive
+        self.send_nodes: Dict[int, np.ndarray] = {}                         # rank q  -> global nodes I send
+        for p in range(world):
+            if p == rank:
+                continue
+            r = np.nonzero(node_mask & (self.owner == p))[0]
+            s_ = np.nonzero(sets[p][2] & (self.owner == rank))[0]
+            if len(r):
+                self.recv_nodes[p] = r
+            if len(s_):
+                self.send_nodes[p] = s_
+        del sets
+        dofs = lambda nodes: node_dofs(self.g2l[nodes], self.n2, self.nv)
+        self.recv_counts = [len(dofs(self.recv_nodes[p])) if p in self.recv_nodes else 0 for p in range(world)]
+        self.send_counts = [len(dofs(self.send_nodes[p])) if p in self.send_nodes else 0 for p in range(world)]
+        cat = lambda d: (np.concatenate([dofs(d[p]) for p in sorted(d)]) if d else np.zeros(0, dtype=np.int64))
+        self.ghost_dofs = cat(self.recv_nodes)                               # local user-layout dofs, in recv-buffer order
+        self.send_dofs = cat(self.send_nodes)                                # ... in send-buffer order
+        self.identity_dofs = node_dofs(np.nonzero(~self.complete_local)[0], self.n2, self.nv)   # outermost layer
+
+        # ---- local <-> global dofs ------------------------------------------------------------------------------
+        nd = self.nodes
+        d = (3 * nd[:, None] + np.arange(3)).ravel()
+        self.l2g_dofs = np.concatenate([d, 3 * N2 + d, 6 * N2 + nd[:self.nv]])
+        own3 = np.repeat(self.owned_local, 3)
+        self.owned_dof_mask = np.concatenate([own3, own3, self.owned_local[:self.nv]])
+
+        # ---- the local problem description ------------------------------------------------------------------------
+        ld = {k: desc[k] for k in ("fluid_props", "solid_props", "solid_models", "dt", "theta", "delta", "laplace_alpha")
+              if k in desc}
+        ld["coords"] = np.ascontiguousarray(np.asarray(desc["coords"])[nd[:self.nv]])
+        ld["tet_nodes"] = self.g2l[tn[self.cells]]
+        ld["tets"] = ld["tet_nodes"][:, :4]
+        ld["num_nodes"] = self.n2
+        ld["cell_kind"] = np.asarray(desc["cell_kind"])[self.cells]
+        ld["cell_region"] = np.asarray(desc["cell_region"])[self.cells]
+        bc = np.asarray(desc.get("bc_dofs", np.zeros(0)), dtype=np.int64)
+        fld = np.minimum(bc // (3 * N2), 2)
+        node = np.where(fld < 2, (bc - fld * 3 * N2) // 3, bc - 6 * N2)
+        comp = np.where(fld < 2, (bc - fld * 3 * N2) % 3, 0)
+        ln = self.g2l[node]
+        self.bc_sel = np.nonzero(ln >= 0)[0]                                 # positions in the global Dirichlet list
+        ln, f, c = ln[self.bc_sel], fld[self.bc_sel], comp[self.bc_sel]
+        ld["bc_dofs"] = np.where(f < 2, f * 3 * self.n2 + 3 * ln + c, 6 * self.n2 + ln)
+        for key, extra in (("pressure_facets", ("pressure_facet_cell",)), ("robin_facets", ("robin_k", "robin_c"))):
+            fn = desc.get(key)
+            if fn is None or not len(fn):
+                continue
+            fn = np.asarray(fn, dtype=np.int64)
+            keep = inner[fn].any(axis=1)                                     # facets that load a row assembled here
+            ld[key] = self.g2l[fn[keep]]
+            for e in extra:
+                ld[e] = np.asarray(desc[e])[keep]
+            if key == "pressure_facets":
+                ld["pressure_facet_cell"] = self.cell_g2l[np.asarray(ld["pressure_facet_cell"], dtype=np.int64)]
+                if (ld["pressure_facet_cell"] < 0).any() or (ld[key] < 0).any():
+                    raise AssertionError("interface facet of an owned node outside the local cells")
+        self.local_desc = ld
+
+    # ---- vectors ------------------------------------------------------------------------------------------------
+    def restrict(self, x_global: np.ndarray) -> np.ndarray:
+        return np.ascontiguousarray(np.asarray(x_global)[self.l2g_dofs])
+
+    def owned_global_dofs(self) -> np.ndarray:
+        return self.l2g_dofs[self.owned_dof_mask]
+
+
+class DistBackend:
+    """The backend protocol of ``monolithic.run`` / ``bench.py`` on an element partition: one ``HipBackend`` per rank on
+    the local cells, coupled through ``fsi_set_partition``.  Takes and returns *global* vectors at the host boundary."""
+
+    _CB_RED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
+    _CB_HALO = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+    def __init__(self, desc: dict, dist, device: int = 0, rank: Optional[int] = None, world: Optional[int] = None,
+                 owner: Optional[np.ndarray] = None, overlap: Optional[int] = None, **kw):
+        import torch
+        from .capi import HipBackend, _ptr
+        self.torch, self.dist = torch, dist
+        self.rank = dist.get_rank() if rank is None else rank
+        self.world = dist.get_world_size() if world is None else world
+        self.on_gpu_wire = dist.get_backend() == "nccl"                       # RCCL moves device buffers directly
+        import os
+        overlap = int(os.environ.get("VASPFSI_OVERLAP", 1)) if overlap is None else overlap
+        self.part = Partition(desc, self.rank, self.world, owner, overlap)
+        self.ndof_global = 6 * self.part.N2 + self.part.V
+        self.hb = HipBackend(self.part.local_desc, device=device, **kw)
+        self.lib, self.ctx, self.ndof = self.hb.lib, self.hb.ctx, self.ndof_global
+        dev = torch.device("cuda", device)
+        self.dev = dev
+        p = self.part
+        self.sendbuf = torch.zeros(max(1, len(p.send_dofs)), dtype=torch.float64, device=dev)
+        self.recvbuf = torch.zeros(max(1, len(p.ghost_dofs)), dtype=torch.float64, device=dev)
+        self._red = torch.zeros(1024, dtype=torch.float64, device=dev)
+        self._error: Optional[BaseException] = None
+        self._cb_red = self._CB_RED(self._allreduce)
+        self._cb_halo = self._CB_HALO(self._halo)
+
+        class FsiComm(C.Structure):
+            _fields_ = [("user", C.c_void_p), ("allreduce_sum", self._CB_RED), ("halo_exchange", self._CB_HALO)]
+        self._comm = FsiComm(None, self._cb_red, self._cb_halo)
+        gd = np.ascontiguousarray(p.ghost_dofs, dtype=np.int64)
+        sd = np.ascontiguousarray(p.send_dofs, dtype=np.int64)
+        idn = np.ascontiguousarray(p.identity_dofs, dtype=np.int64)
+        self.hb._check(self.lib.fsi_set_partition(self.ctx, p.num_owned_cells, len(gd), _ptr(gd), len(idn), _ptr(idn),
+                                                  len(sd), _ptr(sd),
+                                                  C.c_void_p(self.sendbuf.data_ptr()), C.c_void_p(self.recvbuf.data_ptr()),
+                                                  C.byref(self._comm)))
+        self.history = self.hb.history
+
+    # ---- transport (called back from inside fsi_solve / fsi_newton_solve) ------------------------------------------
+    def _allreduce(self, _user, vals, n):
+        try:
+            torch, a = self.torch, np.ctypeslib.as_array(vals, shape=(n,))
+            if self.on_gpu_wire:
+                t = self._red[:n] if n <= len(self._red) else torch.empty(n, dtype=torch.float64, device=self.dev)
+                t.copy_(torch.from_numpy(a))
+                self.dist.all_reduce(t)
+                a[:] = t.cpu().numpy()
+            else:
+                self.dist.all_reduce(torch.from_numpy(a))
+            return 0
+        except BaseException as e:          # never unwind through the C frames
+            self._error = e
+            return 1
+
+    def _halo(self, _user):
+        try:
+            torch, p = self.torch, self.part
+            ns, nr = len(p.send_dofs), len(p.ghost_dofs)
+            if self.on_gpu_wire:
+                self.dist.all_to_all_single(self.recvbuf[:nr], self.sendbuf[:ns], p.recv_counts, p.send_counts)
+            else:                            # rehearsal transport: stage through the host
+                r = torch.empty(nr, dtype=torch.float64)
+                self.dist.all_to_all_single(r, self.sendbuf[:ns].cpu(), p.recv_counts, p.send_counts)
+                self.recvbuf[:nr].copy_(r)
+            torch.cuda.synchronize(self.dev)
+            return 0
+        except BaseException as e:
+            self._error = e
+            return 1
+
+    def _check(self, rc):
+        if rc != 0 and self._error is not None:
+            e, self._error = self._error, None
+            raise e
+        self.hb._check(rc)
+
+    # ---- backend protocol -------------------------------------------------------------------------------------------
+    def set_dirichlet_values(self, values):
+        self.hb.set_dirichlet_values(np.asarray(values, dtype=np.float64)[self.part.bc_sel])
+
+    def set_interface_pressure(self, P):
+        self.hb.set_interface_pressure(P)
+
+    def newton_solve(self, **kw):
+        try:
+            return self.hb.newton_solve(**kw)
+        except Exception:
+            if self._error is not None:
+                e, self._error = self._error, None
+                raise e
+            raise
+
+    def shift(self):
+        self.hb.shift()
+
+    def assemble_residual(self):
+        return self.hb.assemble_residual()
+
+    def assemble_jacobian(self):
+        self.hb.assemble_jacobian()
+
+    def solve(self, *a, **kw):
+        return self.hb.solve(*a, **kw)
+
+    def set_chebyshev(self, **kw):
+        self.hb.set_chebyshev(**kw)
+
+    def timers(self, reset=False):
+        return self.hb.timers(reset)
+
+    def set_state(self, which, x_global):
+        self.hb.set_state(which, self.part.restrict(x_global))
+
+    def get_state(self, which, out=None):
+        """Global vector assembled from the owners' entries (an all-gather over the host; not on the hot path)."""
+        torch, p = self.torch, self.part
+        loc = self.hb.get_state(which)
+        mine = torch.from_numpy(np.ascontiguousarray(loc[p.owned_dof_mask]))
+        idx = torch.from_numpy(np.ascontiguousarray(p.owned_global_dofs()))
+        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+        n_here = torch.tensor([len(idx)], dtype=torch.int64)
+        if self.on_gpu_wire:
+            sizes = [s.to(self.dev) for s in sizes]
+            n_here = n_here.to(self.dev)
+        self.dist.all_gather(sizes, n_here)
+        sizes = [int(s.item()) for s in sizes]
+        out = np.zeros(self.ndof_global) if out is None else out
+        for r in range(self.world):                        # one broadcast per owner: simple, and off the hot path
+            v = mine.clone() if r == self.rank else torch.empty(sizes[r], dtype=torch.float64)
+            i = idx.clone() if r == self.rank else torch.empty(sizes[r], dtype=torch.int64)
+            if self.on_gpu_wire:
+                v, i = v.to(self.dev), i.to(self.dev)
+            self.dist.broadcast(v, src=r)
+            self.dist.broadcast(i, src=r)
+            out[i.cpu().numpy()] = v.cpu().numpy()
+        return out
+
+    def close(self):
+        self.hb.close()
