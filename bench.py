@@ -79,7 +79,9 @@ def main():
 
     import torch
     from vasp_amd.dist import aggregate, init_from_env
-    rank, local_rank, world, dist = init_from_env(backend=os.environ.get("VASPFSI_DIST_BACKEND"))
+    # VASPFSI_FORCE_PARTITION=1: a single rank still goes through DistBackend and the process group (wire-path check)
+    force = bool(os.environ.get("VASPFSI_FORCE_PARTITION"))
+    rank, local_rank, world, dist = init_from_env(backend=os.environ.get("VASPFSI_DIST_BACKEND"), force_group=force)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if os.environ.get("VASPFSI_ONE_GPU"):
@@ -99,7 +101,8 @@ def main():
         ns, desc, bc_values, pressure, hook = prepare(
             ["-p", "offset_stenosis", "-dt", str(args.dt), "-T", str(T_end), "--theta", "0.501", "--verbose", "False",
              "--folder", str(tmp / "results"), "--sub-folder", "1", "--new-arguments", f"mesh_path={mesh_path}"])
-    if world > 1:
+    partitioned = world > 1 or force
+    if partitioned:
         from vasp_amd.partition import DistBackend
         hb = DistBackend(desc, dist, device=local_rank, lin_max_it=int(os.environ.get("VASPFSI_LIN_MAX_IT", 4000)))
     else:
@@ -122,7 +125,7 @@ def main():
         return hist
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -144,17 +147,17 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     tm = hb.timers()
-    wire = "cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu"
+    wire = "cuda" if (dist is None or dist.get_backend() == "nccl") else "cpu"
     elapsed, total_newton = aggregate(dist, elapsed, n_newton, device=wire)
-    if world > 1:
+    if partitioned:
         total_newton /= world        # one partitioned job: every rank counted the same Newton iterations
         _, C_all = aggregate(dist, 0.0, len(hb.part.cells), device=wire)       # cells incl. ghost layers, summed
 
     if rank == 0:
         ndof, nnz = hb.ndof, int(hb.lib.fsi_matrix_nnz(hb.ctx))
         C = mesh.num_cells
-        C_rank = len(hb.part.cells) if world > 1 else C       # the kernels of this rank run on its local cells / rows
-        ndof_rank = hb.part.ndof if world > 1 else ndof
+        C_rank = len(hb.part.cells) if partitioned else C       # the kernels of this rank run on its local cells / rows
+        ndof_rank = hb.part.ndof if partitioned else ndof
         # algorithmic bytes per launch of each timed kernel
         sweeps = tm["inner_vv_iters"] * (ns_cheb[0] / max(1, ns_cheb[0] + ns_cheb[1]))     # solid-block SpMV launches
         ss_avg = tm["solid_spmv_ms"] / max(1, tm["solid_spmv_calls"])
@@ -198,7 +201,7 @@ def main():
             "config": {"workload": f"offset_stenosis synthetic mesh, {C} tets, {ndof} dofs, dt={args.dt}, theta=0.501, "
                                    f"quasi-Newton atol=rtol=1e-6 recompute_tstep={ns['recompute_tstep']}",
                        "tets": C, "dofs": ndof, "matrix_nnz": nnz, "parallelism": (f"element partition over {world} ranks (node slabs, ghost-layer cells {C_all / C - 1:.1%}), "
-                                       f"halo + all-reduce over {dist.get_backend()}") if world > 1 else "1 GPU",
+                                       f"halo + all-reduce over {dist.get_backend()}") if partitioned else "1 GPU",
                        "rank0_matrix_nnz": nnz},
             "dof_updates_per_s": total_newton * ndof / elapsed,
             "newton_iterations": n_newton, "krylov_iterations": n_krylov,
@@ -214,7 +217,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     hb.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -8,12 +8,12 @@ from __future__ import annotations
 import os
 
 
-def init_from_env(prefer_gpu: bool = True, backend=None):
+def init_from_env(prefer_gpu: bool = True, backend=None, force_group: bool = False):
     """(rank, local_rank, world, dist-or-None) from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*."""
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world == 1:
+    if world == 1 and not force_group:
         return rank, local_rank, world, None
     import torch
     import torch.distributed as dist
