@@ -109,6 +109,7 @@ def main():
         hb = HipBackend(desc, device=local_rank)
     ns_cheb = (int(os.environ.get("FSI_CHEB_S", 300)), int(os.environ.get("FSI_CHEB_F", 20)))
     solid_fp32 = int(os.environ.get("FSI_SOLID_FP32", 1)) != 0
+    solid_fused = solid_fp32 and int(os.environ.get("FSI_SOLID_BJ", 1)) != 0 and int(os.environ.get("FSI_SOLID_FUSED", 1)) != 0
     mesh = ns["mesh"]
     setup_s = time.perf_counter() - t_setup
     newton = dict(atol=ns["atol"], rtol=ns["rtol"], max_it=ns["max_it"], lmbda=ns["lmbda"], recompute=ns["recompute"],
@@ -180,10 +181,13 @@ def main():
             ("k_spmv_tiled_f32<3>" if tiled else "k_spmv_db_f32") + " (fluid velocity block sweeps, FP32 component-diagonal node blocks; avg from sampled HIP events)":
                 (db_avg * db_launches, int(db_launches), dbf_bytes),
             # (time attributed in the timed region [ms], launches, algorithmic bytes per launch, avg launch [ms])
-            ("k_spmv_sb (solid velocity block, FP32 3x3 block-CSR, Chebyshev sweeps; avg from sampled HIP events)"
+            (("k_sweep_sb_b3 (solid velocity block: FP32 3x3 block-CSR product fused with the Chebyshev update; avg from sampled HIP events)"
+              if solid_fused else "k_spmv_sb (solid velocity block, FP32 3x3 block-CSR, Chebyshev sweeps; avg from sampled HIP events)")
              if solid_fp32 else "k_spmv<1> (solid velocity block, CSR f64, Chebyshev sweeps; avg from sampled HIP events)"):
                 (ss_avg * sweeps, int(sweeps),
-                 (tm["solid_nnz"] * 4.0 + tm["solid_nnz"] / 9 * 4.0 + tm["solid_rows"] * 8.0 + (tm["solid_rows"] / 3 + 1) * 8.0) if solid_fp32
+                 (tm["solid_nnz"] * 4.0 + tm["solid_nnz"] / 9 * 4.0 + tm["solid_rows"] * 8.0 + (tm["solid_rows"] / 3 + 1) * 8.0
+                  # fused sweep: per node also r, x (read + write), d_out (write) as float4 and the 3x3 scaling block
+                  + (tm["solid_rows"] / 3 * (5 * 16.0 + 48.0) if solid_fused else 0.0)) if solid_fp32
                  else (tm["solid_nnz"] * 12.0 + tm["solid_rows"] * 16.0 + (tm["solid_rows"] + 1) * 8.0)),
             "k_spmv<0> (monolithic Jacobian, CSR f64 + i32)": (tm["spmv_ms"], tm["spmv_calls"], nnz * 12.0 + ndof_rank * 16.0 + (ndof_rank + 1) * 8.0),
             "k_residual (element residual + scatter-add)": (tm["residual_ms"], tm["residual_calls"], C_rank * 1676.0),

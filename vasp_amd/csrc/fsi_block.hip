@@ -777,6 +777,51 @@ __global__ void k_cheb_step_b3(int64_t nS, const float* __restrict__ t, const fl
     reinterpret_cast<float4*>(d)[i] = make_float4(c1 * di.x + c2 * z.x, c1 * di.y + c2 * z.y, c1 * di.z + c2 * z.z, 0.f);
   }
 }
+// One Chebyshev sweep of the solid block in a single launch: t = A d_in (3x3 block-CSR, 16 lanes per node), then on the
+// first three lanes of the group (one component each)  r -= t,  x += d_in,  d_out = c1 d_in + c2 B^-1 r.
+// d is ping-ponged because other nodes still gather d_in; the product never goes through memory.
+__global__ __launch_bounds__(256) void k_sweep_sb_b3(int64_t nS, const int64_t* __restrict__ sb_ptr,
+                                                     const int32_t* __restrict__ sb_col, const float* __restrict__ vals,
+                                                     const float* __restrict__ binv12, float c1, float c2,
+                                                     const float* __restrict__ din, float* __restrict__ dout,
+                                                     float* __restrict__ x, float* __restrict__ r) {
+  const int sub = threadIdx.x & 15;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t i = grp; i < nS; i += ngrp) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int64_t b = sb_ptr[i] + sub; b < sb_ptr[i + 1]; b += 16) {
+      const float4 xv = reinterpret_cast<const float4*>(din)[sb_col[b]];
+      const float* a = vals + 9 * b;
+      const float x0 = xv.x, x1 = xv.y, x2 = xv.z;
+      s0 += a[0] * x0 + a[1] * x1 + a[2] * x2;
+      s1 += a[3] * x0 + a[4] * x1 + a[5] * x2;
+      s2 += a[6] * x0 + a[7] * x1 + a[8] * x2;
+    }
+    for (int off = 8; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
+    }
+    float rc = 0.f, dc = 0.f;
+    if (sub < 3) {
+      dc = din[4 * i + sub];
+      rc = r[4 * i + sub] - (sub == 0 ? s0 : (sub == 1 ? s1 : s2));
+    }
+    const float r0 = __shfl(rc, 0, 16), r1 = __shfl(rc, 1, 16), r2 = __shfl(rc, 2, 16);
+    if (sub < 3) {
+      const float4 brow = reinterpret_cast<const float4*>(binv12 + 12 * i)[sub];
+      x[4 * i + sub] += dc;
+      r[4 * i + sub] = rc;
+      dout[4 * i + sub] = c1 * dc + c2 * (brow.x * r0 + brow.y * r1 + brow.z * r2);
+    }
+  }
+}
+void launch_sweep_sb_b3(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
+                        const float* binv12, float c1, float c2, const float* din, float* dout, float* x, float* r) {
+  int64_t blocks = (nS + 15) / 16;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_sweep_sb_b3, dim3((unsigned)blocks), dim3(256), 0, st, nS, sb_ptr, sb_col, vals, binv12, c1, c2, din,
+                     dout, x, r);
+}
 void launch_sb_binv(hipStream_t st, int64_t nS, const int32_t* snode, const int64_t* diagpos3, const double* Avv,
                     float* binv12, double* binv9) {
   hipLaunchKernelGGL(k_sb_binv, dim3(gridn(nS)), dim3(256), 0, st, nS, snode, diagpos3, Avv, binv12, binv9);

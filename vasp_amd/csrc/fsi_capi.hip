@@ -293,14 +293,24 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
       const bool bj = ctx->solid_block_jacobi != 0;
       if (bj) launch_cheb_init_b3(st, ctx->nS, frhs, ctx->sb_binv12.p, (float)(1.0 / th), fx, fr, fd);
       else launch_cheb_init_f32(st, n, frhs, ctx->sb_dinv.p, (float)(1.0 / th), fx, fr, fd);
+      const bool fused = bj && ctx->solid_fused;
+      if (fused) HIPCHK(hipMemsetAsync(ft, 0, n * sizeof(float), st));     // second d buffer (ping-pong), pads stay zero
+      float *dcur = fd, *dnext = ft;
       for (int k = 0; k < ctx->cheb_its_s; ++k) {
         const bool timed = k < 8 && ctx->ss_ev0[0];
-        if (timed) (void)hipEventRecord(ctx->ss_ev0[k], st);
-        launch_spmv_sb(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_col.p, ctx->sb_vals.p, fd, ft);
-        if (timed) (void)hipEventRecord(ctx->ss_ev1[k], st);
         const double rn = 1.0 / (2.0 * sig - rho);
-        if (bj) launch_cheb_step_b3(st, ctx->nS, ft, ctx->sb_binv12.p, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
-        else launch_cheb_step_f32(st, n, ft, ctx->sb_dinv.p, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
+        if (timed) (void)hipEventRecord(ctx->ss_ev0[k], st);
+        if (fused) {
+          launch_sweep_sb_b3(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_col.p, ctx->sb_vals.p, ctx->sb_binv12.p, (float)(rn * rho),
+                             (float)(2.0 * rn / de), dcur, dnext, fx, fr);
+          std::swap(dcur, dnext);
+          if (timed) (void)hipEventRecord(ctx->ss_ev1[k], st);
+        } else {
+          launch_spmv_sb(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_col.p, ctx->sb_vals.p, fd, ft);
+          if (timed) (void)hipEventRecord(ctx->ss_ev1[k], st);
+          if (bj) launch_cheb_step_b3(st, ctx->nS, ft, ctx->sb_binv12.p, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
+          else launch_cheb_step_f32(st, n, ft, ctx->sb_dinv.p, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
+        }
         rho = rn;
       }
       ctx->ss_samples_pending = ctx->ss_ev0[0] ? std::min(8, ctx->cheb_its_s) : 0;
@@ -1119,6 +1129,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
         HIPCHK(ctx->sb_binv12.alloc(12 * nS));
         HIPCHK(ctx->sb_binv9.alloc(9 * nS));
         if (const char* e = getenv("FSI_SOLID_BJ")) ctx->solid_block_jacobi = atoi(e);
+        if (const char* e = getenv("FSI_SOLID_FUSED")) ctx->solid_fused = atoi(e);
         if (const char* e = getenv("FSI_SOLID_FP32")) ctx->solid_fp32 = atoi(e);
       }
       FSICHK(upload(ctx, ctx->snode, snode));

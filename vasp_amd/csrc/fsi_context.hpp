@@ -171,6 +171,7 @@ struct FsiCtx {
   fsi::DevBuf<float> sb_vals, sb_dinv;
   int solid_fp32 = 1;
   int solid_block_jacobi = 1;                // 3x3 node-block scaling of the solid sweeps (FSI_SOLID_BJ=0: point Jacobi)
+  int solid_fused = 1;                       // SpMV + Chebyshev update of a solid sweep in one launch (FSI_SOLID_FUSED=0: two)
   fsi::DevBuf<float> sb_binv12;
   fsi::DevBuf<double> sb_binv9;
   fsi::DevBuf<double> mask_s, mask_f;        // [3 N2] 1 on velocity dofs of solid (incl. interface) / fluid-interior nodes

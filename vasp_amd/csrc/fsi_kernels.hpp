@@ -123,6 +123,8 @@ void launch_sb_binv(hipStream_t st, int64_t nS, const int32_t* snode, const int6
                     float* binv12, double* binv9);
 void launch_block_scale_d(hipStream_t st, int64_t nS, const double* binv9, double* y);
 void launch_cheb_init_b3(hipStream_t st, int64_t nS, const float* rhs, const float* binv12, float inv_theta, float* x, float* r, float* d);
+void launch_sweep_sb_b3(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
+                        const float* binv12, float c1, float c2, const float* din, float* dout, float* x, float* r);
 void launch_cheb_step_b3(hipStream_t st, int64_t nS, const float* t, const float* binv12, float c1, float c2, float* x, float* r, float* d);
 void launch_sb_gather(hipStream_t st, int64_t nb, const int32_t* sb_row, const int64_t* sb_src, const int32_t* sb_stride,
                       const double* Avv, float* vals);

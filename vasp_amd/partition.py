@@ -81,7 +81,7 @@ def local_sets(owner: np.ndarray, tn: np.ndarray, rank: int, overlap: int):
 class Partition:
     """The part of a global problem description (``monolithic.build_description``) that one rank holds."""
 
-    def __init__(self, desc: dict, rank: int, world: int, owner: Optional[np.ndarray] = None, overlap: int = 1):
+    def __init__(self, desc: dict, rank: int, world: int, owner: Optional[np.ndarray] = None, overlap: int = 2):
         self.rank, self.world, self.overlap = int(rank), int(world), int(overlap)
         tn = np.asarray(desc["tet_nodes"], dtype=np.int64)
         V, N2, Cg = len(desc["coords"]), int(desc["num_nodes"]), len(tn)
@@ -189,7 +189,7 @@ class DistBackend:
         self.world = dist.get_world_size() if world is None else world
         self.on_gpu_wire = dist.get_backend() == "nccl"                       # RCCL moves device buffers directly
         import os
-        overlap = int(os.environ.get("VASPFSI_OVERLAP", 1)) if overlap is None else overlap
+        overlap = int(os.environ.get("VASPFSI_OVERLAP", 2)) if overlap is None else overlap
         self.part = Partition(desc, self.rank, self.world, owner, overlap)
         self.ndof_global = 6 * self.part.N2 + self.part.V
         self.hb = HipBackend(self.part.local_desc, device=device, **kw)
