@@ -337,3 +337,32 @@ def test_device_diagnostics_match_host(cylinder_case):
         assert np.allclose(out[i, 3:6], f.sub(1)(x), rtol=1e-12, atol=1e-300)
         assert np.isclose(out[i, 6], f.sub(2)(x), rtol=1e-12, atol=1e-300)
     hb.close()
+
+
+def test_two_level_displacement_solve_is_a_preconditioner_only(stenosis_case, monkeypatch):
+    """The P2 -> P1 two-level solve of the displacement block (Galerkin coarse operator on the vertex graph) replaces 60
+    one-level Chebyshev sweeps inside the block preconditioner: the converged fields must not move (1e-8), and the outer
+    Krylov iteration counts must stay in the same range."""
+    from vasp_amd.capi import HipBackend
+    ns, desc, bc_values, pressure, hook = stenosis_case
+    out = {}
+    for mg in ("1", "0"):
+        monkeypatch.setenv("FSI_DD_MG", mg)
+        hb = HipBackend(desc, lin_rtol=1e-11)
+        its = 0
+        for k in range(2):
+            g, P = boundary_data(stenosis_case, 0.01 * (k + 1))
+            hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+            hist = hb.newton_solve(counter=k, first_step_num=0, atol=1e-11, rtol=1e-14, max_it=50, lmbda=1.0, recompute=20,
+                                   recompute_tstep=20)
+            assert hist[-1][0] < 1e-11
+            its += sum(h[3] for h in hist)
+            hb.shift()
+        out[mg] = (hb.get_state("n"), its)
+        hb.close()
+    (x1, its1), (x0, its0) = out["1"], out["0"]
+    print("krylov iterations: two-level", its1, "one-level", its0)
+    mesh = ns["mesh"]
+    for name, a, b in zip("dvp", mesh.split(x1), mesh.split(x0)):
+        assert np.abs(a - b).max() <= 1e-8 * np.abs(b).max(), name
+    assert its1 <= 1.25 * its0

@@ -16,9 +16,17 @@ def test_ownership_and_ghost_layer(stenosis_case, world, overlap):
     mesh = ns["mesh"]
     parts = [Partition(desc, r, world, overlap=overlap) for r in range(world)]
     owner = parts[0].owner
-    assert np.array_equal(owner, node_owners(mesh.node_coords, world))          # node coordinates rebuilt from tet_nodes
-    counts = np.bincount(owner, minlength=world)
+    from vasp_amd.partition import _p2_node_coords, balanced_owners
+    assert np.allclose(_p2_node_coords(desc), mesh.node_coords)                    # node coordinates rebuilt from tet_nodes
+    assert np.array_equal(owner, balanced_owners(mesh.node_coords, mesh.tet_nodes, world, overlap))
+    equal = node_owners(mesh.node_coords, world)
+    counts = np.bincount(equal, minlength=world)
     assert counts.max() - counts.min() <= 1
+    x_of = mesh.node_coords[:, int(np.argmax(np.ptp(mesh.node_coords, axis=0)))]
+    assert all(x_of[owner == r].max() <= x_of[owner == r + 1].min() for r in range(world - 1))     # slabs
+    spread = lambda own: np.ptp([Partition(desc, r, world, owner=own, overlap=overlap).n2 for r in range(world)])
+    if world > 2:
+        assert spread(owner) < spread(equal)                                       # local sizes (owned + ghosts) evened out
     assert sum(p.num_owned_cells for p in parts) == mesh.num_cells               # every cell counted once in the L2 norm
     seen = np.zeros(mesh.num_dofs, dtype=int)
     for p in parts:

@@ -600,6 +600,134 @@ void launch_spmv_tiled_f32(hipStream_t st, int nv, int64_t N2, int max_nu, const
 int tile_nodes() { return TILE_NODES; }
 int tile_limit() { return TILE_LIMIT; }
 
+// ---- two-level (P2 -> P1) solve of the displacement block -----------------------------------------------------------
+// A_dd = A0 (x) I_3 with A0 the symmetric mass / mesh-Laplacian matrix of the P2 nodes (rows of the assembled matrix are
+// equilibrated, so a0_ab = db_ab / rowscale_a).  The P1 functions are a subspace of the P2 functions (vertex values kept,
+// edge-midpoint value = mean of the two end vertices), so the Galerkin coarse operator is  A_c = P^T A0 P  on the vertex
+// graph.  Chebyshev sweeps on the fine level only have to damp the upper part of the spectrum; the smooth error is
+// handled by many, 15x cheaper, sweeps on A_c.
+__global__ void k_mg_d0(int64_t N2, const int64_t* __restrict__ nadj_ptr, const int32_t* __restrict__ nadj,
+                        const double* __restrict__ db, const double* __restrict__ rowscale,
+                        const uint8_t* __restrict__ rowflag, float* __restrict__ d0, int32_t* __restrict__ flags) {
+  GS(r, N2) {
+    const uint8_t f0 = rowflag[3 * r], f1 = rowflag[3 * r + 1], f2 = rowflag[3 * r + 2];
+    if (f0 != f1 || f0 != f2) atomicOr(&flags[1], 32);          // per-component Dirichlet rows: one scalar operator does not fit
+    double d = 0.0;
+    if (!f0)
+      for (int64_t e = nadj_ptr[r]; e < nadj_ptr[r + 1]; ++e) if (nadj[e] == r) d = db[3 * e] / rowscale[6 * r];
+    d0[r] = (float)d;
+  }
+}
+__global__ __launch_bounds__(256) void k_mg_rap(int64_t N2, const int64_t* __restrict__ nadj_ptr,
+                                                const int32_t* __restrict__ nadj, const double* __restrict__ db,
+                                                const double* __restrict__ rowscale, const uint8_t* __restrict__ rowflag,
+                                                const int32_t* __restrict__ par, const float* __restrict__ pw,
+                                                const int64_t* __restrict__ cptr, const int32_t* __restrict__ ccol,
+                                                double* __restrict__ Ac, int32_t* __restrict__ flags) {
+  const int sub = threadIdx.x & 15;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t a = grp; a < N2; a += ngrp) {
+    if (rowflag[3 * a]) continue;
+    const double inv_sc = 1.0 / rowscale[6 * a];
+    for (int64_t e = nadj_ptr[a] + sub; e < nadj_ptr[a + 1]; e += 16) {
+      const int32_t b = nadj[e];
+      if (rowflag[3 * (int64_t)b]) continue;
+      const double aab = db[3 * e] * inv_sc;
+      for (int pi = 0; pi < 2; ++pi) {
+        const float wi = pw[2 * a + pi];
+        if (wi == 0.f) continue;
+        const int32_t i = par[2 * a + pi];
+        for (int pj = 0; pj < 2; ++pj) {
+          const float wj = pw[2 * (int64_t)b + pj];
+          if (wj == 0.f) continue;
+          const int32_t j = par[2 * (int64_t)b + pj];
+          int64_t lo = cptr[i], hi = cptr[i + 1];
+          while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ccol[mid] < j) lo = mid + 1; else hi = mid; }
+          if (lo < cptr[i + 1] && ccol[lo] == j) unsafeAtomicAdd(&Ac[lo], (double)(wi * wj) * aab);
+          else atomicOr(&flags[1], 64);                            // the vertex graph misses a pair: structure bug
+        }
+      }
+    }
+  }
+}
+// Jacobi-scaled coarse operator (one ratio per vertex pair), identity rows where the vertex is a Dirichlet node of the fine
+// operator or no free fine node feeds it; dcinv4 = 1 / diag as float4 per coarse node; rowmax = max_i sum_j |cc_ij|
+__global__ void k_mg_coarse_finish(int64_t nc, const int64_t* __restrict__ cptr, const int32_t* __restrict__ ccol,
+                                   const double* __restrict__ Ac, const int32_t* __restrict__ cfine,
+                                   const uint8_t* __restrict__ rowflag, float* __restrict__ cc, uint8_t* __restrict__ cflag,
+                                   float* __restrict__ dcinv4, int32_t* __restrict__ rowmax_bits) {
+  GS(i, nc) {
+    int64_t dg = -1;
+    for (int64_t e = cptr[i]; e < cptr[i + 1]; ++e) if (ccol[e] == i) dg = e;
+    const double d = dg >= 0 ? Ac[dg] : 0.0;
+    const bool ident = rowflag[3 * (int64_t)cfine[i]] || !(d > 0.0);
+    float sum = 0.f;
+    for (int64_t e = cptr[i]; e < cptr[i + 1]; ++e) {
+      const float v = ident ? (e == dg ? 1.f : 0.f) : (float)(Ac[e] / d);
+      cc[e] = v;
+      sum += fabsf(v);
+    }
+    for (int c = 0; c < 3; ++c) { cflag[3 * i + c] = ident ? 1 : 0; dcinv4[4 * i + c] = ident ? 0.f : (float)(1.0 / d); }
+    dcinv4[4 * i + 3] = 0.f;
+    atomicMax(rowmax_bits, __float_as_int(sum));                   // positive floats order like their bit patterns
+  }
+}
+// coarse right-hand side: D_c^-1 P^T (D0 r), the fine residual r being that of the Jacobi-scaled system
+__global__ void k_mg_restrict(int64_t nc, const int64_t* __restrict__ chptr, const int32_t* __restrict__ child,
+                              const float* __restrict__ chw, const float* __restrict__ d0, const float* __restrict__ r4,
+                              const float* __restrict__ dcinv4, float* __restrict__ rc4) {
+  GS(i, nc) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int64_t k = chptr[i]; k < chptr[i + 1]; ++k) {
+      const int32_t a = child[k];
+      const float w = chw[k] * d0[a];                              // d0 = 0 on Dirichlet rows: they do not feed the coarse level
+      const float4 rv = reinterpret_cast<const float4*>(r4)[a];
+      s0 += w * rv.x; s1 += w * rv.y; s2 += w * rv.z;
+    }
+    const float di = dcinv4[4 * i];
+    reinterpret_cast<float4*>(rc4)[i] = make_float4(di * s0, di * s1, di * s2, 0.f);
+  }
+}
+__global__ void k_mg_prolong(int64_t N2, const int32_t* __restrict__ par, const float* __restrict__ pw,
+                             const float* __restrict__ d0, const float* __restrict__ xc4, float* __restrict__ e4) {
+  GS(a, N2) {
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d0[a] != 0.f) {
+      const float4 u = reinterpret_cast<const float4*>(xc4)[par[2 * a]], v = reinterpret_cast<const float4*>(xc4)[par[2 * a + 1]];
+      const float wu = pw[2 * a], wv = pw[2 * a + 1];
+      out = make_float4(wu * u.x + wv * v.x, wu * u.y + wv * v.y, wu * u.z + wv * v.z, 0.f);
+    }
+    reinterpret_cast<float4*>(e4)[a] = out;
+  }
+}
+void launch_mg_d0(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
+                  const double* rowscale, const uint8_t* rowflag, float* d0, int32_t* flags) {
+  hipLaunchKernelGGL(k_mg_d0, dim3(gridn(N2)), dim3(256), 0, st, N2, nadj_ptr, nadj, db, rowscale, rowflag, d0, flags);
+}
+void launch_mg_rap(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
+                   const double* rowscale, const uint8_t* rowflag, const int32_t* par, const float* pw, const int64_t* cptr,
+                   const int32_t* ccol, double* Ac, int32_t* flags) {
+  int64_t blocks = (N2 + 15) / 16;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_mg_rap, dim3((unsigned)blocks), dim3(256), 0, st, N2, nadj_ptr, nadj, db, rowscale, rowflag, par, pw,
+                     cptr, ccol, Ac, flags);
+}
+void launch_mg_coarse_finish(hipStream_t st, int64_t nc, const int64_t* cptr, const int32_t* ccol, const double* Ac,
+                             const int32_t* cfine, const uint8_t* rowflag, float* cc, uint8_t* cflag, float* dcinv4,
+                             int32_t* rowmax_bits) {
+  hipLaunchKernelGGL(k_mg_coarse_finish, dim3(gridn(nc)), dim3(256), 0, st, nc, cptr, ccol, Ac, cfine, rowflag, cc, cflag,
+                     dcinv4, rowmax_bits);
+}
+void launch_mg_restrict(hipStream_t st, int64_t nc, const int64_t* chptr, const int32_t* child, const float* chw,
+                        const float* d0, const float* r4, const float* dcinv4, float* rc4) {
+  hipLaunchKernelGGL(k_mg_restrict, dim3(gridn(nc)), dim3(256), 0, st, nc, chptr, child, chw, d0, r4, dcinv4, rc4);
+}
+void launch_mg_prolong(hipStream_t st, int64_t N2, const int32_t* par, const float* pw, const float* d0, const float* xc4,
+                       float* e4) {
+  hipLaunchKernelGGL(k_mg_prolong, dim3(gridn(N2)), dim3(256), 0, st, N2, par, pw, d0, xc4, e4);
+}
+
 void launch_extract_chat(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
                          float* chat, uint8_t* rowflag, int32_t* flags) {
   hipLaunchKernelGGL(k_extract_chat, dim3(gridn(N2)), dim3(256), 0, st, N2, nadj_ptr, nadj, db, chat, rowflag, flags);

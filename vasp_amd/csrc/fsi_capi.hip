@@ -372,6 +372,53 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
       launch_pad_to_f32(st, N2, td, ctx->dd_dinv32.p, frhs);
       const double lmax = ctx->lmax_d, lmin = lmax / ctx->cheb_kappa_d, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
       double rho = 1.0 / sig;
+      auto fine_spmv = [&](int k_sample) {
+        const bool timed = k_sample >= 0 && k_sample < 4 && ctx->sc_ev0[0];
+        if (timed) (void)hipEventRecord(ctx->sc_ev0[k_sample], st);
+        if (ctx->tiled)
+          launch_spmv_tiled_f32(st, 1, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_chat.p, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
+                                ctx->dd_rowflag.p, fd, ft);
+        else
+          launch_spmv_sc_f32(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_chat.p, ctx->dd_rowflag.p, fd, ft);
+        if (timed) { (void)hipEventRecord(ctx->sc_ev1[k_sample], st); ctx->sc_samples_pending = k_sample + 1; }
+      };
+      if (ctx->mg_ready) {
+        // two-level cycle: Chebyshev smoothing on [lmax/alpha, lmax], coarse solve on the vertex graph, smoothing again
+        const double slmin = lmax / ctx->mg_alpha, sth = 0.5 * (lmax + slmin), sde = 0.5 * (lmax - slmin), ssig = sth / sde;
+        double srho = 1.0 / ssig;
+        launch_cheb_init_f32(st, n, frhs, ctx->ones32.p, (float)(1.0 / sth), fx, fr, fd);
+        for (int k = 0; k < ctx->mg_pre; ++k) {
+          fine_spmv(k);
+          const double rn = 1.0 / (2.0 * ssig - srho);
+          launch_cheb_step_f32(st, n, ft, ctx->ones32.p, (float)(rn * srho), (float)(2.0 * rn / sde), fx, fr, fd);
+          srho = rn;
+        }
+        const int64_t nc = ctx->mg_nc, n4c = 4 * nc;
+        float *cr = ctx->mg_work.p, *cd = cr + n4c, *ct = cr + 2 * n4c, *cx = cr + 3 * n4c, *crhs = cr + 4 * n4c;
+        launch_mg_restrict(st, nc, ctx->mg_chptr.p, ctx->mg_child.p, ctx->mg_chw.p, ctx->mg_d0.p, fr, ctx->mg_dcinv4.p, crhs);
+        {
+          const double cl = ctx->mg_clmax, clmin = cl / ctx->mg_ckappa, cth = 0.5 * (cl + clmin), cde = 0.5 * (cl - clmin), csig = cth / cde;
+          double crho = 1.0 / csig;
+          launch_cheb_init_f32(st, n4c, crhs, ctx->mg_cones.p, (float)(1.0 / cth), cx, cr, cd);
+          for (int k = 0; k < ctx->mg_cits; ++k) {
+            launch_spmv_sc_f32(st, nc, ctx->mg_cptr.p, ctx->mg_ccol.p, ctx->mg_cc.p, ctx->mg_cflag.p, cd, ct);
+            const double rn = 1.0 / (2.0 * csig - crho);
+            launch_cheb_step_f32(st, n4c, ct, ctx->mg_cones.p, (float)(rn * crho), (float)(2.0 * rn / cde), cx, cr, cd);
+            crho = rn;
+          }
+        }
+        launch_mg_prolong(st, N2, ctx->mg_par.p, ctx->mg_pw.p, ctx->mg_d0.p, cx, fd);     // correction as the next direction
+        fine_spmv(-1);
+        launch_cheb_step_f32(st, n, ft, ctx->ones32.p, 0.f, (float)(1.0 / sth), fx, fr, fd);   // x += P x_c, r -= C P x_c, restart
+        srho = 1.0 / ssig;
+        for (int k = 0; k < ctx->mg_post; ++k) {
+          fine_spmv(-1);
+          const double rn = 1.0 / (2.0 * ssig - srho);
+          launch_cheb_step_f32(st, n, ft, ctx->ones32.p, (float)(rn * srho), (float)(2.0 * rn / sde), fx, fr, fd);
+          srho = rn;
+        }
+        ctx->inner_its[2] += ctx->mg_pre + 1 + ctx->mg_post - ctx->cheb_its_d;     // counted below as cheb_its_d
+      } else {
       launch_cheb_init_f32(st, n, frhs, ctx->ones32.p, (float)(1.0 / th), fx, fr, fd);
       for (int k = 0; k < ctx->cheb_its_d; ++k) {
         const bool timed = k < 4 && ctx->sc_ev0[0];
@@ -385,6 +432,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         const double rn = 1.0 / (2.0 * sig - rho);
         launch_cheb_step_f32(st, n, ft, ctx->ones32.p, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
         rho = rn;
+      }
       }
       launch_unpad_from_f32(st, N2, fx, dd);
     } else if (ctx->dd_is_db && ctx->sweeps_fp32)
@@ -628,6 +676,23 @@ int refresh_preconditioner(FsiCtx* ctx) {
       launch_extract_chat(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_db.p, ctx->dd_chat.p, ctx->dd_rowflag.p, ctx->iflags.p);
       HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
       ctx->dd_is_scalar = ctx->dd_is_db && !(flags[1] & 16) && !getenv("FSI_NO_SCALAR_DD");
+      ctx->mg_ready = false;
+      if (ctx->dd_mg && ctx->dd_is_scalar && ctx->sweeps_fp32 && ctx->mg_nc > 0) {
+        // Galerkin coarse operator of the displacement block, A_c = P^T A0 P, and its Jacobi-scaled single-precision form
+        HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
+        HIPCHK(hipMemsetAsync(ctx->mg_Ac.p, 0, ctx->mg_cnnz * sizeof(double), st));
+        launch_mg_d0(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_db.p, ctx->rowscale.p, ctx->dd_rowflag.p, ctx->mg_d0.p, ctx->iflags.p);
+        launch_mg_rap(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_db.p, ctx->rowscale.p, ctx->dd_rowflag.p, ctx->mg_par.p,
+                      ctx->mg_pw.p, ctx->mg_cptr.p, ctx->mg_ccol.p, ctx->mg_Ac.p, ctx->iflags.p);
+        launch_mg_coarse_finish(st, ctx->mg_nc, ctx->mg_cptr.p, ctx->mg_ccol.p, ctx->mg_Ac.p, ctx->mg_cfine.p, ctx->dd_rowflag.p,
+                                ctx->mg_cc.p, ctx->mg_cflag.p, ctx->mg_dcinv4.p, ctx->iflags.p + 2);
+        HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
+        float rowmax;
+        std::memcpy(&rowmax, &flags[2], sizeof rowmax);
+        ctx->mg_ready = !(flags[1] & (32 | 64)) && std::isfinite(rowmax) && rowmax > 0.f;
+        ctx->mg_clmax = rowmax;                   // Gershgorin bound of the Jacobi-scaled coarse operator
+        HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
+      }
       launch_to_f32(st, 3 * npairs, ctx->dd_db.p, ctx->dd_db32.p);
       launch_to_f32(st, 3 * npairs, ctx->vv_db.p, ctx->vv_db32.p);
       launch_dinv_f32(st, ctx->N2, nullptr, ctx->diagpos3.p, ctx->Mdd.vals.p, ctx->dd_dinv32.p);
@@ -746,6 +811,9 @@ int fsi_destroy(FsiCtx* ctx) {
   for (auto* b : i32) b->release();
   DevBuf<int64_t>* i64[] = {&ctx->nadj_ptr, &ctx->padj_ptr, &ctx->rowptr, &ctx->diagpos, &ctx->rb_pos};
   for (auto* b : i64) b->release();
+  ctx->mg_par.release(); ctx->mg_ccol.release(); ctx->mg_child.release(); ctx->mg_cfine.release(); ctx->mg_pw.release();
+  ctx->mg_chw.release(); ctx->mg_cptr.release(); ctx->mg_chptr.release(); ctx->mg_Ac.release(); ctx->mg_cc.release();
+  ctx->mg_d0.release(); ctx->mg_dcinv4.release(); ctx->mg_cones.release(); ctx->mg_work.release(); ctx->mg_cflag.release();
   ctx->ghost_idx.release(); ctx->ident_idx.release(); ctx->send_idx.release(); ctx->mbc_dofs.release(); ctx->ghost_zero.release();
   ctx->enbr.release();
   ctx->epnbr.release();
@@ -1225,6 +1293,79 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
       std::vector<float> ones(4 * N2, 1.0f);
       for (int64_t i = 0; i < N2; ++i) ones[4 * i + 3] = 0.0f;
       FSICHK(upload(ctx, ctx->ones32, ones));
+    }
+    {   // P2 -> P1 hierarchy of the displacement block: parents of every node, vertex graph, children of every vertex
+      if (const char* e = getenv("FSI_DD_MG")) ctx->dd_mg = atoi(e);
+      if (const char* e = getenv("FSI_MG_PRE")) ctx->mg_pre = atoi(e);
+      if (const char* e = getenv("FSI_MG_POST")) ctx->mg_post = atoi(e);
+      if (const char* e = getenv("FSI_MG_CITS")) ctx->mg_cits = atoi(e);
+      if (const char* e = getenv("FSI_MG_ALPHA")) ctx->mg_alpha = atof(e);
+      if (const char* e = getenv("FSI_MG_CKAPPA")) ctx->mg_ckappa = atof(e);
+      std::vector<int32_t> cidx(N2, -1), cfine;
+      for (int64_t r = 0; r < N2; ++r)
+        if (ctx->h_rank2node[r] < V) { cidx[r] = (int32_t)cfine.size(); cfine.push_back((int32_t)r); }
+      const int64_t nc = (int64_t)cfine.size();
+      static const int TE[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};      // UFC edge -> local vertices
+      std::vector<int32_t> ends(2 * (size_t)N2, -1);
+      for (int64_t c = 0; c < C; ++c)
+        for (int e = 0; e < 6; ++e) {
+          const int32_t nd = tn[10 * c + 4 + e];
+          ends[2 * (size_t)nd] = tn[10 * c + TE[e][0]];
+          ends[2 * (size_t)nd + 1] = tn[10 * c + TE[e][1]];
+        }
+      std::vector<int32_t> par(2 * (size_t)N2);
+      std::vector<float> pw(2 * (size_t)N2);
+      std::vector<int64_t> chptr(nc + 1, 0);
+      bool ok = nc == V;
+      for (int64_t r = 0; r < N2 && ok; ++r) {
+        const int32_t nd = ctx->h_rank2node[r];
+        if (nd < V) { par[2 * r] = par[2 * r + 1] = cidx[r]; pw[2 * r] = 1.f; pw[2 * r + 1] = 0.f; chptr[cidx[r] + 1] += 1; }
+        else {
+          const int32_t a = ends[2 * (size_t)nd], b = ends[2 * (size_t)nd + 1];
+          if (a < 0 || b < 0 || a >= V || b >= V) { ok = false; break; }
+          par[2 * r] = cidx[rk[a]]; par[2 * r + 1] = cidx[rk[b]];
+          pw[2 * r] = pw[2 * r + 1] = 0.5f;
+          chptr[par[2 * r] + 1] += 1; chptr[par[2 * r + 1] + 1] += 1;
+        }
+      }
+      if (ok) {
+        for (int64_t i = 0; i < nc; ++i) chptr[i + 1] += chptr[i];
+        std::vector<int32_t> child(chptr[nc]);
+        std::vector<float> chw(chptr[nc]);
+        std::vector<int64_t> fill(chptr.begin(), chptr.end() - 1);
+        for (int64_t r = 0; r < N2; ++r)
+          for (int k = 0; k < 2; ++k)
+            if (pw[2 * r + k] != 0.f) { const int64_t pos = fill[par[2 * r + k]]++; child[pos] = (int32_t)r; chw[pos] = pw[2 * r + k]; }
+        std::vector<int64_t> cptr(nc + 1, 0);
+        std::vector<int32_t> ccol;
+        for (int64_t i = 0; i < nc; ++i) {
+          const int64_t r = cfine[i];
+          for (int64_t e = ctx->h_nadj_ptr[r]; e < ctx->h_nadj_ptr[r + 1]; ++e)
+            if (cidx[ctx->h_nadj[e]] >= 0) ccol.push_back(cidx[ctx->h_nadj[e]]);      // ascending: ranks ascend, cidx is monotone
+          cptr[i + 1] = (int64_t)ccol.size();
+        }
+        ctx->mg_nc = nc;
+        ctx->mg_cnnz = (int64_t)ccol.size();
+        FSICHK(upload(ctx, ctx->mg_par, par));
+        FSICHK(upload(ctx, ctx->mg_pw, pw));
+        FSICHK(upload(ctx, ctx->mg_chptr, chptr));
+        FSICHK(upload(ctx, ctx->mg_child, child));
+        FSICHK(upload(ctx, ctx->mg_chw, chw));
+        FSICHK(upload(ctx, ctx->mg_cptr, cptr));
+        FSICHK(upload(ctx, ctx->mg_ccol, ccol));
+        FSICHK(upload(ctx, ctx->mg_cfine, cfine));
+        HIPCHK(ctx->mg_Ac.alloc(ctx->mg_cnnz));
+        HIPCHK(ctx->mg_cc.alloc(ctx->mg_cnnz));
+        HIPCHK(ctx->mg_d0.alloc(N2));
+        HIPCHK(ctx->mg_dcinv4.alloc(4 * nc));
+        HIPCHK(ctx->mg_cflag.alloc(3 * nc));
+        HIPCHK(ctx->mg_work.alloc(5 * 4 * nc));
+        std::vector<float> cones(4 * (size_t)nc, 1.0f);
+        for (int64_t i = 0; i < nc; ++i) cones[4 * i + 3] = 0.0f;
+        FSICHK(upload(ctx, ctx->mg_cones, cones));
+      } else {
+        ctx->dd_mg = 0;
+      }
     }
     HIPCHK(ctx->vvf_dinv32.alloc(4 * N2));
     if (const char* e = getenv("FSI_SWEEPS_FP32")) ctx->sweeps_fp32 = atoi(e);

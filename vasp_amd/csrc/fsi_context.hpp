@@ -159,6 +159,18 @@ struct FsiCtx {
   fsi::DevBuf<uint16_t> tile_ploc;           // [pairs] local index of the pair's column node in its tile's list
   fsi::DevBuf<int64_t> tile_uptr;            // [tiles+1]
   fsi::DevBuf<int32_t> tile_ulist;           // distinct neighbour nodes of each tile, ascending
+  // two-level (P2 -> P1) solve of the displacement block: Galerkin coarse operator on the vertex graph (fsi_block.hip)
+  int dd_mg = 1;                             // FSI_DD_MG=0: one-level Chebyshev sweeps
+  bool mg_ready = false;
+  int64_t mg_nc = 0, mg_cnnz = 0;            // coarse nodes = vertices in rank order
+  fsi::DevBuf<int32_t> mg_par, mg_ccol, mg_child, mg_cfine;   // [N2][2] parents; coarse columns; children; vertex -> fine rank
+  fsi::DevBuf<float> mg_pw, mg_chw;          // [N2][2] parent weights (vertex 1,0; edge node 1/2,1/2); child weights
+  fsi::DevBuf<int64_t> mg_cptr, mg_chptr;
+  fsi::DevBuf<double> mg_Ac;
+  fsi::DevBuf<float> mg_cc, mg_d0, mg_dcinv4, mg_cones, mg_work;
+  fsi::DevBuf<uint8_t> mg_cflag;
+  int mg_pre = 4, mg_post = 4, mg_cits = 40;
+  double mg_alpha = 10.0, mg_ckappa = 250.0, mg_clmax = 2.0;
   fsi::SubMat Mdd, Mvv, Ms;                  // A_dd, Avv~, sparsified Schur complement (ILU only)
   fsi::DevBuf<double> blk;                   // work vectors of the block preconditioner
   int64_t nS = 0;                            // solid (incl. interface) nodes; compact velocity block A_SS on them

@@ -123,6 +123,18 @@ void launch_sb_binv(hipStream_t st, int64_t nS, const int32_t* snode, const int6
                     float* binv12, double* binv9);
 void launch_block_scale_d(hipStream_t st, int64_t nS, const double* binv9, double* y);
 void launch_cheb_init_b3(hipStream_t st, int64_t nS, const float* rhs, const float* binv12, float inv_theta, float* x, float* r, float* d);
+void launch_mg_d0(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
+                  const double* rowscale, const uint8_t* rowflag, float* d0, int32_t* flags);
+void launch_mg_rap(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
+                   const double* rowscale, const uint8_t* rowflag, const int32_t* par, const float* pw, const int64_t* cptr,
+                   const int32_t* ccol, double* Ac, int32_t* flags);
+void launch_mg_coarse_finish(hipStream_t st, int64_t nc, const int64_t* cptr, const int32_t* ccol, const double* Ac,
+                             const int32_t* cfine, const uint8_t* rowflag, float* cc, uint8_t* cflag, float* dcinv4,
+                             int32_t* rowmax_bits);
+void launch_mg_restrict(hipStream_t st, int64_t nc, const int64_t* chptr, const int32_t* child, const float* chw,
+                        const float* d0, const float* r4, const float* dcinv4, float* rc4);
+void launch_mg_prolong(hipStream_t st, int64_t N2, const int32_t* par, const float* pw, const float* d0, const float* xc4,
+                       float* e4);
 void launch_sweep_sb_b3(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
                         const float* binv12, float c1, float c2, const float* din, float* dout, float* x, float* r);
 void launch_cheb_step_b3(hipStream_t st, int64_t nS, const float* t, const float* binv12, float c1, float c2, float* x, float* r, float* d);

@@ -6,8 +6,8 @@ reductions at this boundary are in REF src/vasp/simulations/simulation_common.py
 
 Layout chosen for one process per GPU over RCCL/xGMI:
 
-* **nodes have owners**: P2 nodes are cut into ``world`` slabs of equal node count along the longest axis of the
-  mesh (vessel-like domains: the cut surfaces are cross-sections, every rank has at most two neighbours, and each
+* **nodes have owners**: P2 nodes are cut into ``world`` slabs along the longest axis of the mesh, sized so that owned +
+  ghost nodes per rank are equal (vessel-like domains: the cut surfaces are cross-sections, every rank has at most two neighbours, and each
   neighbour pair has its own xGMI link);
 * **a rank holds every cell that touches a node it owns**, grown by ``overlap`` further node layers (its owned cells
   first, then the ghost cells), so the rows of owned nodes - and of the ghost nodes inside the overlap - are assembled
@@ -38,6 +38,26 @@ def node_owners(node_coords: np.ndarray, world: int) -> np.ndarray:
     order = np.argsort(node_coords[:, axis], kind="stable")
     owner = np.empty(n, dtype=np.int32)
     owner[order] = (np.arange(n, dtype=np.int64) * world // n).astype(np.int32)
+    return owner
+
+
+def balanced_owners(node_coords: np.ndarray, tn: np.ndarray, world: int, overlap: int, rounds: int = 1) -> np.ndarray:
+    """Slabs as in ``node_owners``, with the cuts moved so that the *local* node counts (owned + ghost layers: what a
+    rank's kernels run over) are equal - end slabs have one ghost side, interior slabs two."""
+    n = len(node_coords)
+    axis = int(np.argmax(np.ptp(node_coords, axis=0)))
+    order = np.argsort(node_coords[:, axis], kind="stable")
+    share = np.full(world, n / world)
+    owner = np.empty(n, dtype=np.int32)
+    for it in range(rounds + 1):
+        bounds = np.round(np.cumsum(share)).astype(np.int64)
+        bounds[-1] = n
+        owner[order] = np.searchsorted(bounds, np.arange(n, dtype=np.int64), side="right").astype(np.int32)
+        if it == rounds or world == 1:
+            break
+        ghosts = np.array([local_sets(owner, tn, q, overlap)[2].sum() for q in range(world)]) - np.bincount(owner, minlength=world)
+        share = np.maximum((n + ghosts.sum()) / world - ghosts, 0.25 * n / world)
+        share *= n / share.sum()
     return owner
 
 
@@ -86,7 +106,8 @@ class Partition:
         tn = np.asarray(desc["tet_nodes"], dtype=np.int64)
         V, N2, Cg = len(desc["coords"]), int(desc["num_nodes"]), len(tn)
         self.V, self.N2 = V, N2
-        self.owner = node_owners(_p2_node_coords(desc), world) if owner is None else np.asarray(owner, dtype=np.int32)
+        self.owner = (balanced_owners(_p2_node_coords(desc), tn, world, overlap) if owner is None
+                      else np.asarray(owner, dtype=np.int32))
         sets = {q: local_sets(self.owner, tn, q, overlap) for q in range(world)}   # every rank derives all lists
         local, inner, node_mask = sets[rank]
         cell_owner = self.owner[tn[:, 0]]                                    # a cell is counted by the owner of its first vertex
