@@ -169,8 +169,8 @@ struct FsiCtx {
   fsi::DevBuf<double> mg_Ac;
   fsi::DevBuf<float> mg_cc, mg_d0, mg_dcinv4, mg_cones, mg_work;
   fsi::DevBuf<uint8_t> mg_cflag;
-  int mg_pre = 4, mg_post = 4, mg_cits = 40;
-  double mg_alpha = 10.0, mg_ckappa = 250.0, mg_clmax = 2.0;
+  int mg_pre = 4, mg_post = 8, mg_cits = 40;  // fine Chebyshev sweeps before / after the coarse solve; coarse sweeps
+  double mg_alpha = 30.0, mg_ckappa = 250.0, mg_clmax = 2.0;   // smoothing interval [lmax/alpha, lmax]; coarse interval
   fsi::SubMat Mdd, Mvv, Ms;                  // A_dd, Avv~, sparsified Schur complement (ILU only)
   fsi::DevBuf<double> blk;                   // work vectors of the block preconditioner
   int64_t nS = 0;                            // solid (incl. interface) nodes; compact velocity block A_SS on them
