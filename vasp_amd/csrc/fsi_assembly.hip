@@ -176,22 +176,32 @@ __global__ __launch_bounds__(64) void k_residual(ElemArrays ea, ElemParams ep, c
 // L2(Omega) norm of a mixed function: out += int |d|^2 + |v|^2 + p^2 dx over the cells  (`norm(dvp_res, 'l2')` of the
 // reference's newtonsolver is DOLFIN's *function* norm; see oracle/fsi_oracle.py:function_norm)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_l2norm(ElemArrays ea, const double* __restrict__ X, double* __restrict__ out) {
-  const int64_t c = blockIdx.x;
-  const int lane = threadIdx.x;
-  __shared__ double sU[NLOC], sJ[10];
-  sU[lane] = X[ea.cell_dofs[c * NLOC + lane]];
-  if (lane < 10) sJ[lane] = ea.geom[c * 10 + lane];
-  __syncthreads();
-  double s = 0.0;
-  if (lane < NQ) {
-    Kin<double> k;
-    interpolate(sU, sJ, lane, k);
-    s = sJ[9] * c_qw[lane] * (k.d[0] * k.d[0] + k.d[1] * k.d[1] + k.d[2] * k.d[2] + k.v[0] * k.v[0] + k.v[1] * k.v[1] +
-                              k.v[2] * k.v[2] + k.p * k.p);
+// One wave per cell, waves stride over the cells and keep their sum in a register (one atomic per wave at the end:
+// a million same-address atomics cost more than the whole integration).  Values only - no gradients are needed.
+__global__ __launch_bounds__(256) void k_l2norm(ElemArrays ea, const double* __restrict__ X, int64_t C, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t wave = blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+  __shared__ double sU[4][NLOC];
+  double acc = 0.0;
+  for (int64_t c = wave; c < C; c += nwaves) {
+    sU[w][lane] = X[ea.cell_dofs[c * NLOC + lane]];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < NQ) {
+      const double* U = sU[w];
+      double s = 0.0;
+      for (int f = 0; f < 6; ++f) {                        // d_x d_y d_z v_x v_y v_z: 10 P2 values each
+        double val = 0.0;
+        for (int a = 0; a < 10; ++a) val += c_N[lane][a] * U[10 * f + a];
+        s += val * val;
+      }
+      double p = 0.0;
+      for (int a = 0; a < 4; ++a) p += c_L[lane][a] * U[60 + a];
+      acc += ea.geom[c * 10 + 9] * c_qw[lane] * (s + p * p);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  if (lane == 0) unsafeAtomicAdd(out, s);
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0 && acc != 0.0) unsafeAtomicAdd(out, acc);
 }
 // ---------------------------------------------------------------------------------------------------------
 // per-step diagnostics of post_solve [REF src/vasp/simulations/simulation_common.py:253-348]: per cell the DG0
@@ -270,7 +280,8 @@ void launch_probe(hipStream_t st, int64_t n, const ElemArrays& ea, const int32_t
   hipLaunchKernelGGL(k_probe, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, ea, cells, bary, X, out);
 }
 void launch_l2norm(hipStream_t st, int64_t C, const ElemArrays& ea, const double* X, double* out) {
-  hipLaunchKernelGGL(k_l2norm, dim3((unsigned)C), dim3(64), 0, st, ea, X, out);
+  const int64_t blocks = std::min<int64_t>((C + 3) / 4, 4096);
+  hipLaunchKernelGGL(k_l2norm, dim3((unsigned)blocks), dim3(256), 0, st, ea, X, C, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------

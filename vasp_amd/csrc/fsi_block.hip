@@ -1019,6 +1019,30 @@ __global__ __launch_bounds__(256) void k_residual_csr(int64_t n, const int64_t* 
     if (lane == 0) y[row] = b[row] - s;
   }
 }
+// y[rows] = b[rows] - sum_t vals[src[t]] x[col[t]] on a short list of rows: the fluid rows next to the wall, whose only
+// coupling to the solid predictor is through a few solid columns (y = b elsewhere, set by the caller).  16 lanes per row.
+__global__ __launch_bounds__(256) void k_residual_rows(int64_t nrows, const int32_t* __restrict__ rows,
+                                                       const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
+                                                       const int64_t* __restrict__ src, const double* __restrict__ vals,
+                                                       const double* __restrict__ x, const double* __restrict__ b,
+                                                       double* __restrict__ y) {
+  const int sub = threadIdx.x & 15;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t i = grp; i < nrows; i += ngrp) {
+    double s = 0.0;
+    for (int64_t t = ptr[i] + sub; t < ptr[i + 1]; t += 16) s += vals[src[t]] * x[col[t]];
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+    if (sub == 0) { const int32_t r = rows[i]; y[r] = b[r] - s; }
+  }
+}
+void launch_residual_rows(hipStream_t st, int64_t nrows, const int32_t* rows, const int64_t* ptr, const int32_t* col,
+                          const int64_t* src, const double* vals, const double* x, const double* b, double* y) {
+  if (nrows <= 0) return;
+  int64_t blocks = (nrows + 15) / 16;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_residual_rows, dim3((unsigned)blocks), dim3(256), 0, st, nrows, rows, ptr, col, src, vals, x, b, y);
+}
 void launch_residual_csr(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const double* vals,
                          const double* x, const double* b, double* y) {
   int64_t blocks = (n + 3) / 4;

@@ -335,7 +335,10 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
     launch_fill(st, xs, n3, 0.0);
     launch_scatter3(st, ctx->nS, ctx->snode.p, cs_x, xs);
     }
-    launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Mvv.vals.p, xs, rv, rhs2);
+    // rhs of the fluid part: rv - Avv~ xs; xs lives on the solid nodes, the fluid solve masks the solid rows, so only
+    // the fluid rows with solid columns differ from rv
+    launch_copy(st, rhs2, rv, n3);
+    launch_residual_rows(st, ctx->nfs, ctx->fs_rows.p, ctx->fs_ptr.p, ctx->fs_col.p, ctx->fs_src.p, ctx->Mvv.vals.p, xs, rv, rhs2);
     if (ctx->sweeps_fp32)
       cheb_db_f32(ctx, ctx->vv_db32.p, ctx->vvf_dinv32.p, rhs2, xf, IW, ctx->cheb_its_f, ctx->lmax_f, ctx->cheb_kappa_f);
     else
@@ -811,6 +814,7 @@ int fsi_destroy(FsiCtx* ctx) {
   for (auto* b : i32) b->release();
   DevBuf<int64_t>* i64[] = {&ctx->nadj_ptr, &ctx->padj_ptr, &ctx->rowptr, &ctx->diagpos, &ctx->rb_pos};
   for (auto* b : i64) b->release();
+  ctx->fs_rows.release(); ctx->fs_col.release(); ctx->fs_ptr.release(); ctx->fs_src.release();
   ctx->mg_par.release(); ctx->mg_ccol.release(); ctx->mg_child.release(); ctx->mg_cfine.release(); ctx->mg_pw.release();
   ctx->mg_chw.release(); ctx->mg_cptr.release(); ctx->mg_chptr.release(); ctx->mg_Ac.release(); ctx->mg_cc.release();
   ctx->mg_d0.release(); ctx->mg_dcinv4.release(); ctx->mg_cones.release(); ctx->mg_work.release(); ctx->mg_cflag.release();
@@ -1199,6 +1203,32 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
         if (const char* e = getenv("FSI_SOLID_BJ")) ctx->solid_block_jacobi = atoi(e);
         if (const char* e = getenv("FSI_SOLID_FUSED")) ctx->solid_fused = atoi(e);
         if (const char* e = getenv("FSI_SOLID_FP32")) ctx->solid_fp32 = atoi(e);
+      }
+      {   // rows of fluid-interior nodes that see solid columns: the only rows the solid predictor changes in the fluid rhs
+        std::vector<int32_t> fs_rows, fs_col;
+        std::vector<int64_t> fs_ptr(1, 0), fs_src;
+        for (int64_t r = 0; r < N2; ++r) {
+          if (node_solid[r]) continue;
+          const int64_t a = ctx->h_nadj_ptr[r], deg = ctx->h_nadj_ptr[r + 1] - a;
+          bool any = false;
+          for (int64_t k = 0; k < deg && !any; ++k) any = node_solid[ctx->h_nadj[a + k]] != 0;
+          if (!any) continue;
+          for (int c = 0; c < 3; ++c) {
+            const int64_t row0 = 9 * a + 3 * c * deg;
+            for (int64_t k = 0; k < deg; ++k) {
+              const int32_t nb = ctx->h_nadj[a + k];
+              if (!node_solid[nb]) continue;
+              for (int j = 0; j < 3; ++j) { fs_col.push_back(3 * nb + j); fs_src.push_back(row0 + 3 * k + j); }
+            }
+            fs_rows.push_back((int32_t)(3 * r + c));
+            fs_ptr.push_back((int64_t)fs_col.size());
+          }
+        }
+        ctx->nfs = (int64_t)fs_rows.size();
+        FSICHK(upload(ctx, ctx->fs_rows, fs_rows));
+        FSICHK(upload(ctx, ctx->fs_ptr, fs_ptr));
+        FSICHK(upload(ctx, ctx->fs_col, fs_col));
+        FSICHK(upload(ctx, ctx->fs_src, fs_src));
       }
       FSICHK(upload(ctx, ctx->snode, snode));
       FSICHK(upload(ctx, ctx->ss_rowptr, ss_rowptr));

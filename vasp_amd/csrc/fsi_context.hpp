@@ -183,6 +183,9 @@ struct FsiCtx {
   fsi::DevBuf<float> sb_vals, sb_dinv;
   int solid_fp32 = 1;
   int solid_block_jacobi = 1;                // 3x3 node-block scaling of the solid sweeps (FSI_SOLID_BJ=0: point Jacobi)
+  int64_t nfs = 0;                           // fluid-interior velocity rows with solid columns (coupling of the predictor)
+  fsi::DevBuf<int32_t> fs_rows, fs_col;
+  fsi::DevBuf<int64_t> fs_ptr, fs_src;
   int solid_fused = 1;                       // SpMV + Chebyshev update of a solid sweep in one launch (FSI_SOLID_FUSED=0: two)
   fsi::DevBuf<float> sb_binv12;
   fsi::DevBuf<double> sb_binv9;

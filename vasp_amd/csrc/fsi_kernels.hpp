@@ -135,6 +135,8 @@ void launch_mg_restrict(hipStream_t st, int64_t nc, const int64_t* chptr, const 
                         const float* d0, const float* r4, const float* dcinv4, float* rc4);
 void launch_mg_prolong(hipStream_t st, int64_t N2, const int32_t* par, const float* pw, const float* d0, const float* xc4,
                        float* e4);
+void launch_residual_rows(hipStream_t st, int64_t nrows, const int32_t* rows, const int64_t* ptr, const int32_t* col,
+                          const int64_t* src, const double* vals, const double* x, const double* b, double* y);
 void launch_sweep_sb_b3(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
                         const float* binv12, float c1, float c2, const float* din, float* dout, float* x, float* r);
 void launch_cheb_step_b3(hipStream_t st, int64_t nS, const float* t, const float* binv12, float c1, float c2, float* x, float* r, float* d);
