@@ -202,6 +202,7 @@ struct FsiCtx {
   int64_t kry_cap = 0, kry_m = 0;
   fsi::DevBuf<double> KP, KQ;
   fsi::DevBuf<double> hcoef;                 // [kry_cap] coefficients on device
+  double gs_rtol = 0.0;                      // tolerance floor of the current Newton solve (re-orthogonalisation criterion)
 
   // timers
   fsi::PhaseTimer t_res, t_jac, t_fac, t_spmv, t_prec, t_ortho, t_kry, t_ss;
