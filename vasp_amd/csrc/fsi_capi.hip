@@ -489,7 +489,14 @@ int precondition(FsiCtx* ctx, const double* r, double* z) {
 }
 int spmv(FsiCtx* ctx, const double* x, double* y) {
   Phase ph(ctx, &ctx->t_spmv);
-  launch_spmv(ctx->stream, ctx->ndof, ctx->rowptr.p, ctx->cols.p, ctx->A.p, x, y, SPMV_MONOLITHIC);
+  // FSI_SPMV_MONO=1: column-array-free variant (8.7 instead of 12 bytes per entry); measured SLOWER on MI355X (6.6 vs
+  // 5.5 ms at 1.7 G entries: the index chain nadj -> x and the t / 6 outweigh the bytes), so the CSR kernel stays
+  static const bool generic = getenv("FSI_SPMV_MONO") == nullptr;
+  if (generic)
+    launch_spmv(ctx->stream, ctx->ndof, ctx->rowptr.p, ctx->cols.p, ctx->A.p, x, y, SPMV_MONOLITHIC);
+  else
+    launch_spmv_mono(ctx->stream, ctx->ndof, ctx->N2, ctx->rowptr.p, ctx->nadj_ptr.p, ctx->nadj.p, ctx->padj_ptr.p, ctx->padj.p,
+                     ctx->vrank.p, ctx->A.p, x, y);
   return FSI_OK;
 }
 
@@ -1817,7 +1824,7 @@ int fsi_spmv(FsiCtx* ctx, const double* x, double* y) {
   const int64_t n = ctx->ndof;
   HIPCHK(hipMemcpyAsync(ctx->tmp7.p, x, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   launch_scatter(ctx->stream, ctx->tmp1.p, ctx->tmp7.p, ctx->user2solver.p, n);
-  launch_spmv(ctx->stream, n, ctx->rowptr.p, ctx->cols.p, ctx->A.p, ctx->tmp1.p, ctx->tmp2.p, SPMV_MONOLITHIC);
+  FSICHK(spmv(ctx, ctx->tmp1.p, ctx->tmp2.p));                 // the kernel of the outer Krylov method
   // undo the row equilibration: y = D^-1 (D A) x
   launch_gather(ctx->stream, ctx->tmp7.p, ctx->tmp2.p, ctx->user2solver.p, n);
   std::vector<double> ys(n), sc(n);
