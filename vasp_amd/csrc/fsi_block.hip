@@ -905,6 +905,52 @@ __global__ void k_cheb_step_b3(int64_t nS, const float* __restrict__ t, const fl
     reinterpret_cast<float4*>(d)[i] = make_float4(c1 * di.x + c2 * z.x, c1 * di.y + c2 * z.y, c1 * di.z + c2 * z.z, 0.f);
   }
 }
+// One Jacobi-Chebyshev sweep on a scalar CSR matrix kept in FP32 (the explicit Schur complement: ~60 entries per row) in a
+// single launch: 16 lanes per row form t = A d_in, lane 0 does  r -= t,  x += d_in,  d_out = c1 d_in + c2 r / a_ii.
+__global__ __launch_bounds__(256) void k_sweep_csr_f32(int64_t n, const int64_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ cols, const float* __restrict__ vals,
+                                                       const float* __restrict__ dinv, float c1, float c2,
+                                                       const float* __restrict__ din, float* __restrict__ dout,
+                                                       float* __restrict__ x, float* __restrict__ r) {
+  const int sub = threadIdx.x & 15;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t i = grp; i < n; i += ngrp) {
+    float s = 0.f;
+    for (int64_t e = rowptr[i] + sub; e < rowptr[i + 1]; e += 16) s += vals[e] * din[cols[e]];
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+    if (sub == 0) {
+      const float di = din[i], ri = r[i] - s;
+      x[i] += di;
+      r[i] = ri;
+      dout[i] = c1 * di + c2 * ri * dinv[i];
+    }
+  }
+}
+__global__ void k_csr_dinv_f32(int64_t n, const int64_t* __restrict__ diagpos, const double* __restrict__ A, float* __restrict__ dinv) {
+  GS(i, n) dinv[i] = (float)(1.0 / A[diagpos[i]]);
+}
+__global__ void k_cheb_init_plain_f32(int64_t n, const double* __restrict__ rhs, const float* __restrict__ dinv, float inv_theta,
+                                      float* __restrict__ x, float* __restrict__ r, float* __restrict__ d, float* __restrict__ d2) {
+  GS(i, n) { const float ri = (float)rhs[i]; x[i] = 0.f; r[i] = ri; d[i] = ri * inv_theta * dinv[i]; d2[i] = 0.f; }
+}
+__global__ void k_f32_to_f64(int64_t n, const float* __restrict__ a, double* __restrict__ b) { GS(i, n) b[i] = (double)a[i]; }
+void launch_sweep_csr_f32(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const float* vals,
+                          const float* dinv, float c1, float c2, const float* din, float* dout, float* x, float* r) {
+  int64_t blocks = (n + 15) / 16;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_sweep_csr_f32, dim3((unsigned)blocks), dim3(256), 0, st, n, rowptr, cols, vals, dinv, c1, c2, din, dout, x, r);
+}
+void launch_csr_dinv_f32(hipStream_t st, int64_t n, const int64_t* diagpos, const double* A, float* dinv) {
+  hipLaunchKernelGGL(k_csr_dinv_f32, dim3(gridn(n)), dim3(256), 0, st, n, diagpos, A, dinv);
+}
+void launch_cheb_init_plain_f32(hipStream_t st, int64_t n, const double* rhs, const float* dinv, float inv_theta, float* x,
+                                float* r, float* d, float* d2) {
+  hipLaunchKernelGGL(k_cheb_init_plain_f32, dim3(gridn(n)), dim3(256), 0, st, n, rhs, dinv, inv_theta, x, r, d, d2);
+}
+void launch_f32_to_f64(hipStream_t st, int64_t n, const float* a, double* b) {
+  hipLaunchKernelGGL(k_f32_to_f64, dim3(gridn(n)), dim3(256), 0, st, n, a, b);
+}
 // One Chebyshev sweep of the solid block in a single launch: t = A d_in (3x3 block-CSR, 16 lanes per node), then on the
 // first three lanes of the group (one component each)  r -= t,  x += d_in,  d_out = c1 d_in + c2 B^-1 r.
 // d is ping-ponged because other nodes still gather d_in; the product never goes through memory.

@@ -350,7 +350,21 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   // pressure: S dp = rp - Apv~ vs,  S x = App x - Apv~ D^-1 Avp x
   launch_pres_rows(st, V, ctx->rowptr_pp.p, ctx->cols_pp.p, ctx->App.p, nullptr, 0.0, ctx->rowptr_pv.p, ctx->cols_pv.p,
                    ctx->Apv.p, vs, -1.0, rp, 1.0, tp);
-  if (ctx->cheb_its_p > 0) {
+  if (ctx->cheb_its_p > 0 && ctx->schur_fp32 && ctx->s_vals32.p) {
+    float *fx = ctx->s_work32.p, *fr = fx + V, *fa = fx + 2 * V, *fb = fx + 3 * V;
+    const double lmax = ctx->lmax_p, lmin = lmax / ctx->cheb_kappa_p, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
+    double rho = 1.0 / sig;
+    launch_cheb_init_plain_f32(st, V, tp, ctx->s_dinv32.p, (float)(1.0 / th), fx, fr, fa, fb);
+    for (int k = 0; k < ctx->cheb_its_p; ++k) {
+      const double rn = 1.0 / (2.0 * sig - rho);
+      launch_sweep_csr_f32(st, V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->s_vals32.p, ctx->s_dinv32.p, (float)(rn * rho),
+                           (float)(2.0 * rn / de), fa, fb, fx, fr);
+      std::swap(fa, fb);
+      rho = rn;
+    }
+    launch_f32_to_f64(st, V, fx, dp);
+    ctx->inner_its[1] += ctx->cheb_its_p;
+  } else if (ctx->cheb_its_p > 0) {
     cheb_solve_op(ctx, V, [&](const double* in, double* out) { schur_apply(ctx, in, out, w3); }, ctx->s_vals.p,
                   ctx->s_diagpos.p, nullptr, tp, dp, IW, ctx->cheb_its_p, ctx->lmax_p, ctx->cheb_kappa_p);
     ctx->inner_its[1] += ctx->cheb_its_p;
@@ -746,6 +760,15 @@ int refresh_preconditioner(FsiCtx* ctx) {
                       ctx->blk.p, &ctx->lmax_d));
     FSICHK(power_lmax_op(ctx, ctx->V, [&](const double* in, double* o) { schur_apply(ctx, in, o, ctx->blk.p + 19 * 3 * ctx->N2); },
                          ctx->s_vals.p, ctx->s_diagpos.p, nullptr, ctx->blk.p, &ctx->lmax_p));
+    if (ctx->schur_fp32) {
+      if (!ctx->s_vals32.p) {
+        HIPCHK(ctx->s_vals32.alloc(ctx->s_vals.n));
+        HIPCHK(ctx->s_dinv32.alloc(ctx->V));
+        HIPCHK(ctx->s_work32.alloc(4 * ctx->V));
+      }
+      launch_to_f32(st, (int64_t)ctx->s_vals.n, ctx->s_vals.p, ctx->s_vals32.p);
+      launch_csr_dinv_f32(st, ctx->V, ctx->s_diagpos.p, ctx->s_vals.p, ctx->s_dinv32.p);
+    }
     for (SubMat* M : {&ctx->Mdd, &ctx->Ms}) {
       if ((M == &ctx->Mdd && ctx->cheb_its_d > 0) || (M == &ctx->Ms && ctx->cheb_its_p > 0)) continue;   // Jacobi-Chebyshev: no factors
       HIPCHK(hipMemcpyAsync(M->LU.p, M->vals.p, M->nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -830,6 +853,7 @@ int fsi_destroy(FsiCtx* ctx) {
   for (auto* b : i32) b->release();
   DevBuf<int64_t>* i64[] = {&ctx->nadj_ptr, &ctx->padj_ptr, &ctx->rowptr, &ctx->diagpos, &ctx->rb_pos};
   for (auto* b : i64) b->release();
+  ctx->s_vals32.release(); ctx->s_dinv32.release(); ctx->s_work32.release();
   ctx->fs_rows.release(); ctx->fs_col.release(); ctx->fs_ptr.release(); ctx->fs_src.release();
   ctx->mg_par.release(); ctx->mg_ccol.release(); ctx->mg_child.release(); ctx->mg_cfine.release(); ctx->mg_pw.release();
   ctx->mg_chw.release(); ctx->mg_cptr.release(); ctx->mg_chptr.release(); ctx->mg_Ac.release(); ctx->mg_cc.release();
@@ -1218,6 +1242,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
         HIPCHK(ctx->sb_binv9.alloc(9 * nS));
         if (const char* e = getenv("FSI_SOLID_BJ")) ctx->solid_block_jacobi = atoi(e);
         if (const char* e = getenv("FSI_SOLID_FUSED")) ctx->solid_fused = atoi(e);
+        if (const char* e = getenv("FSI_SCHUR_FP32")) ctx->schur_fp32 = atoi(e);
         if (const char* e = getenv("FSI_SOLID_FP32")) ctx->solid_fp32 = atoi(e);
       }
       {   // rows of fluid-interior nodes that see solid columns: the only rows the solid predictor changes in the fluid rhs

@@ -146,6 +146,8 @@ struct FsiCtx {
   fsi::DevBuf<int64_t> s_rowptr, s_diagpos;  // explicit Schur complement on its full (two-ring) vertex pattern
   fsi::DevBuf<int32_t> s_cols;
   fsi::DevBuf<double> s_vals;
+  fsi::DevBuf<float> s_vals32, s_dinv32, s_work32;   // FSI_SCHUR_FP32=1: FP32 copy + fused Chebyshev sweeps (measured: no gain over
+  int schur_fp32 = 0;                                 // the FP64 product + update, 21.0 vs 20.4 ms per application: stays off)
   fsi::DevBuf<double> dd_db, vv_db;          // component-diagonal node-block copies of A_dd and Avv~ ([pairs][3])
   fsi::DevBuf<double> adv_db;
   bool dd_is_db = false, adv_is_db = false;

@@ -140,6 +140,12 @@ void launch_residual_rows(hipStream_t st, int64_t nrows, const int32_t* rows, co
 void launch_spmv_mono(hipStream_t st, int64_t n, int64_t N2, const int64_t* rowptr, const int64_t* nadj_ptr,
                       const int32_t* nadj, const int64_t* padj_ptr, const int32_t* padj, const int32_t* vrank,
                       const double* vals, const double* x, double* y);
+void launch_sweep_csr_f32(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const float* vals,
+                          const float* dinv, float c1, float c2, const float* din, float* dout, float* x, float* r);
+void launch_csr_dinv_f32(hipStream_t st, int64_t n, const int64_t* diagpos, const double* A, float* dinv);
+void launch_cheb_init_plain_f32(hipStream_t st, int64_t n, const double* rhs, const float* dinv, float inv_theta, float* x,
+                                float* r, float* d, float* d2);
+void launch_f32_to_f64(hipStream_t st, int64_t n, const float* a, double* b);
 void launch_sweep_sb_b3(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
                         const float* binv12, float c1, float c2, const float* din, float* dout, float* x, float* r);
 void launch_cheb_step_b3(hipStream_t st, int64_t nS, const float* t, const float* binv12, float c1, float c2, float* x, float* r, float* d);
