@@ -160,11 +160,11 @@ def main():
         C_rank = len(hb.part.cells) if partitioned else C       # the kernels of this rank run on its local cells / rows
         ndof_rank = hb.part.ndof if partitioned else ndof
         # algorithmic bytes per launch of each timed kernel
-        sweeps = tm["inner_vv_iters"] * (ns_cheb[0] / max(1, ns_cheb[0] + ns_cheb[1]))     # solid-block SpMV launches
+        f_launches = tm["precond_applies"] * ns_cheb[1]                                # fluid velocity sweeps
+        sweeps = max(0, tm["inner_vv_iters"] - f_launches)                              # fine-level solid sweeps
         ss_avg = tm["solid_spmv_ms"] / max(1, tm["solid_spmv_calls"])
         db_avg = tm["db_spmv_ms"] / max(1, tm["db_spmv_calls"])
         scalar, tiled = bool(tm["disp_scalar"] & 1), bool(tm["disp_scalar"] & 2)
-        f_launches = tm["inner_vv_iters"] * (ns_cheb[1] / max(1, ns_cheb[0] + ns_cheb[1]))
         db_launches = f_launches + (0 if scalar else tm["inner_dd_iters"])
         sc_avg = tm["sc_spmv_ms"] / max(1, tm["sc_spmv_calls"])
         sc_launches = tm["inner_dd_iters"] if scalar else 0
@@ -181,7 +181,7 @@ def main():
             ("k_spmv_tiled_f32<3>" if tiled else "k_spmv_db_f32") + " (fluid velocity block sweeps, FP32 component-diagonal node blocks; avg from sampled HIP events)":
                 (db_avg * db_launches, int(db_launches), dbf_bytes),
             # (time attributed in the timed region [ms], launches, algorithmic bytes per launch, avg launch [ms])
-            (("k_sweep_sb_b3 (solid velocity block: FP32 3x3 block-CSR product fused with the Chebyshev update; avg from sampled HIP events)"
+            (("k_sweep_sb_b3<0> (solid velocity block, fine level: FP32 3x3 block-CSR product fused with the Chebyshev update; avg from sampled HIP events)"
               if solid_fused else "k_spmv_sb (solid velocity block, FP32 3x3 block-CSR, Chebyshev sweeps; avg from sampled HIP events)")
              if solid_fp32 else "k_spmv<1> (solid velocity block, CSR f64, Chebyshev sweeps; avg from sampled HIP events)"):
                 (ss_avg * sweeps, int(sweeps),

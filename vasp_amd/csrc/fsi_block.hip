@@ -905,6 +905,155 @@ __global__ void k_cheb_step_b3(int64_t nS, const float* __restrict__ t, const fl
     reinterpret_cast<float4*>(d)[i] = make_float4(c1 * di.x + c2 * z.x, c1 * di.y + c2 * z.y, c1 * di.z + c2 * z.z, 0.f);
   }
 }
+// ---- two-level (P2 -> P1) solve of the solid velocity block: 3x3-block version of the displacement cycle above ---------
+// Fine operator: the FP32 block-CSR copy (rows equilibrated by `rowscale`), undone here so that A_c = P^T A0 P is the
+// Galerkin operator of the symmetric elasticity + mass matrix.  Nodes whose rows are identity rows (Dirichlet / ghost)
+// take no part in the coarse correction.
+__global__ void k_sbmg_flags(int64_t nS, const int64_t* __restrict__ sb_ptr, const int32_t* __restrict__ sb_col,
+                             const float* __restrict__ vals, uint8_t* __restrict__ flag) {
+  GS(i, nS) {
+    bool off[3] = {false, false, false};
+    for (int64_t b = sb_ptr[i]; b < sb_ptr[i + 1]; ++b) {
+      const bool dg = sb_col[b] == i;
+      for (int c = 0; c < 3; ++c)
+        for (int j = 0; j < 3; ++j)
+          if (!(dg && c == j) && vals[9 * b + 3 * c + j] != 0.f) off[c] = true;
+    }
+    flag[i] = (off[0] && off[1] && off[2]) ? 0 : 1;
+  }
+}
+__global__ __launch_bounds__(256) void k_sbmg_rap(int64_t nS, const int64_t* __restrict__ sb_ptr,
+                                                  const int32_t* __restrict__ sb_col, const float* __restrict__ vals,
+                                                  const int32_t* __restrict__ snode, const double* __restrict__ rowscale,
+                                                  const uint8_t* __restrict__ flag, const int32_t* __restrict__ par,
+                                                  const float* __restrict__ pw, const int64_t* __restrict__ cptr,
+                                                  const int32_t* __restrict__ ccol, float* __restrict__ cvals,
+                                                  int32_t* __restrict__ flags) {
+  const int sub = threadIdx.x & 15;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t a = grp; a < nS; a += ngrp) {
+    if (flag[a]) continue;
+    const int64_t r = snode[a];
+    const float is0 = (float)(1.0 / rowscale[6 * r + 3]), is1 = (float)(1.0 / rowscale[6 * r + 4]), is2 = (float)(1.0 / rowscale[6 * r + 5]);
+    for (int64_t e = sb_ptr[a] + sub; e < sb_ptr[a + 1]; e += 16) {
+      const int32_t b = sb_col[e];
+      if (flag[b]) continue;
+      float blk[9];
+      for (int j = 0; j < 3; ++j) { blk[j] = vals[9 * e + j] * is0; blk[3 + j] = vals[9 * e + 3 + j] * is1; blk[6 + j] = vals[9 * e + 6 + j] * is2; }
+      for (int pi = 0; pi < 2; ++pi) {
+        const float wi = pw[2 * a + pi];
+        if (wi == 0.f) continue;
+        const int32_t i = par[2 * a + pi];
+        for (int pj = 0; pj < 2; ++pj) {
+          const float wj = pw[2 * (int64_t)b + pj];
+          if (wj == 0.f) continue;
+          const int32_t j = par[2 * (int64_t)b + pj];
+          int64_t lo = cptr[i], hi = cptr[i + 1];
+          while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ccol[mid] < j) lo = mid + 1; else hi = mid; }
+          if (lo < cptr[i + 1] && ccol[lo] == j) { for (int t = 0; t < 9; ++t) unsafeAtomicAdd(&cvals[9 * lo + t], wi * wj * blk[t]); }
+          else atomicOr(&flags[1], 64);
+        }
+      }
+    }
+  }
+}
+// coarse rows: inverse of the diagonal block (block-Jacobi scaling), identity rows for flagged / singular vertices, and a
+// bound for the largest eigenvalue of B^-1 A_c (largest absolute row sum of the scaled blocks)
+__global__ void k_sbmg_coarse_finish(int64_t nc, const int64_t* __restrict__ cptr, const int32_t* __restrict__ ccol,
+                                     float* __restrict__ cvals, const int32_t* __restrict__ cfine,
+                                     const uint8_t* __restrict__ flag, float* __restrict__ cbinv12, uint8_t* __restrict__ cflag,
+                                     int32_t* __restrict__ rowmax_bits) {
+  GS(i, nc) {
+    int64_t dg = -1;
+    for (int64_t e = cptr[i]; e < cptr[i + 1]; ++e) if (ccol[e] == i) dg = e;
+    float a[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    if (dg >= 0) for (int c = 0; c < 3; ++c) for (int j = 0; j < 3; ++j) a[c][j] = cvals[9 * dg + 3 * c + j];
+    const float c00 = a[1][1] * a[2][2] - a[1][2] * a[2][1], c01 = a[0][2] * a[2][1] - a[0][1] * a[2][2],
+                c02 = a[0][1] * a[1][2] - a[0][2] * a[1][1], c10 = a[1][2] * a[2][0] - a[1][0] * a[2][2],
+                c11 = a[0][0] * a[2][2] - a[0][2] * a[2][0], c12 = a[0][2] * a[1][0] - a[0][0] * a[1][2],
+                c20 = a[1][0] * a[2][1] - a[1][1] * a[2][0], c21 = a[0][1] * a[2][0] - a[0][0] * a[2][1],
+                c22 = a[0][0] * a[1][1] - a[0][1] * a[1][0];
+    const float det = a[0][0] * c00 + a[0][1] * c10 + a[0][2] * c20;
+    const bool ident = flag[cfine[i]] || dg < 0 || !(det > 0.f) || !(a[0][0] > 0.f);
+    float inv[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    if (!ident) {
+      const float q = 1.f / det;
+      const float t[3][3] = {{c00 * q, c01 * q, c02 * q}, {c10 * q, c11 * q, c12 * q}, {c20 * q, c21 * q, c22 * q}};
+      for (int c = 0; c < 3; ++c) for (int j = 0; j < 3; ++j) inv[c][j] = t[c][j];
+    }
+    float rs[3] = {0.f, 0.f, 0.f};
+    for (int64_t e = cptr[i]; e < cptr[i + 1]; ++e) {
+      if (ident) { for (int t = 0; t < 9; ++t) cvals[9 * e + t] = (e == dg && (t == 0 || t == 4 || t == 8)) ? 1.f : 0.f; continue; }
+      for (int c = 0; c < 3; ++c)
+        for (int j = 0; j < 3; ++j)
+          rs[c] += fabsf(inv[c][0] * cvals[9 * e + j] + inv[c][1] * cvals[9 * e + 3 + j] + inv[c][2] * cvals[9 * e + 6 + j]);
+    }
+    for (int c = 0; c < 3; ++c) {
+      for (int j = 0; j < 3; ++j) cbinv12[12 * i + 4 * c + j] = inv[c][j];
+      cbinv12[12 * i + 4 * c + 3] = 0.f;
+    }
+    cflag[i] = ident ? 1 : 0;
+    atomicMax(rowmax_bits, __float_as_int(ident ? 1.f : fmaxf(rs[0], fmaxf(rs[1], rs[2]))));
+  }
+}
+// coarse rhs = P^T (r / rowscale) of the free fine nodes (zero on identity vertices)
+__global__ void k_sbmg_restrict(int64_t nc, const int64_t* __restrict__ chptr, const int32_t* __restrict__ child,
+                                const float* __restrict__ chw, const int32_t* __restrict__ snode,
+                                const double* __restrict__ rowscale, const uint8_t* __restrict__ flag,
+                                const uint8_t* __restrict__ cflag, const float* __restrict__ r4, float* __restrict__ rc4) {
+  GS(i, nc) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (!cflag[i])
+      for (int64_t k = chptr[i]; k < chptr[i + 1]; ++k) {
+        const int32_t a = child[k];
+        if (flag[a]) continue;
+        const int64_t r = snode[a];
+        const float w = chw[k];
+        const float4 rv = reinterpret_cast<const float4*>(r4)[a];
+        s0 += w * rv.x / (float)rowscale[6 * r + 3]; s1 += w * rv.y / (float)rowscale[6 * r + 4]; s2 += w * rv.z / (float)rowscale[6 * r + 5];
+      }
+    reinterpret_cast<float4*>(rc4)[i] = make_float4(s0, s1, s2, 0.f);
+  }
+}
+__global__ void k_sbmg_prolong(int64_t nS, const int32_t* __restrict__ par, const float* __restrict__ pw,
+                               const uint8_t* __restrict__ flag, const float* __restrict__ xc4, float* __restrict__ e4) {
+  GS(a, nS) {
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!flag[a]) {
+      const float4 u = reinterpret_cast<const float4*>(xc4)[par[2 * a]], v = reinterpret_cast<const float4*>(xc4)[par[2 * a + 1]];
+      const float wu = pw[2 * a], wv = pw[2 * a + 1];
+      out = make_float4(wu * u.x + wv * v.x, wu * u.y + wv * v.y, wu * u.z + wv * v.z, 0.f);
+    }
+    reinterpret_cast<float4*>(e4)[a] = out;
+  }
+}
+void launch_sbmg_flags(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals, uint8_t* flag) {
+  hipLaunchKernelGGL(k_sbmg_flags, dim3(gridn(nS)), dim3(256), 0, st, nS, sb_ptr, sb_col, vals, flag);
+}
+void launch_sbmg_rap(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
+                     const int32_t* snode, const double* rowscale, const uint8_t* flag, const int32_t* par, const float* pw,
+                     const int64_t* cptr, const int32_t* ccol, float* cvals, int32_t* flags) {
+  int64_t blocks = (nS + 15) / 16;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_sbmg_rap, dim3((unsigned)blocks), dim3(256), 0, st, nS, sb_ptr, sb_col, vals, snode, rowscale, flag, par,
+                     pw, cptr, ccol, cvals, flags);
+}
+void launch_sbmg_coarse_finish(hipStream_t st, int64_t nc, const int64_t* cptr, const int32_t* ccol, float* cvals,
+                               const int32_t* cfine, const uint8_t* flag, float* cbinv12, uint8_t* cflag, int32_t* rowmax_bits) {
+  hipLaunchKernelGGL(k_sbmg_coarse_finish, dim3(gridn(nc)), dim3(256), 0, st, nc, cptr, ccol, cvals, cfine, flag, cbinv12, cflag,
+                     rowmax_bits);
+}
+void launch_sbmg_restrict(hipStream_t st, int64_t nc, const int64_t* chptr, const int32_t* child, const float* chw,
+                          const int32_t* snode, const double* rowscale, const uint8_t* flag, const uint8_t* cflag,
+                          const float* r4, float* rc4) {
+  hipLaunchKernelGGL(k_sbmg_restrict, dim3(gridn(nc)), dim3(256), 0, st, nc, chptr, child, chw, snode, rowscale, flag, cflag, r4, rc4);
+}
+void launch_sbmg_prolong(hipStream_t st, int64_t nS, const int32_t* par, const float* pw, const uint8_t* flag, const float* xc4,
+                         float* e4) {
+  hipLaunchKernelGGL(k_sbmg_prolong, dim3(gridn(nS)), dim3(256), 0, st, nS, par, pw, flag, xc4, e4);
+}
+
 // One Jacobi-Chebyshev sweep on a scalar CSR matrix kept in FP32 (the explicit Schur complement: ~60 entries per row) in a
 // single launch: 16 lanes per row form t = A d_in, lane 0 does  r -= t,  x += d_in,  d_out = c1 d_in + c2 r / a_ii.
 __global__ __launch_bounds__(256) void k_sweep_csr_f32(int64_t n, const int64_t* __restrict__ rowptr,
@@ -954,6 +1103,7 @@ void launch_f32_to_f64(hipStream_t st, int64_t n, const float* a, double* b) {
 // One Chebyshev sweep of the solid block in a single launch: t = A d_in (3x3 block-CSR, 16 lanes per node), then on the
 // first three lanes of the group (one component each)  r -= t,  x += d_in,  d_out = c1 d_in + c2 B^-1 r.
 // d is ping-ponged because other nodes still gather d_in; the product never goes through memory.
+template <int LEVEL>      // LEVEL only names the instantiation: 0 = solid nodes, 1 = coarse level (solid vertices) of the two-level cycle
 __global__ __launch_bounds__(256) void k_sweep_sb_b3(int64_t nS, const int64_t* __restrict__ sb_ptr,
                                                      const int32_t* __restrict__ sb_col, const float* __restrict__ vals,
                                                      const float* __restrict__ binv12, float c1, float c2,
@@ -990,11 +1140,15 @@ __global__ __launch_bounds__(256) void k_sweep_sb_b3(int64_t nS, const int64_t* 
   }
 }
 void launch_sweep_sb_b3(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
-                        const float* binv12, float c1, float c2, const float* din, float* dout, float* x, float* r) {
+                        const float* binv12, float c1, float c2, const float* din, float* dout, float* x, float* r, int level) {
   int64_t blocks = (nS + 15) / 16;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(k_sweep_sb_b3, dim3((unsigned)blocks), dim3(256), 0, st, nS, sb_ptr, sb_col, vals, binv12, c1, c2, din,
-                     dout, x, r);
+  if (level == 0)
+    hipLaunchKernelGGL(k_sweep_sb_b3<0>, dim3((unsigned)blocks), dim3(256), 0, st, nS, sb_ptr, sb_col, vals, binv12, c1, c2, din,
+                       dout, x, r);
+  else
+    hipLaunchKernelGGL(k_sweep_sb_b3<1>, dim3((unsigned)blocks), dim3(256), 0, st, nS, sb_ptr, sb_col, vals, binv12, c1, c2, din,
+                       dout, x, r);
 }
 void launch_sb_binv(hipStream_t st, int64_t nS, const int32_t* snode, const int64_t* diagpos3, const double* Avv,
                     float* binv12, double* binv9) {

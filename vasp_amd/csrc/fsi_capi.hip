@@ -296,6 +296,52 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
       const bool fused = bj && ctx->solid_fused;
       if (fused) HIPCHK(hipMemsetAsync(ft, 0, n * sizeof(float), st));     // second d buffer (ping-pong), pads stay zero
       float *dcur = fd, *dnext = ft;
+      if (fused && ctx->sbmg_ready) {
+        // two-level cycle (see the displacement block): smoothing on [lmax/alpha, lmax], coarse solve on the solid vertices
+        const double slmin = lmax / ctx->sbmg_alpha, sth = 0.5 * (lmax + slmin), sde = 0.5 * (lmax - slmin), ssig = sth / sde;
+        double srho = 1.0 / ssig;
+        launch_cheb_init_b3(st, ctx->nS, frhs, ctx->sb_binv12.p, (float)(1.0 / sth), fx, fr, fd);
+        auto sweep = [&](float c1, float c2, int sample) {
+          const bool timed = sample >= 0 && sample < 8 && ctx->ss_ev0[0];
+          if (timed) (void)hipEventRecord(ctx->ss_ev0[sample], st);
+          launch_sweep_sb_b3(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_col.p, ctx->sb_vals.p, ctx->sb_binv12.p, c1, c2, dcur, dnext, fx, fr);
+          if (timed) (void)hipEventRecord(ctx->ss_ev1[sample], st);
+          std::swap(dcur, dnext);
+        };
+        for (int k = 0; k < ctx->sbmg_pre; ++k) {
+          const double rn = 1.0 / (2.0 * ssig - srho);
+          sweep((float)(rn * srho), (float)(2.0 * rn / sde), k);
+          srho = rn;
+        }
+        const int64_t nc = ctx->sbmg_nc, n4c = 4 * nc;
+        float *cr = ctx->sbmg_work.p, *cd = cr + n4c, *cd2 = cr + 2 * n4c, *cx = cr + 3 * n4c, *crhs = cr + 4 * n4c;
+        launch_sbmg_restrict(st, nc, ctx->sbmg_chptr.p, ctx->sbmg_child.p, ctx->sbmg_chw.p, ctx->snode.p, ctx->rowscale.p,
+                             ctx->sbmg_flag.p, ctx->sbmg_cflag.p, fr, crhs);
+        {
+          const double cl = ctx->sbmg_clmax, clmin = cl / ctx->sbmg_ckappa, cth = 0.5 * (cl + clmin), cde = 0.5 * (cl - clmin), csig = cth / cde;
+          double crho = 1.0 / csig;
+          launch_cheb_init_b3(st, nc, crhs, ctx->sbmg_cbinv12.p, (float)(1.0 / cth), cx, cr, cd);
+          HIPCHK(hipMemsetAsync(cd2, 0, n4c * sizeof(float), st));
+          float *ca = cd, *cb = cd2;
+          for (int k = 0; k < ctx->sbmg_cits; ++k) {
+            const double rn = 1.0 / (2.0 * csig - crho);
+            launch_sweep_sb_b3(st, nc, ctx->sbmg_cptr.p, ctx->sbmg_ccol.p, ctx->sbmg_cvals.p, ctx->sbmg_cbinv12.p, (float)(rn * crho),
+                               (float)(2.0 * rn / cde), ca, cb, cx, cr, 1);
+            std::swap(ca, cb);
+            crho = rn;
+          }
+        }
+        launch_sbmg_prolong(st, ctx->nS, ctx->sbmg_par.p, ctx->sbmg_pw.p, ctx->sbmg_flag.p, cx, dcur);   // correction as the next direction
+        sweep(0.f, (float)(1.0 / sth), -1);                    // x += P x_c, r -= A P x_c, restart the recurrence
+        srho = 1.0 / ssig;
+        for (int k = 0; k < ctx->sbmg_post; ++k) {
+          const double rn = 1.0 / (2.0 * ssig - srho);
+          sweep((float)(rn * srho), (float)(2.0 * rn / sde), -1);
+          srho = rn;
+        }
+        ctx->inner_its[0] += ctx->sbmg_pre + 1 + ctx->sbmg_post - ctx->cheb_its_s;    // counted below as cheb_its_s
+        ctx->ss_samples_pending = ctx->ss_ev0[0] ? std::min(8, ctx->sbmg_pre) : 0;
+      } else
       for (int k = 0; k < ctx->cheb_its_s; ++k) {
         const bool timed = k < 8 && ctx->ss_ev0[0];
         const double rn = 1.0 / (2.0 * sig - rho);
@@ -313,7 +359,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         }
         rho = rn;
       }
-      ctx->ss_samples_pending = ctx->ss_ev0[0] ? std::min(8, ctx->cheb_its_s) : 0;
+      if (!(fused && ctx->sbmg_ready)) ctx->ss_samples_pending = ctx->ss_ev0[0] ? std::min(8, ctx->cheb_its_s) : 0;
       launch_fill(st, xs, n3, 0.0);
       launch_scatter3_f32(st, ctx->nS, ctx->snode.p, fx, xs);
     } else {
@@ -735,6 +781,23 @@ int refresh_preconditioner(FsiCtx* ctx) {
     launch_sb_gather(st, ctx->sb_nblocks, ctx->sb_row.p, ctx->sb_src.p, ctx->sb_stride.p, ctx->Mvv.vals.p, ctx->sb_vals.p);
     launch_sb_dinv(st, ctx->nS, ctx->snode.p, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->sb_dinv.p);
     launch_sb_binv(st, ctx->nS, ctx->snode.p, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->sb_binv12.p, ctx->sb_binv9.p);
+    ctx->sbmg_ready = false;
+    if (ctx->solid_mg && ctx->sbmg_nc > 0 && ctx->solid_fp32 && ctx->solid_block_jacobi && ctx->solid_fused) {
+      HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
+      HIPCHK(hipMemsetAsync(ctx->sbmg_cvals.p, 0, 9 * ctx->sbmg_nblk * sizeof(float), st));
+      launch_sbmg_flags(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_col.p, ctx->sb_vals.p, ctx->sbmg_flag.p);
+      launch_sbmg_rap(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_col.p, ctx->sb_vals.p, ctx->snode.p, ctx->rowscale.p, ctx->sbmg_flag.p,
+                      ctx->sbmg_par.p, ctx->sbmg_pw.p, ctx->sbmg_cptr.p, ctx->sbmg_ccol.p, ctx->sbmg_cvals.p, ctx->iflags.p);
+      launch_sbmg_coarse_finish(st, ctx->sbmg_nc, ctx->sbmg_cptr.p, ctx->sbmg_ccol.p, ctx->sbmg_cvals.p, ctx->sbmg_cfine.p,
+                                ctx->sbmg_flag.p, ctx->sbmg_cbinv12.p, ctx->sbmg_cflag.p, ctx->iflags.p + 2);
+      HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
+      float rowmax;
+      std::memcpy(&rowmax, &flags[2], sizeof rowmax);
+      ctx->sbmg_ready = !(flags[1] & 64) && std::isfinite(rowmax) && rowmax > 0.f;
+      ctx->sbmg_clmax = rowmax;
+      HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
+      if (getenv("FSI_DEBUG")) fprintf(stderr, "[fsi] solid two-level: %lld coarse nodes, clmax %.3f, ready %d\n", (long long)ctx->sbmg_nc, rowmax, (int)ctx->sbmg_ready);
+    }
     if (ctx->solid_block_jacobi && ctx->solid_fp32) {      // largest eigenvalue of D_b^-1 A_SS (power iteration, as power_lmax_op)
       const CsrRef M = ss_ref(ctx);
       double *x = ctx->blk.p, *y = ctx->blk.p + M.n, lam = 1.0;
@@ -853,6 +916,9 @@ int fsi_destroy(FsiCtx* ctx) {
   for (auto* b : i32) b->release();
   DevBuf<int64_t>* i64[] = {&ctx->nadj_ptr, &ctx->padj_ptr, &ctx->rowptr, &ctx->diagpos, &ctx->rb_pos};
   for (auto* b : i64) b->release();
+  ctx->sbmg_par.release(); ctx->sbmg_ccol.release(); ctx->sbmg_child.release(); ctx->sbmg_cfine.release(); ctx->sbmg_pw.release();
+  ctx->sbmg_chw.release(); ctx->sbmg_cvals.release(); ctx->sbmg_cbinv12.release(); ctx->sbmg_work.release(); ctx->sbmg_cptr.release();
+  ctx->sbmg_chptr.release(); ctx->sbmg_flag.release(); ctx->sbmg_cflag.release();
   ctx->s_vals32.release(); ctx->s_dinv32.release(); ctx->s_work32.release();
   ctx->fs_rows.release(); ctx->fs_col.release(); ctx->fs_ptr.release(); ctx->fs_src.release();
   ctx->mg_par.release(); ctx->mg_ccol.release(); ctx->mg_child.release(); ctx->mg_cfine.release(); ctx->mg_pw.release();
@@ -1231,6 +1297,9 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
           sb_ptr[i + 1] = (int64_t)sb_col.size();
         }
         ctx->sb_nblocks = (int64_t)sb_col.size();
+        ctx->h_sb_ptr = sb_ptr;
+        ctx->h_sb_col = sb_col;
+        ctx->h_snode = snode;
         FSICHK(upload(ctx, ctx->sb_ptr, sb_ptr));
         FSICHK(upload(ctx, ctx->sb_src, sb_src));
         FSICHK(upload(ctx, ctx->sb_col, sb_col));
@@ -1434,6 +1503,70 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
         std::vector<float> cones(4 * (size_t)nc, 1.0f);
         for (int64_t i = 0; i < nc; ++i) cones[4 * i + 3] = 0.0f;
         FSICHK(upload(ctx, ctx->mg_cones, cones));
+        // the same hierarchy on the compact solid numbering (3x3-block operator of the velocity predictor)
+        if (const char* e = getenv("FSI_SOLID_MG")) ctx->solid_mg = atoi(e);
+        if (const char* e = getenv("FSI_SBMG_PRE")) ctx->sbmg_pre = atoi(e);
+        if (const char* e = getenv("FSI_SBMG_POST")) ctx->sbmg_post = atoi(e);
+        if (const char* e = getenv("FSI_SBMG_CITS")) ctx->sbmg_cits = atoi(e);
+        if (const char* e = getenv("FSI_SBMG_ALPHA")) ctx->sbmg_alpha = atof(e);
+        if (const char* e = getenv("FSI_SBMG_CKAPPA")) ctx->sbmg_ckappa = atof(e);
+        const int64_t nS = ctx->nS;
+        if (ctx->solid_mg && nS > 0) {
+          std::vector<int32_t> sidx2(N2, -1), scidx(nS, -1), scfine;
+          for (int64_t i = 0; i < nS; ++i) sidx2[ctx->h_snode[i]] = (int32_t)i;
+          for (int64_t i = 0; i < nS; ++i)
+            if (ctx->h_rank2node[ctx->h_snode[i]] < V) { scidx[i] = (int32_t)scfine.size(); scfine.push_back((int32_t)i); }
+          const int64_t nsc = (int64_t)scfine.size();
+          std::vector<int32_t> spar(2 * (size_t)nS);
+          std::vector<float> spw(2 * (size_t)nS);
+          std::vector<int64_t> schptr(nsc + 1, 0);
+          bool sok = nsc > 0;
+          for (int64_t i = 0; i < nS && sok; ++i) {
+            const int32_t nd = ctx->h_rank2node[ctx->h_snode[i]];
+            if (nd < V) { spar[2 * i] = spar[2 * i + 1] = scidx[i]; spw[2 * i] = 1.f; spw[2 * i + 1] = 0.f; schptr[scidx[i] + 1] += 1; }
+            else {
+              const int32_t ia = sidx2[rk[ends[2 * (size_t)nd]]], ib = sidx2[rk[ends[2 * (size_t)nd + 1]]];
+              if (ia < 0 || ib < 0 || scidx[ia] < 0 || scidx[ib] < 0) { sok = false; break; }   // an end vertex outside the solid set
+              spar[2 * i] = scidx[ia]; spar[2 * i + 1] = scidx[ib];
+              spw[2 * i] = spw[2 * i + 1] = 0.5f;
+              schptr[scidx[ia] + 1] += 1; schptr[scidx[ib] + 1] += 1;
+            }
+          }
+          if (sok) {
+            for (int64_t i = 0; i < nsc; ++i) schptr[i + 1] += schptr[i];
+            std::vector<int32_t> schild(schptr[nsc]);
+            std::vector<float> schw(schptr[nsc]);
+            std::vector<int64_t> sfill(schptr.begin(), schptr.end() - 1);
+            for (int64_t i = 0; i < nS; ++i)
+              for (int k = 0; k < 2; ++k)
+                if (spw[2 * i + k] != 0.f) { const int64_t pos = sfill[spar[2 * i + k]]++; schild[pos] = (int32_t)i; schw[pos] = spw[2 * i + k]; }
+            std::vector<int64_t> scptr(nsc + 1, 0);
+            std::vector<int32_t> sccol;
+            for (int64_t I = 0; I < nsc; ++I) {
+              const int64_t i = scfine[I];
+              for (int64_t b = ctx->h_sb_ptr[i]; b < ctx->h_sb_ptr[i + 1]; ++b)
+                if (scidx[ctx->h_sb_col[b]] >= 0) sccol.push_back(scidx[ctx->h_sb_col[b]]);
+              scptr[I + 1] = (int64_t)sccol.size();
+            }
+            ctx->sbmg_nc = nsc;
+            ctx->sbmg_nblk = (int64_t)sccol.size();
+            FSICHK(upload(ctx, ctx->sbmg_par, spar));
+            FSICHK(upload(ctx, ctx->sbmg_pw, spw));
+            FSICHK(upload(ctx, ctx->sbmg_chptr, schptr));
+            FSICHK(upload(ctx, ctx->sbmg_child, schild));
+            FSICHK(upload(ctx, ctx->sbmg_chw, schw));
+            FSICHK(upload(ctx, ctx->sbmg_cptr, scptr));
+            FSICHK(upload(ctx, ctx->sbmg_ccol, sccol));
+            FSICHK(upload(ctx, ctx->sbmg_cfine, scfine));
+            HIPCHK(ctx->sbmg_cvals.alloc(9 * sccol.size()));
+            HIPCHK(ctx->sbmg_cbinv12.alloc(12 * nsc));
+            HIPCHK(ctx->sbmg_flag.alloc(nS));
+            HIPCHK(ctx->sbmg_cflag.alloc(nsc));
+            HIPCHK(ctx->sbmg_work.alloc(5 * 4 * nsc));
+          } else {
+            ctx->solid_mg = 0;
+          }
+        }
       } else {
         ctx->dd_mg = 0;
       }

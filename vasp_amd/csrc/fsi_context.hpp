@@ -185,6 +185,18 @@ struct FsiCtx {
   fsi::DevBuf<float> sb_vals, sb_dinv;
   int solid_fp32 = 1;
   int solid_block_jacobi = 1;                // 3x3 node-block scaling of the solid sweeps (FSI_SOLID_BJ=0: point Jacobi)
+  // two-level solve of the solid velocity block (3x3-block version of the displacement cycle); FSI_SOLID_MG=0: 300 one-level sweeps
+  int solid_mg = 1;
+  bool sbmg_ready = false;
+  int64_t sbmg_nc = 0, sbmg_nblk = 0;
+  std::vector<int32_t> h_snode, h_sb_col;    // host copies for the hierarchy set-up
+  std::vector<int64_t> h_sb_ptr;
+  fsi::DevBuf<int32_t> sbmg_par, sbmg_ccol, sbmg_child, sbmg_cfine;
+  fsi::DevBuf<float> sbmg_pw, sbmg_chw, sbmg_cvals, sbmg_cbinv12, sbmg_work;
+  fsi::DevBuf<int64_t> sbmg_cptr, sbmg_chptr;
+  fsi::DevBuf<uint8_t> sbmg_flag, sbmg_cflag;
+  int sbmg_pre = 16, sbmg_post = 16, sbmg_cits = 200;
+  double sbmg_alpha = 200.0, sbmg_ckappa = 4000.0, sbmg_clmax = 2.0;
   int64_t nfs = 0;                           // fluid-interior velocity rows with solid columns (coupling of the predictor)
   fsi::DevBuf<int32_t> fs_rows, fs_col;
   fsi::DevBuf<int64_t> fs_ptr, fs_src;

@@ -146,8 +146,20 @@ void launch_csr_dinv_f32(hipStream_t st, int64_t n, const int64_t* diagpos, cons
 void launch_cheb_init_plain_f32(hipStream_t st, int64_t n, const double* rhs, const float* dinv, float inv_theta, float* x,
                                 float* r, float* d, float* d2);
 void launch_f32_to_f64(hipStream_t st, int64_t n, const float* a, double* b);
+void launch_sbmg_flags(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals, uint8_t* flag);
+void launch_sbmg_rap(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
+                     const int32_t* snode, const double* rowscale, const uint8_t* flag, const int32_t* par, const float* pw,
+                     const int64_t* cptr, const int32_t* ccol, float* cvals, int32_t* flags);
+void launch_sbmg_coarse_finish(hipStream_t st, int64_t nc, const int64_t* cptr, const int32_t* ccol, float* cvals,
+                               const int32_t* cfine, const uint8_t* flag, float* cbinv12, uint8_t* cflag, int32_t* rowmax_bits);
+void launch_sbmg_restrict(hipStream_t st, int64_t nc, const int64_t* chptr, const int32_t* child, const float* chw,
+                          const int32_t* snode, const double* rowscale, const uint8_t* flag, const uint8_t* cflag,
+                          const float* r4, float* rc4);
+void launch_sbmg_prolong(hipStream_t st, int64_t nS, const int32_t* par, const float* pw, const uint8_t* flag, const float* xc4,
+                         float* e4);
 void launch_sweep_sb_b3(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
-                        const float* binv12, float c1, float c2, const float* din, float* dout, float* x, float* r);
+                        const float* binv12, float c1, float c2, const float* din, float* dout, float* x, float* r,
+                        int level = 0);
 void launch_cheb_step_b3(hipStream_t st, int64_t nS, const float* t, const float* binv12, float c1, float c2, float* x, float* r, float* d);
 void launch_sb_gather(hipStream_t st, int64_t nb, const int32_t* sb_row, const int64_t* sb_src, const int32_t* sb_stride,
                       const double* Avv, float* vals);
