@@ -189,7 +189,11 @@ def main():
                   # fused sweep: per node also r, x (read + write), d_out (write) as float4 and the 3x3 scaling block
                   + (tm["solid_rows"] / 3 * (5 * 16.0 + 48.0) if solid_fused else 0.0)) if solid_fp32
                  else (tm["solid_nnz"] * 12.0 + tm["solid_rows"] * 16.0 + (tm["solid_rows"] + 1) * 8.0)),
-            "k_spmv<0> (monolithic Jacobian, CSR f64 + i32)": (tm["spmv_ms"], tm["spmv_calls"], nnz * 12.0 + ndof_rank * 16.0 + (ndof_rank + 1) * 8.0),
+            # node-blocked product: the six rows of a node share one column index per entry column (b_i = 4/6 B per entry)
+            ("k_spmv_node6 (monolithic Jacobian, f64 values, one i32 column per six entries; + k_spmv<0> on the pressure rows)"
+             if not os.environ.get("FSI_SPMV_GENERIC") else "k_spmv<0> (monolithic Jacobian, CSR f64 + i32)"):
+                (tm["spmv_ms"], tm["spmv_calls"],
+                 nnz * (8.0 + (4.0 / 6.0 if not os.environ.get("FSI_SPMV_GENERIC") else 4.0)) + ndof_rank * 16.0 + (ndof_rank + 1) * 8.0),
             "k_residual (element residual + scatter-add)": (tm["residual_ms"], tm["residual_calls"], C_rank * 1676.0),
             "k_jacobian<nonlinear> (element Jacobian + scatter-add)": (tm["jacobian_ms"], tm["jacobian_calls"], C_rank * 33420.0),
         }

@@ -552,7 +552,10 @@ int spmv(FsiCtx* ctx, const double* x, double* y) {
   // FSI_SPMV_MONO=1: column-array-free variant (8.7 instead of 12 bytes per entry); measured SLOWER on MI355X (6.6 vs
   // 5.5 ms at 1.7 G entries: the index chain nadj -> x and the t / 6 outweigh the bytes), so the CSR kernel stays
   static const bool generic = getenv("FSI_SPMV_MONO") == nullptr;
-  if (generic)
+  static const bool node6 = getenv("FSI_SPMV_GENERIC") == nullptr;
+  if (generic && node6)
+    launch_spmv_node6(ctx->stream, ctx->N2, ctx->V, ctx->rowptr.p, ctx->cols.p, ctx->A.p, x, y);
+  else if (generic)
     launch_spmv(ctx->stream, ctx->ndof, ctx->rowptr.p, ctx->cols.p, ctx->A.p, x, y, SPMV_MONOLITHIC);
   else
     launch_spmv_mono(ctx->stream, ctx->ndof, ctx->N2, ctx->rowptr.p, ctx->nadj_ptr.p, ctx->nadj.p, ctx->padj_ptr.p, ctx->padj.p,

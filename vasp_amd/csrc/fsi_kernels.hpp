@@ -137,6 +137,8 @@ void launch_mg_prolong(hipStream_t st, int64_t N2, const int32_t* par, const flo
                        float* e4);
 void launch_residual_rows(hipStream_t st, int64_t nrows, const int32_t* rows, const int64_t* ptr, const int32_t* col,
                           const int64_t* src, const double* vals, const double* x, const double* b, double* y);
+void launch_spmv_node6(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const double* vals,
+                       const double* x, double* y);
 void launch_spmv_mono(hipStream_t st, int64_t n, int64_t N2, const int64_t* rowptr, const int64_t* nadj_ptr,
                       const int32_t* nadj, const int64_t* padj_ptr, const int32_t* padj, const int32_t* vrank,
                       const double* vals, const double* x, double* y);
