@@ -107,7 +107,7 @@ def main():
         hb = DistBackend(desc, dist, device=local_rank, lin_max_it=int(os.environ.get("VASPFSI_LIN_MAX_IT", 4000)))
     else:
         hb = HipBackend(desc, device=local_rank)
-    ns_cheb = (int(os.environ.get("FSI_CHEB_S", 300)), int(os.environ.get("FSI_CHEB_F", 14)))
+    ns_cheb = (int(os.environ.get("FSI_CHEB_S", 300)), int(os.environ.get("FSI_CHEB_F", 4)))
     solid_fp32 = int(os.environ.get("FSI_SOLID_FP32", 1)) != 0
     solid_fused = solid_fp32 and int(os.environ.get("FSI_SOLID_BJ", 1)) != 0 and int(os.environ.get("FSI_SOLID_FUSED", 1)) != 0
     mesh = ns["mesh"]

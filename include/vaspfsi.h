@@ -109,7 +109,7 @@ int fsi_set_robin_facets(FsiCtx* ctx, int64_t nf, const int32_t* facet_nodes, co
 int fsi_set_linear_solver(FsiCtx* ctx, int32_t precond, double inner_rtol, int32_t inner_max_it);
 /* Sweep counts and assumed condition numbers of the Chebyshev solves inside the block preconditioner (solid and
  * fluid-interior part of the velocity block, pressure Schur complement).  Non-positive arguments keep the current value.
- * Defaults: solid 300 / 1e4, fluid 14 / 50, Schur 40 / 1e2, displacement 60 / 1e3 (one-level fallback; the default
+ * Defaults: solid 300 / 1e4 (one-level fallback; default: two-level cycle), fluid 4 / 5, Schur 40 / 1e2, displacement 60 / 1e3 (one-level fallback; the default
  * displacement solve is the two-level P2 -> P1 cycle: 4 + 8 smoothing sweeps around 40 coarse sweeps). */
 int fsi_set_chebyshev(FsiCtx* ctx, int32_t its_solid, double kappa_solid, int32_t its_fluid, double kappa_fluid,
                       int32_t its_schur, double kappa_schur, int32_t its_disp, double kappa_disp);

@@ -204,8 +204,8 @@ struct FsiCtx {
   fsi::DevBuf<float> sb_binv12;
   fsi::DevBuf<double> sb_binv9;
   fsi::DevBuf<double> mask_s, mask_f;        // [3 N2] 1 on velocity dofs of solid (incl. interface) / fluid-interior nodes
-  int cheb_its_s = 300, cheb_its_f = 14, cheb_its_p = 40, cheb_its_d = 60;     // Chebyshev sweeps on the solid / fluid part of the velocity block
-  double cheb_kappa_s = 1e4, cheb_kappa_f = 50.0, cheb_kappa_p = 100.0, lmax_s = 1.0, lmax_f = 1.0, lmax_p = 1.0, cheb_kappa_d = 1000.0, lmax_d = 1.0;
+  int cheb_its_s = 300, cheb_its_f = 4, cheb_its_p = 40, cheb_its_d = 60;     // Chebyshev sweeps on the solid / fluid part of the velocity block
+  double cheb_kappa_s = 1e4, cheb_kappa_f = 5.0, cheb_kappa_p = 100.0, lmax_s = 1.0, lmax_f = 1.0, lmax_p = 1.0, cheb_kappa_d = 1000.0, lmax_d = 1.0;
   double inner_rtol = 1e-2;
   int inner_maxit = 40, inner_maxit_p = 60;
   int64_t inner_its[3] = {0, 0, 0};          // accumulated inner iterations: vv, schur, dd
