@@ -2,17 +2,23 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--tets T]
 
-One "step" = one time step of the offset-stenosis problem (pre_solve data, quasi-Newton solve through the C-ABI, state
-shift) on a synthetic offset-stenosis mesh of about T tetrahedra (default 1 M = BASELINE.json configs[1]; the mesh comes
-from vasp_amd.meshgen because the reference tree has no mesh of that size).  All inputs are resident in HBM before the
-timed region; the only host<->device traffic inside it is the per-step Dirichlet values and a few scalars.
+One "step" = one time step of the offset-stenosis problem exactly as the product driver runs it
+(``vasp_amd.monolithic.advance``: pre_solve data, quasi-Newton solve through the C-ABI, state shift, post_solve
+diagnostics; only file output is left out) on a synthetic offset-stenosis mesh of about T tetrahedra
+(default 1 M = BASELINE.json configs[1]; the mesh comes from vasp_amd.meshgen because the reference tree has no mesh of
+that size).  All inputs are resident in HBM before the timed region; the host<->device traffic inside it is the per-step
+Dirichlet values, a few scalars per Krylov iteration and the probe / inlet values post_solve prints.
 
-N > 1: the SAME problem is partitioned by elements across the N ranks (vasp_amd/partition.py): every
-rank assembles and solves on the cells of the nodes it owns, one owner->ghost halo exchange and a few scalar all-reduces
-per Krylov iteration go over RCCL; total work is fixed, so `scaling` is "strong" and `value` is the Newton rate of the
-one job.  (VASPFSI_DIST_BACKEND=gloo VASPFSI_ONE_GPU=1 rehearses N ranks on a single card with host-staged exchanges.)
+N > 1: ``python bench.py --gpus N`` starts N ranks itself (``python -m torch.distributed.run``, one per GPU, before
+anything touches a GPU) unless it already runs as one of them (RANK / WORLD_SIZE set by the launcher).  The SAME problem
+is partitioned by elements across the N ranks (vasp_amd/partition.py): every rank assembles and solves on
+the cells of the nodes it owns, one owner->ghost halo exchange and a few scalar all-reduces per Krylov iteration go over
+RCCL; total work is fixed, so `scaling` is "strong" and `value` is the Newton rate of the one job.
+(VASPFSI_DIST_BACKEND=gloo VASPFSI_ONE_GPU=1 rehearses N ranks on a single card with host-staged exchanges.)
 
-Output: ONE JSON line on rank 0 (metric, value, roofline of the dominant kernel, cpu_baseline of the oracle).
+Output: ONE JSON line on rank 0: metric, value, `roofline` of the kernel group with the largest share of GPU time in the
+timed region (orthogonalisation kernels included, their bytes exact from the number of columns streamed), `kernels` (the
+whole table the choice was made from), `cpu_baseline`.
 """
 from __future__ import annotations
 
@@ -21,6 +27,7 @@ import contextlib
 import io
 import json
 import os
+import subprocess
 import sys
 import tempfile
 import time
@@ -34,48 +41,40 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def self_launch(args) -> int:
+    """--gpus N without a launcher: hand over to torch.distributed.run as a CHILD process (this process has not touched
+    a GPU and never will), relay its output and exit code."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--tets", str(args.tets),
+           "--dt", str(args.dt)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def cpu_baseline(budget_s: float = 25.0):
-    """The oracle (numpy restatement, exact sparse LU) timed on the host cores on a bounded sample: the cylinder
-    fixture (1 647 tets, 15 352 dofs), quasi-Newton iterations with one Jacobian, until ~budget_s is spent."""
-    from oracle.backend import OracleBackend
-    from vasp_amd.monolithic import prepare
-    with contextlib.redirect_stdout(io.StringIO()):
-        ns, desc, bc_values, pressure, hook = prepare(
-            ["-p", "cylinder", "-dt", "0.001", "-T", "0.1", "--theta", "0.501", "--verbose", "False", "--folder",
-             tempfile.mkdtemp(), "--sub-folder", "1", "--new-arguments",
-             f"mesh_path={ROOT / 'tests' / 'golden' / 'cylinder' / 'cylinder.h5'}"])
-    t0 = time.perf_counter()
-    ob = OracleBackend(desc)            # includes A_pre = assemble(J_linear), as the reference's solver_setup
-    its, step, t = 0, 0, 0.0
-    while time.perf_counter() - t0 < budget_s or its == 0:
-        t += 0.001
-        with contextlib.redirect_stdout(io.StringIO()):
-            ns["t"] = t
-            hook("pre_solve")(**ns)
-        ob.set_dirichlet_values(bc_values())
-        ob.set_interface_pressure(float(pressure.P))
-        hist = ob.newton_solve(counter=step, first_step_num=0, atol=1e-6, rtol=1e-6, max_it=50, lmbda=1.0, recompute=20,
-                               recompute_tstep=20)
-        ob.shift()
-        its += len(hist)
-        step += 1
-    dt = time.perf_counter() - t0
-    ndof = ob.o.ndof
-    return {"value": its / dt, "unit": "Newton-iterations/s", "cores": 1, "kind": "port",
-            "sample": f"oracle (numpy + SuperLU) on the cylinder fixture: 1647 tets, {ndof} dofs, {step} time steps, "
-                      f"{its} Newton iterations in {dt:.1f} s incl. one Jacobian + LU",
-            "dof_updates_per_s": its * ndof / dt}
+    """The CPU port of the same algorithm (oracle/: C element routines under OpenMP for the assembly, exact sparse LU
+    for the solve - the reference's own linear solver is a direct LU, MUMPS) timed on the host cores on a bounded sample
+    of the bench workload: the same offset-stenosis problem on a mesh of the same generator, sized so that the run takes
+    about ``budget_s``."""
+    from oracle.cpu_port import timed_newton_run
+    return timed_newton_run(budget_s)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)       # BASELINE.json configs[1]: 20 time steps (one Jacobian lifetime)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--tets", type=int, default=int(os.environ.get("VASPFSI_BENCH_TETS", 1000000)))
     ap.add_argument("--dt", type=float, default=1e-3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     from vasp_amd.dist import aggregate, init_from_env
@@ -90,7 +89,7 @@ def main():
 
     from vasp_amd.capi import HipBackend
     from vasp_amd.meshgen import write_mesh
-    from vasp_amd.monolithic import prepare
+    from vasp_amd.monolithic import advance, prepare
 
     tmp = Path(tempfile.mkdtemp(prefix=f"vaspfsi_bench_r{rank}_"))
     mesh_path = tmp / "stenosis.h5"
@@ -107,22 +106,22 @@ def main():
         hb = DistBackend(desc, dist, device=local_rank, lin_max_it=int(os.environ.get("VASPFSI_LIN_MAX_IT", 4000)))
     else:
         hb = HipBackend(desc, device=local_rank)
+    for which, fn in ns["dvp_"].items():          # post_solve diagnostics run on the device, as in monolithic.run
+        fn.backend, fn.which = hb, which
+    ns["backend"] = hb
     ns_cheb = (int(os.environ.get("FSI_CHEB_S", 300)), int(os.environ.get("FSI_CHEB_F", 4)))
     solid_fp32 = int(os.environ.get("FSI_SOLID_FP32", 1)) != 0
     solid_fused = solid_fp32 and int(os.environ.get("FSI_SOLID_BJ", 1)) != 0 and int(os.environ.get("FSI_SOLID_FUSED", 1)) != 0
     mesh = ns["mesh"]
     setup_s = time.perf_counter() - t_setup
-    newton = dict(atol=ns["atol"], rtol=ns["rtol"], max_it=ns["max_it"], lmbda=ns["lmbda"], recompute=ns["recompute"],
-                  recompute_tstep=ns["recompute_tstep"])
+    sink = io.StringIO()
 
-    def one_step(counter, t):
-        with contextlib.redirect_stdout(io.StringIO()):
-            ns["t"] = t
-            hook("pre_solve")(**ns)
-        hb.set_dirichlet_values(bc_values())
-        hb.set_interface_pressure(float(pressure.P))
-        hist = hb.newton_solve(counter=counter, first_step_num=0, **newton)
-        hb.shift()
+    def one_step():
+        with contextlib.redirect_stdout(sink):       # the log lines of pre_solve / post_solve are produced, not shown
+            hist = advance(ns, hb, bc_values, pressure, hook, 0, out=lambda *a: None)
+        ns["counter"] += 1
+        sink.seek(0)
+        sink.truncate()
         return hist
 
     def barrier():
@@ -130,19 +129,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    t, counter = 0.0, 0
     for _ in range(args.warmup):
-        t += args.dt
-        one_step(counter, t)
-        counter += 1
+        one_step()
     hb.timers(reset=True)
     barrier()
     t0 = time.perf_counter()
     n_newton, n_krylov = 0, 0
     for _ in range(args.steps):
-        t += args.dt
-        hist = one_step(counter, t)
-        counter += 1
+        hist = one_step()
         n_newton += len(hist)
         n_krylov += sum(h[3] for h in hist)
     barrier()
@@ -159,7 +153,8 @@ def main():
         C = mesh.num_cells
         C_rank = len(hb.part.cells) if partitioned else C       # the kernels of this rank run on its local cells / rows
         ndof_rank = hb.part.ndof if partitioned else ndof
-        # algorithmic bytes per launch of each timed kernel
+        # ---- per kernel group: (GPU time attributed in the timed region [ms], launches, algorithmic bytes per launch) ----
+        # (sweep kernels: average of sampled HIP-event launches x launches, the rest: every launch timed)
         f_launches = tm["precond_applies"] * ns_cheb[1]                                # fluid velocity sweeps
         sweeps = max(0, tm["inner_vv_iters"] - f_launches)                              # fine-level solid sweeps
         ss_avg = tm["solid_spmv_ms"] / max(1, tm["solid_spmv_calls"])
@@ -168,58 +163,86 @@ def main():
         db_launches = f_launches + (0 if scalar else tm["inner_dd_iters"])
         sc_avg = tm["sc_spmv_ms"] / max(1, tm["sc_spmv_calls"])
         sc_launches = tm["inner_dd_iters"] if scalar else 0
-        # per launch: values (+ 2-byte LDS index or 4-byte column) per pair, the vector once (tiled: once per tile
-        # entry, 16 B + 4 B index), row pointers, flags and the float4 result per node
+        sch_avg = tm["schur_ms"] / max(1, tm["schur_calls"])
         sc_bytes = (tm["db_pairs"] * 6.0 + tm["tile_entries"] * 20.0 + tm["db_nodes"] * 27.0) if tiled else \
                    (tm["db_pairs"] * 8.0 + tm["db_nodes"] * 43.0)
         dbf_bytes = (tm["db_pairs"] * 14.0 + tm["tile_entries"] * 20.0 + tm["db_nodes"] * 24.0) if tiled else \
                     (tm["db_pairs"] * 16.0 + tm["db_nodes"] * 40.0)
+        qb = tm["q_elem_bytes"]
+        # orthogonalisation: every launch of k_gcr_dots / k_gcr_axpy streams m columns of Q (ld * qb bytes each) plus
+        # w (read, and written by the update) and r; the exact column count is kept by the library
+        q_launches = max(1, tm["ortho_q_launches"])
+        q_bytes = (tm["ortho_q_cols"] * tm["ldq"] * qb) / q_launches + ndof_rank * 20.0
+        z_launches = max(1, tm["ortho_z_launches"])
+        z_bytes = (tm["ortho_z_cols"] * tm["ldz"] * 8.0) / z_launches + ndof_rank * 24.0
+        generic = bool(os.environ.get("FSI_SPMV_GENERIC"))
         kernels = {
+            f"k_gcr_dots + k_gcr_axpy (Gram-Schmidt against the kept directions: Q in FP{8 * qb} streamed once per launch, "
+            f"mean {tm['ortho_q_cols'] / q_launches:.0f} columns)":
+                (tm["ortho_ms"], int(tm["ortho_q_launches"]), q_bytes),
+            f"k_gcr_flush (x and the new directions from the direction store, mean {tm['ortho_z_cols'] / z_launches:.0f} columns)":
+                (tm["flush_ms"], int(tm["ortho_z_launches"]), z_bytes),
             ("k_spmv_tiled_f32<1>" if tiled else "k_spmv_sc_f32") + " (displacement block sweeps: one FP32 ratio per node pair"
             + (", neighbour vector entries staged in LDS" if tiled else "") + "; avg from sampled HIP events)":
                 (sc_avg * sc_launches, int(sc_launches), sc_bytes),
             ("k_spmv_tiled_f32<3>" if tiled else "k_spmv_db_f32") + " (fluid velocity block sweeps, FP32 component-diagonal node blocks; avg from sampled HIP events)":
                 (db_avg * db_launches, int(db_launches), dbf_bytes),
-            # (time attributed in the timed region [ms], launches, algorithmic bytes per launch, avg launch [ms])
             (("k_sweep_sb_b3<0> (solid velocity block, fine level: FP32 3x3 block-CSR product fused with the Chebyshev update; avg from sampled HIP events)"
               if solid_fused else "k_spmv_sb (solid velocity block, FP32 3x3 block-CSR, Chebyshev sweeps; avg from sampled HIP events)")
              if solid_fp32 else "k_spmv<1> (solid velocity block, CSR f64, Chebyshev sweeps; avg from sampled HIP events)"):
                 (ss_avg * sweeps, int(sweeps),
                  (tm["solid_nnz"] * 4.0 + tm["solid_nnz"] / 9 * 4.0 + tm["solid_rows"] * 8.0 + (tm["solid_rows"] / 3 + 1) * 8.0
-                  # fused sweep: per node also r, x (read + write), d_out (write) as float4 and the 3x3 scaling block
                   + (tm["solid_rows"] / 3 * (5 * 16.0 + 48.0) if solid_fused else 0.0)) if solid_fp32
                  else (tm["solid_nnz"] * 12.0 + tm["solid_rows"] * 16.0 + (tm["solid_rows"] + 1) * 8.0)),
-            # node-blocked product: the six rows of a node share one column index per entry column (b_i = 4/6 B per entry)
+            "Schur-complement sweep (explicit two-ring pressure matrix: product + Chebyshev update; avg from sampled HIP events)":
+                (sch_avg * tm["inner_schur_iters"], int(tm["inner_schur_iters"]),
+                 tm["schur_nnz"] * (tm["schur_elem_bytes"] + 4.0) + tm["schur_rows"] * 8.0 * 5),
             ("k_spmv_node6 (monolithic Jacobian, f64 values, one i32 column per six entries; + k_spmv<0> on the pressure rows)"
-             if not os.environ.get("FSI_SPMV_GENERIC") else "k_spmv<0> (monolithic Jacobian, CSR f64 + i32)"):
+             if not generic else "k_spmv<0> (monolithic Jacobian, CSR f64 + i32)"):
                 (tm["spmv_ms"], tm["spmv_calls"],
-                 nnz * (8.0 + (4.0 / 6.0 if not os.environ.get("FSI_SPMV_GENERIC") else 4.0)) + ndof_rank * 16.0 + (ndof_rank + 1) * 8.0),
+                 nnz * (8.0 + (4.0 / 6.0 if not generic else 4.0)) + ndof_rank * 16.0 + (ndof_rank + 1) * 8.0),
             "k_residual (element residual + scatter-add)": (tm["residual_ms"], tm["residual_calls"], C_rank * 1676.0),
             "k_jacobian<nonlinear> (element Jacobian + scatter-add)": (tm["jacobian_ms"], tm["jacobian_calls"], C_rank * 33420.0),
         }
-        dom = max(kernels, key=lambda k: kernels[k][0])
-        ms, calls, nbytes = kernels[dom]
-        achieved = nbytes / (ms / max(calls, 1) * 1e-3) / 1e9 if ms > 0 else 0.0
+        table = {}
+        for name, (ms, calls, nbytes) in kernels.items():
+            ach = nbytes / (ms / max(calls, 1) * 1e-3) / 1e9 if ms > 0 and calls > 0 else 0.0
+            table[name] = {"gpu_ms": ms, "launches": int(calls), "avg_launch_ms": ms / max(calls, 1),
+                           "algorithmic_bytes_per_launch": nbytes, "achieved_GBps": ach, "frac_of_hbm_peak": ach / HBM_PEAK_GBS,
+                           "share_of_timed_region": ms / (1e3 * elapsed)}
+        dom = max(table, key=lambda k: table[k]["gpu_ms"])
+        d = table[dom]
+        traffic = None
+        pmc = ROOT / "profiles" / "r02_pmc_traffic.json"       # corrected FETCH_SIZE + WRITE_SIZE per launch (tools/pmc_traffic.py)
+        if pmc.exists():
+            with contextlib.suppress(Exception):
+                for key, val in json.loads(pmc.read_text()).get("per_launch_bytes", {}).items():
+                    if dom.startswith(key):
+                        traffic = val
         out = {
             "metric": "Newton-iterations/sec (offset_stenosis, monolithic ALE-FSI step)",
             "value": total_newton / elapsed, "unit": "Newton-iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak",
+            "scaling": "strong",       # one problem of fixed size, partitioned over the N ranks
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"offset_stenosis synthetic mesh, {C} tets, {ndof} dofs, dt={args.dt}, theta=0.501, "
-                                   f"quasi-Newton atol=rtol=1e-6 recompute_tstep={ns['recompute_tstep']}",
+                                   f"quasi-Newton atol=rtol=1e-6 recompute_tstep={ns['recompute_tstep']}, "
+                                   f"per step: pre_solve, Newton solve, shift, post_solve (no file output)",
                        "tets": C, "dofs": ndof, "matrix_nnz": nnz, "parallelism": (f"element partition over {world} ranks (node slabs, ghost-layer cells {C_all / C - 1:.1%}), "
                                        f"halo + all-reduce over {dist.get_backend()}") if partitioned else "1 GPU",
-                       "rank0_matrix_nnz": nnz},
+                       "rank0_matrix_nnz": nnz, "krylov_storage": f"Q FP{8 * qb}, directions FP64, capacity {tm['krylov_cap']}"},
             "dof_updates_per_s": total_newton * ndof / elapsed,
             "newton_iterations": n_newton, "krylov_iterations": n_krylov,
-            "phase_ms": {k: tm[k] for k in ("residual_ms", "jacobian_ms", "factor_ms", "spmv_ms", "precond_ms", "ortho_ms", "krylov_ms")},
+            "phase_ms": {k: tm[k] for k in ("residual_ms", "jacobian_ms", "factor_ms", "spmv_ms", "precond_ms", "ortho_ms", "flush_ms", "krylov_ms")},
             "phase_calls": {k: tm[k] for k in ("residual_calls", "jacobian_calls", "factor_calls", "spmv_calls", "precond_calls",
-                                               "krylov_solves", "krylov_iters", "inner_vv_iters", "inner_schur_iters", "inner_dd_iters")},
+                                               "krylov_solves", "krylov_iters", "inner_vv_iters", "inner_schur_iters", "inner_dd_iters",
+                                               "ortho_q_launches", "ortho_q_cols", "ortho_z_launches", "ortho_z_cols")},
             "setup_s": setup_s,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": calls,
-                         "avg_launch_ms": ms / max(calls, 1), "algorithmic_bytes_per_launch": nbytes},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": d["frac_of_hbm_peak"], "traffic": traffic, "launches": d["launches"],
+                         "avg_launch_ms": d["avg_launch_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                         "share_of_timed_region": d["share_of_timed_region"]},
+            "kernels": table,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

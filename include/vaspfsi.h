@@ -156,6 +156,10 @@ int fsi_set_partition(FsiCtx* ctx, int64_t num_owned_cells, int64_t n_ghost, con
 /* which: 0 = dvp_["n"], 1 = dvp_["n-1"], 2 = last rhs b, 3 = last update du.  User layout, length ndof. */
 int fsi_get_state(FsiCtx* ctx, int which, double* out);
 int fsi_set_state(FsiCtx* ctx, int which, const double* in);
+/* out[i] = state[dofs[i]] (user layout): what a hook needs of dvp_ on a patch (the inlet facets of
+ * assemble(inner(v, n) * ds(inlet)) [REF src/vasp/simulations/simulation_common.py:276]) without the whole vector
+ * crossing PCIe every time step. */
+int fsi_get_values(FsiCtx* ctx, int which, int64_t n, const int64_t* dofs, double* out);
 int64_t fsi_num_dofs(const FsiCtx* ctx);
 int64_t fsi_matrix_nnz(const FsiCtx* ctx);
 /* Copies the assembled matrix out in user-layout row/column numbering (CSR, rows sorted).  rowptr [ndof+1],
@@ -193,6 +197,17 @@ typedef struct FsiTimers {
   double sc_spmv_ms;     int64_t sc_spmv_calls;      /* sampled launches of the scalar-ratio displacement SpMV        */
   int64_t disp_scalar;                               /* bit 0: displacement sweeps use that kernel; bit 1: LDS-tiled  */
   int64_t tile_entries;                              /* total length of the per-tile distinct-neighbour lists         */
+  /* orthogonalisation of the recycled GCR: columns of Q / of the direction store streamed since the last reset, and the
+     number of launches that streamed them (bytes = columns x ld x element size; see csrc/fsi_gcr.hip)                 */
+  int64_t ortho_q_cols;  int64_t ortho_q_launches;
+  int64_t ortho_z_cols;  int64_t ortho_z_launches;
+  int64_t q_elem_bytes;                              /* 4: Q stored in FP32, 8: FP64                                   */
+  int64_t ldq;           int64_t ldz;                /* column strides of Q and of the direction store (elements)     */
+  int64_t krylov_dirs;   int64_t krylov_cap;         /* directions currently kept / capacity                          */
+  int64_t schur_nnz;     int64_t schur_rows;         /* explicit Schur complement                                     */
+  double flush_ms;       int64_t flush_calls;        /* k_gcr_flush (one pass over the direction store per solve)     */
+  double schur_ms;       int64_t schur_calls;        /* sampled launches of the Schur-complement sweep                */
+  int64_t schur_elem_bytes;                          /* 8: FP64 product, 4: FP32 fused sweep                          */
 } FsiTimers;
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
 

@@ -1,0 +1,83 @@
+"""CPU baseline of bench.py: the CPU port of the algorithm, timed on the host cores on a bounded sample of the bench
+workload.
+
+Test infrastructure (only ``bench.py``'s ``cpu_baseline`` leg calls this; nothing here is measured as the product).
+What runs: the offset-stenosis problem file on a mesh of the bench's own generator (``vasp_amd.meshgen``), the reference's
+quasi-Newton policy (``oracle.fsi_oracle.FsiOracle.newtonsolver``) with
+  * residual and Jacobian assembly by the C restatement under OpenMP on all host cores (oracle/fsi_oracle_c.c), and
+  * the linear solve by an exact sparse LU re-used across Newton iterations - what the reference itself does with MUMPS
+    [REF src/vasp/simulations/offset_stenosis.py:44-48] (SuperLU here, one thread).
+The sample is sized so that set-up + time steps take about the budget; throughput is reported in the bench's unit and,
+because the sample is ~150x smaller than the bench mesh, also per degree of freedom.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+
+def timed_newton_run(budget_s: float = 25.0, tets: int = 6500) -> dict:
+    from vasp_amd.meshgen import write_mesh
+    from vasp_amd.monolithic import prepare
+    from .backend import OracleBackend
+    from . import c_oracle
+
+    tmp = Path(tempfile.mkdtemp(prefix="vaspfsi_cpu_baseline_"))
+    write_mesh(tmp / "stenosis.h5", tets, seed=0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ns, desc, bc_values, pressure, hook = prepare(
+            ["-p", "offset_stenosis", "-dt", "0.001", "-T", "1.0", "--theta", "0.501", "--verbose", "False", "--folder",
+             str(tmp / "results"), "--sub-folder", "1", "--new-arguments", f"mesh_path={tmp / 'stenosis.h5'}"])
+    t0 = time.perf_counter()
+    ob = OracleBackend(desc)            # includes A_pre = assemble(J_linear), as the reference's solver_setup
+    kind = "port"
+    its, step, t = 0, 0, 0.0
+    t_first = None
+    while time.perf_counter() - t0 < budget_s or its == 0:
+        t += 0.001
+        with contextlib.redirect_stdout(io.StringIO()):
+            ns["t"] = t
+            hook("pre_solve")(**ns)
+        ob.set_dirichlet_values(bc_values())
+        ob.set_interface_pressure(float(pressure.P))
+        hist = ob.newton_solve(counter=step, first_step_num=0, atol=1e-6, rtol=1e-6, max_it=50, lmbda=1.0, recompute=20,
+                               recompute_tstep=20)
+        ob.shift()
+        its += len(hist)
+        step += 1
+        if t_first is None:
+            t_first = time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    o = ob.o
+    cores = c_oracle.load().fsi_c_num_threads() if o.c is not None else 1
+    # kernel rates of the port on the same sample (all cores): residual assembly and the sparse product
+    U, U1 = ob.U.copy(), ob.U1.copy()
+    ta = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - ta < 1.0:
+        o.residual(U, U1, 0.0)
+        reps += 1
+    res_rate = reps * len(o.tets) / (time.perf_counter() - ta)
+    spmv_gbs = None
+    if o.c is not None and getattr(o, "A", None) is not None:
+        A = o.A.tocsr()
+        x = np.ones(A.shape[0])
+        tb = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - tb < 1.0:
+            o.c.spmv(A, x)
+            reps += 1
+        spmv_gbs = reps * (A.nnz * 12.0 + A.shape[0] * 20.0) / (time.perf_counter() - tb) / 1e9
+    return {"value": its / dt, "unit": "Newton-iterations/s", "cores": int(cores), "kind": kind,
+            "sample": f"offset_stenosis on a {len(o.tets)}-tet mesh of the bench's generator ({o.ndof} dofs), dt=1e-3, theta=0.501, "
+                      f"quasi-Newton atol=rtol=1e-6 recompute_tstep=20: {step} time steps, {its} Newton iterations in {dt:.1f} s "
+                      f"incl. Jacobian assembly + sparse LU every 20 steps (first step {t_first:.1f} s); assembly in C/OpenMP on "
+                      f"{cores} threads, LU/triangular solves SuperLU on 1 thread (the reference's linear solver is a direct LU)",
+            "dof_updates_per_s": its * o.ndof / dt,
+            "residual_assembly_tets_per_s": res_rate, "spmv_GBps": spmv_gbs, "host_cpus": os.cpu_count()}

@@ -141,7 +141,7 @@ class FsiOracle:
     Global dof layout: [d: 3*N2 | v: 3*N2 | p: V], component-minor.
     """
 
-    def __init__(self, desc):
+    def __init__(self, desc, impl: str = "auto"):
         self.D = desc
         self.x = np.asarray(desc["coords"], dtype=float)
         self.tets = np.asarray(desc["tets"])
@@ -171,6 +171,13 @@ class FsiOracle:
         self.cell_dofs = np.concatenate(cols, axis=1)                   # (C,64)
         self.bc_dofs = np.asarray(desc.get("bc_dofs", np.zeros(0, dtype=np.int64)), dtype=np.int64)
         self._facet_setup()
+        # the same element arithmetic in C under OpenMP (oracle/fsi_oracle_c.c), used when its library is there;
+        # ORACLE_IMPL=numpy forces the numpy definition below (tests/test_oracle_c.py holds the two together)
+        self.c = None
+        if impl != "numpy":
+            from . import c_oracle
+            if c_oracle.available():
+                self.c = c_oracle.CElements(self)
 
     # ---- local <-> global -----------------------------------------------------------------------
     def gather(self, U):
@@ -297,6 +304,8 @@ class FsiOracle:
 
     def element_residuals(self, U, U1):
         """(R_linear, R_nonlinear): per-element vectors (C,64)."""
+        if self.c is not None and not np.iscomplexobj(U) and not np.iscomplexobj(U1):
+            return self.c.residuals(np.asarray(U, dtype=float), np.asarray(U1, dtype=float))
         loc, loc1 = self.gather(U), self.gather(U1)
         Rl = np.zeros(loc.shape, dtype=loc.dtype)
         Rn = np.zeros(loc.shape, dtype=loc.dtype)
@@ -307,6 +316,8 @@ class FsiOracle:
 
     def element_jacobians(self, U, U1):
         """(J_linear, J_nonlinear) element matrices (C,64,64) = d R_e / d U^n_e by complex step."""
+        if self.c is not None:
+            return self.c.jacobians(np.asarray(U, dtype=float), np.asarray(U1, dtype=float))
         h = 1e-30
         loc, loc1 = self.gather(U).astype(complex), self.gather(U1).astype(complex)
         C = len(loc)
@@ -394,6 +405,8 @@ class FsiOracle:
         return np.bincount(self.cell_dofs.ravel(), weights=Re.ravel(), minlength=self.ndof)
 
     def assemble_matrix(self, Je):
+        if self.c is not None:
+            return self.c.assemble_matrix(Je)
         rows = np.repeat(self.cell_dofs[:, :, None], 64, axis=2).ravel()
         cols = np.repeat(self.cell_dofs[:, None, :], 64, axis=1).ravel()
         A = sp.coo_matrix((Je.ravel(), (rows, cols)), shape=(self.ndof, self.ndof)).tocsr()

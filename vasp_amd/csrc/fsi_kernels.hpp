@@ -60,9 +60,21 @@ void launch_spmv(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t
                  const double* x, double* y, int tag = SPMV_FIELD_BLOCK);
 // reductions: out[0] = x.y (deterministic two-stage); scratch must hold >= 4096 doubles
 void launch_dot(hipStream_t st, const double* x, const double* y, int64_t n, double* scratch, double* out);
-// h[i] = Q_i . w for i < m  (Q stored as m contiguous vectors of length n); then w -= sum_i h[i] Q_i
-void launch_multi_dot(hipStream_t st, const double* Q, int64_t n, int m, const double* w, double* scratch, double* h);
-void launch_multi_axpy(hipStream_t st, const double* Q, int64_t n, int m, const double* h, double sign, double* w);
+// fsi_gcr.hip — orthogonalisation against the kept directions of the recycled GCR (Q in FP32 or FP64, see there)
+// out[k] = Q_k . w (k < m), out[m] = w . w, out[m+1] = w . r (r may be null); scratch >= (m + 2) * 64 doubles
+void launch_gcr_dots(hipStream_t st, bool fp32, const void* Q, int64_t ldq, int64_t n, int m, const double* w,
+                     const double* r, double* scratch, double* out);
+// w -= sum_k h[k] Q_k; out2[0] = |w'|^2, out2[1] = w' . r
+void launch_gcr_axpy(hipStream_t st, bool fp32, const void* Q, int64_t ldq, int64_t n, int m, const double* h, double* w,
+                     const double* r, double* scratch, double* out2);
+// Q_slot = qd = w * inv_wn, Z_slot = z, r -= alpha w * inv_wn; out1[0] = |r'|^2
+void launch_gcr_update(hipStream_t st, bool fp32, void* Q, int64_t ldq, double* Z, int64_t ldz, int slot, int64_t n,
+                       const double* w, const double* z, double inv_wn, double alpha, double* r, double* qd,
+                       double* scratch, double* out1);
+// x += sum_j y[j] Z_j; Z_slots[k] = sum_j cn[k * m + j] Z_j for k < knew (<= 32); cn has gcr_flush_width(knew) columns
+int gcr_flush_width(int knew);
+void launch_gcr_flush(hipStream_t st, double* Z, int64_t ldz, int64_t n, int m, const double* y, const double* cn,
+                      const int32_t* slots, int knew, double* x);
 // incomplete factorisation and triangular solves, colour by colour (fsi_solver.hip)
 void launch_ilu0_levels(hipStream_t st, const std::vector<Level>& levels, const int64_t* rowptr, const int32_t* cols,
                         const int64_t* diagpos, double* LU, int32_t* counters);

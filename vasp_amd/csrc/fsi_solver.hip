@@ -312,67 +312,6 @@ void launch_dot(hipStream_t st, const double* x, const double* y, int64_t n, dou
   hipLaunchKernelGGL(k_dot_partial, dim3(np), dim3(256), 0, st, x, y, n, scratch);
   hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, st, scratch, np, np, out);
 }
-// Gram-Schmidt against the m kept directions: both kernels stream m n doubles and are bound by how many loads a wave
-// keeps in flight, so a block takes FOUR directions per pass over w (one w load feeds four products) and the update
-// unrolls eight directions with independent loads.
-__global__ __launch_bounds__(256) void k_multi_dot_partial(const double* __restrict__ Q, int64_t n, int m,
-                                                           const double* __restrict__ w, double* __restrict__ part) {
-  const int k0 = 4 * blockIdx.y;
-  const double* q0 = Q + (int64_t)k0 * n;
-  const double* q1 = Q + (int64_t)(k0 + 1 < m ? k0 + 1 : k0) * n;
-  const double* q2 = Q + (int64_t)(k0 + 2 < m ? k0 + 2 : k0) * n;
-  const double* q3 = Q + (int64_t)(k0 + 3 < m ? k0 + 3 : k0) * n;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  for (; i + stride < n; i += 2 * stride) {
-    const double wa = w[i], wb = w[i + stride];
-    const double a0 = q0[i], a1 = q1[i], a2 = q2[i], a3 = q3[i];
-    const double b0 = q0[i + stride], b1 = q1[i + stride], b2 = q2[i + stride], b3 = q3[i + stride];
-    s0 += a0 * wa + b0 * wb; s1 += a1 * wa + b1 * wb; s2 += a2 * wa + b2 * wb; s3 += a3 * wa + b3 * wb;
-  }
-  for (; i < n; i += stride) {
-    const double wa = w[i];
-    s0 += q0[i] * wa; s1 += q1[i] * wa; s2 += q2[i] * wa; s3 += q3[i] * wa;
-  }
-  s0 = block_sum(s0); s1 = block_sum(s1); s2 = block_sum(s2); s3 = block_sum(s3);
-  if (threadIdx.x == 0) {
-    part[(int64_t)k0 * gridDim.x + blockIdx.x] = s0;
-    if (k0 + 1 < m) part[(int64_t)(k0 + 1) * gridDim.x + blockIdx.x] = s1;
-    if (k0 + 2 < m) part[(int64_t)(k0 + 2) * gridDim.x + blockIdx.x] = s2;
-    if (k0 + 3 < m) part[(int64_t)(k0 + 3) * gridDim.x + blockIdx.x] = s3;
-  }
-}
-void launch_multi_dot(hipStream_t st, const double* Q, int64_t n, int m, const double* w, double* scratch, double* h) {
-  if (m <= 0) return;
-  int np = (int)((n + 8191) / 8192);
-  if (np < 1) np = 1;
-  if (np > 64) np = 64;
-  hipLaunchKernelGGL(k_multi_dot_partial, dim3(np, (m + 3) / 4), dim3(256), 0, st, Q, n, m, w, scratch);
-  hipLaunchKernelGGL(k_sum_final, dim3(m), dim3(256), 0, st, scratch, np, np, h);
-}
-__global__ __launch_bounds__(256) void k_multi_axpy(const double* __restrict__ Q, int64_t n, int m,
-                                                    const double* __restrict__ h, double sign, double* __restrict__ w) {
-  GRID_STRIDE(i, n) {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    const double* q = Q + i;
-    int k = 0;
-    for (; k + 8 <= m; k += 8) {
-      const double v0 = q[(int64_t)k * n], v1 = q[(int64_t)(k + 1) * n], v2 = q[(int64_t)(k + 2) * n], v3 = q[(int64_t)(k + 3) * n];
-      const double v4 = q[(int64_t)(k + 4) * n], v5 = q[(int64_t)(k + 5) * n], v6 = q[(int64_t)(k + 6) * n], v7 = q[(int64_t)(k + 7) * n];
-      a0 += h[k] * v0 + h[k + 4] * v4;
-      a1 += h[k + 1] * v1 + h[k + 5] * v5;
-      a2 += h[k + 2] * v2 + h[k + 6] * v6;
-      a3 += h[k + 3] * v3 + h[k + 7] * v7;
-    }
-    for (; k < m; ++k) a0 += h[k] * q[(int64_t)k * n];
-    w[i] += sign * ((a0 + a1) + (a2 + a3));
-  }
-}
-void launch_multi_axpy(hipStream_t st, const double* Q, int64_t n, int m, const double* h, double sign, double* w) {
-  if (m > 0) LAUNCH1D(k_multi_axpy, st, n, Q, n, m, h, sign, w);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // ILU(0) and triangular solves on a multicolour ordering.
 //

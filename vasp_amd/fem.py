@@ -139,12 +139,34 @@ class FormTerms(list):
 
 
 class Function:
-    """A view of one field (d, v or p) of a monolithic state vector, with point evaluation."""
+    """A view of one field (d, v or p) of a monolithic state vector, with point evaluation.
 
-    def __init__(self, mesh: FsiMesh, fld: int, nodal: np.ndarray, backend=None):
-        self.mesh, self.field, self.nodal = mesh, fld, nodal
+    The nodal array is resolved on first use: when the state lives on the device (``MixedFunction.mark_stale``), hooks
+    that only need probes, cell statistics or the values on a patch never pull the whole vector over PCIe."""
+
+    def __init__(self, mesh: FsiMesh, fld: int, nodal: Optional[np.ndarray] = None, backend=None, parent=None,
+                 deepcopy: bool = False):
+        self.mesh, self.field, self._nodal = mesh, fld, nodal
         self.backend = backend          # the time-step kernel holding the same state on the device (or None)
+        self._parent, self._deepcopy = parent, deepcopy
         self._allow_extrapolation = False
+
+    @property
+    def nodal(self) -> np.ndarray:
+        if self._nodal is None:
+            arr = self.mesh.split(self._parent.vector())[(FIELD_D, FIELD_V, FIELD_P).index(self.field)]
+            self._nodal = arr.copy() if self._deepcopy else arr
+        return self._nodal
+
+    def values_at_nodes(self, nodes: np.ndarray) -> np.ndarray:
+        """Nodal values at P2 ``nodes`` (vertices for p): (n, 3) or (n,).  Fetched from the device when the host copy of
+        the state is stale (``fsi_get_values``)."""
+        nodes = np.asarray(nodes, dtype=np.int64)
+        par = self._parent
+        if self._nodal is None and par is not None and par.stale and hasattr(par.backend, "get_values"):
+            vals = par.backend.get_values(par.which, self.mesh.dofs(self.field, nodes))
+            return vals if self.field == FIELD_P else vals.reshape(len(nodes), 3)
+        return self.nodal[nodes]
 
     def get_allow_extrapolation(self):
         return self._allow_extrapolation
@@ -169,15 +191,24 @@ class Function:
 
 
 class MixedFunction:
-    """``dvp_["n"]``: the monolithic vector with ``sub(i, deepcopy=True)`` → ``Function``."""
+    """``dvp_["n"]``: the monolithic vector with ``sub(i, deepcopy=True)`` → ``Function``.
 
-    def __init__(self, mesh: FsiMesh, vector: np.ndarray, backend=None):
-        self.mesh, self._x, self.backend = mesh, vector, backend
+    ``mark_stale()`` says the device state has moved on (after a time step); the host array is refreshed from the
+    backend on the next ``vector()`` - i.e. only when a hook, a checkpoint or a visualization frame really needs it."""
+
+    def __init__(self, mesh: FsiMesh, vector: np.ndarray, backend=None, which: str = "n"):
+        self.mesh, self._x, self.backend, self.which = mesh, vector, backend, which
+        self.stale = False
+
+    def mark_stale(self):
+        self.stale = self.backend is not None
 
     def vector(self) -> np.ndarray:
+        if self.stale:
+            self.backend.get_state(self.which, self._x)
+            self.stale = False
         return self._x
 
     def sub(self, i: int, deepcopy: bool = False) -> Function:
-        parts = self.mesh.split(self._x)
-        arr = parts[i].copy() if deepcopy else parts[i]
-        return Function(self.mesh, (FIELD_D, FIELD_V, FIELD_P)[i], arr, backend=self.backend)
+        return Function(self.mesh, (FIELD_D, FIELD_V, FIELD_P)[i], None, backend=self.backend, parent=self,
+                        deepcopy=deepcopy)

@@ -172,6 +172,20 @@ def build_description(mesh: FsiMesh, v: dict, bcs, F_solid_linear) -> dict:
 # ------------------------------------------------------------------------------------------------
 
 def default_backend(desc):
+    """The HIP time-step kernel: one context on one GPU, or - when the process was started as one of N ranks
+    (``torchrun`` / ``python -m torch.distributed.run``: WORLD_SIZE > 1, the counterpart of the reference's
+    ``mpirun -np N turtleFSI ...`` [REF docs/simulation.md:16,30]) - this rank's part of the element partition."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        import torch
+        from .dist import init_from_env
+        from .partition import DistBackend
+        rank, local_rank, world, dist = init_from_env(backend=os.environ.get("VASPFSI_DIST_BACKEND"))
+        if os.environ.get("VASPFSI_ONE_GPU"):
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        return DistBackend(desc, dist, device=local_rank)
     from .capi import HipBackend   # raises loudly if libvaspfsi.so or the GPU is missing
     return HipBackend(desc)
 
@@ -198,7 +212,12 @@ def prepare(argv: Optional[List[str]] = None):
 
     # folders ---------------------------------------------------------------------------------
     folder = Path(str(ns["folder"]))
-    if ns.get("sub_folder") is not None:
+    if ns.get("restart_folder"):
+        # a restarted run continues in the folder it restarts from: the checkpoint is overwritten and the visualization
+        # series goes on in <name>_run_N.h5 behind the same xdmf (what output_file_lists expects of a restarted series
+        # [REF src/vasp/postprocessing/postprocessing_common.py:63-121])
+        results = Path(str(ns["restart_folder"]))
+    elif ns.get("sub_folder") is not None:
         results = folder / str(ns["sub_folder"])
     else:
         existing = [int(p.name) for p in folder.glob("*") if p.name.isdigit()] if folder.exists() else []
@@ -215,7 +234,7 @@ def prepare(argv: Optional[List[str]] = None):
     DVP = MixedSpace(mesh)
     n_dof = mesh.num_dofs
     state = {k: np.zeros(n_dof) for k in ("n", "n-1")}
-    dvp_ = {k: MixedFunction(mesh, x) for k, x in state.items()}
+    dvp_ = {k: MixedFunction(mesh, x, which=k) for k, x in state.items()}
     ns.update(mesh=mesh, domains=domains, boundaries=boundaries, DVP=DVP, dvp_=dvp_, psi="psi", phi="phi",
               gamma="gamma", F_solid_linear=FormTerms(), F_fluid_linear=FormTerms(),
               t=float(ns["t"]), counter=int(ns["counter"]), _state=state)
@@ -233,15 +252,50 @@ def prepare(argv: Optional[List[str]] = None):
     return ns, desc, bc_values, pressure, hook
 
 
+def advance(ns, backend, bc_values, pressure, hook, first_step_num: int, out=print) -> list:
+    """One time step of the reference's loop body: ``t += dt``; ``pre_solve``; Dirichlet data and
+    interface pressure to the device; the quasi-Newton solve behind the C-ABI; state shift; ``post_solve``.  File output
+    and the step counter stay with the caller.  ``bench.py`` times exactly this function."""
+    ns["t"] = ns["t"] + float(ns["dt"])
+    upd = hook("pre_solve")(**ns)
+    ns.update(upd or {})
+    backend.set_dirichlet_values(bc_values())
+    backend.set_interface_pressure(float(pressure.P) if pressure is not None else 0.0)
+    hist = backend.newton_solve(counter=ns["counter"], first_step_num=first_step_num,
+                                log=out if ns["verbose"] else None,
+                                **{k: ns[k] for k in ("atol", "rtol", "max_it", "lmbda", "recompute", "recompute_tstep")})
+    backend.shift()                       # dvp_["n-1"] <- dvp_["n"]
+    for fn in ns["dvp_"].values():        # the host copies are refreshed only if somebody reads them
+        fn.mark_stale()
+    upd = hook("post_solve")(**ns)
+    ns.update(upd or {})
+    return hist
+
+
+def _rank() -> int:
+    import os
+    return int(os.environ.get("RANK", 0))
+
+
 def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_backend, out=print):
     """Run one simulation; returns the final namespace (for tests).  ``out`` receives solver log lines."""
-    ns, desc, bc_values, pressure, hook = prepare(argv)
+    import builtins
+    import contextlib
+    import io
+    import os
+    rank0 = _rank() == 0
+    if not rank0:                                 # the reference guards its prints with MPI.rank == 0
+        out = lambda *a, **k: None
+    quiet = contextlib.nullcontext() if rank0 else contextlib.redirect_stdout(io.StringIO())
+    with quiet:
+        ns, desc, bc_values, pressure, hook = prepare(argv)
     state = ns["_state"]
     backend = backend_factory(desc)
     ns["backend"] = backend
     mesh = ns["mesh"]
-    if hasattr(backend, "flow_stats"):            # per-step diagnostics of post_solve run on the device
-        ns["dvp_"]["n"].backend = backend
+    for which, fn in ns["dvp_"].items():          # per-step diagnostics of post_solve run on the device
+        fn.backend, fn.which = backend, which
+    restart_run = 0
     if ns.get("restart_folder"):                  # --restart-folder: resume from Checkpoint/ of an earlier run
         ck = Path(str(ns["restart_folder"])) / "Checkpoint"
         meta = json.loads((ck / "default_variables.json").read_text())
@@ -250,44 +304,54 @@ def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_ba
         backend.set_state("n", state["n"])
         backend.set_state("n-1", state["n-1"])
         ns["t"], ns["counter"] = float(meta["t"]), int(meta["counter"])
-    viz = VisualizationWriter(ns["visualization_folder"], mesh, ns["save_deg"]) if ns.get("save_step") else None
+        runs = [int(p.stem.rsplit("_", 1)[1]) for p in Path(ns["visualization_folder"]).glob("velocity_run_*.h5")]
+        restart_run = 1 + max(runs, default=0)
+    viz = None
+    if ns.get("save_step") and rank0:
+        viz = VisualizationWriter(ns["visualization_folder"], mesh, ns["save_deg"], run_index=restart_run)
     first_step_num = ns["counter"]
-    newton_keys = ("atol", "rtol", "max_it", "lmbda", "recompute", "recompute_tstep")
 
-    t, dt, T = ns["t"], float(ns["dt"]), float(ns["T"])
+    dt, T = float(ns["dt"]), float(ns["T"])
+    killtime = ns.get("killtime")
+    results = Path(ns["results_folder"])
     total_newton = 0
+    stop = False
     t_loop = _time.perf_counter()
-    while t <= T + dt / 10:
+    while ns["t"] <= T + dt / 10 and not stop:
         t0 = _time.perf_counter()
-        t += dt
-        ns["t"] = t
-        upd = hook("pre_solve")(**ns)
-        ns.update(upd or {})
-
-        backend.set_dirichlet_values(bc_values())
-        backend.set_interface_pressure(float(pressure.P) if pressure is not None else 0.0)
-        hist = backend.newton_solve(counter=ns["counter"], first_step_num=first_step_num,
-                                    log=out if ns["verbose"] else None, **{k: ns[k] for k in newton_keys})
+        with quiet:
+            hist = advance(ns, backend, bc_values, pressure, hook, first_step_num, out)
+        t = ns["t"]
         total_newton += len(hist)
-        backend.shift()                       # dvp_["n-1"] <- dvp_["n"]
-        backend.get_state("n", state["n"])
-        state["n-1"][:] = state["n"]
-
-        upd = hook("post_solve")(**ns)
-        ns.update(upd or {})
-        if ns.get("checkpoint_step") and ns["counter"] % int(ns["checkpoint_step"]) == 0:
-            checkpoint(ns["checkpoint_folder"], mesh, state["n"], ns["default_variables"], t, ns["counter"])
-            if viz is not None:
-                viz.flush()
+        # turtleFSI's stop controls: wall-clock budget, and the sentinel files a user drops into the results folder
+        # (``killturtle``: checkpoint and stop; ``pauseturtle``: wait until it is removed)
+        if killtime is not None and _time.perf_counter() - t_loop > float(killtime):
+            out("Reached killtime = %s s: writing a checkpoint and stopping" % killtime)
+            stop = True
+        if (results / "killturtle").exists():
+            out("killturtle found: writing a checkpoint and stopping")
+            if rank0:
+                with contextlib.suppress(OSError):
+                    (results / "killturtle").unlink()
+            stop = True
+        while (results / "pauseturtle").exists():
+            _time.sleep(5.0)
+        if ns.get("checkpoint_step") and (ns["counter"] % int(ns["checkpoint_step"]) == 0 or stop):
+            x = ns["dvp_"]["n"].vector()
+            if rank0:
+                checkpoint(ns["checkpoint_folder"], mesh, x, ns["default_variables"], t, ns["counter"])
         if viz is not None and ns["counter"] % int(ns["save_step"]) == 0:
-            viz.write(state["n"], t)
+            viz.write(ns["dvp_"]["n"].vector(), t)
+        elif ns.get("save_step") and ns["counter"] % int(ns["save_step"]) == 0:
+            ns["dvp_"]["n"].vector()              # partitioned: every rank takes part in the gather
         ns["counter"] += 1
         out("Solved for timestep %d, t = %.4f in %.1f s" % (ns["counter"], t, _time.perf_counter() - t0))
     if viz is not None:
         viz.flush()
     ns["time_loop_seconds"] = _time.perf_counter() - t_loop
     ns["newton_iterations"] = total_newton
-    hook("finished")(**ns)
+    with quiet:
+        hook("finished")(**ns)
     return ns
 
 

@@ -44,7 +44,17 @@ def refine_topology(mesh: FsiMesh) -> np.ndarray:
 
 
 class VisualizationWriter:
-    def __init__(self, folder, mesh: FsiMesh, save_deg: int):
+    """Streams frames to disk in bounded segments.
+
+    A frame of the 1 M-tet bench mesh at save_deg 2 is 35 MB per vector field, a 951-step cycle 100 GB: the series is
+    therefore cut into files of at most ``segment_bytes`` of frames - ``<name>.h5`` (which also carries
+    ``/Mesh/0/mesh``), ``<name>_run_1.h5``, ... - and only the segment being filled is held in memory.  One XDMF per
+    field lists, per time step, the file and the index inside it, which is how the reference's consumers address
+    frames anyway [REF src/vasp/postprocessing/postprocessing_common.py:63-121] (a restarted turtleFSI run leaves the
+    same ``_run_N`` pattern behind).  ``run_index`` > 0 continues an existing series after ``--restart-folder``.
+    """
+
+    def __init__(self, folder, mesh: FsiMesh, save_deg: int, run_index: int = 0, segment_bytes: int = 256 << 20):
         self.folder = Path(folder)
         self.folder.mkdir(parents=True, exist_ok=True)
         self.mesh, self.save_deg = mesh, int(save_deg)
@@ -54,10 +64,37 @@ class VisualizationWriter:
         else:
             self.geometry = mesh.coords
             self.topology = mesh.tets.astype(np.int64)
-        self.frames = {name: [] for name, _, _ in FIELDS}
-        self.times = []
-        self.flush_every = 20       # the libhdf5-free writer emits whole files: do it every few frames, and at the end
+        frame_bytes = 8 * 3 * len(self.geometry)
+        self.frames_per_segment = max(1, int(segment_bytes // frame_bytes))
+        self.entries = {name: [] for name, _, _ in FIELDS}     # per field: (time, h5 file name, index in that file)
+        self.segment = run_index                                # number of the file being filled (0: <name>.h5)
+        self.frames = {name: [] for name, _, _ in FIELDS}      # frames of the current segment only
+        self.flush_every = 20      # the segment being filled is rewritten whole: every few frames, and when it is full
         self._dirty = False
+        if run_index > 0:
+            self._adopt_existing()
+
+    def _file(self, name: str, segment: int) -> str:
+        return f"{name}.h5" if segment == 0 else f"{name}_run_{segment}.h5"
+
+    def _adopt_existing(self) -> None:
+        import re
+        for name, _, _ in FIELDS:
+            path = self.folder / f"{name}.xdmf"
+            if not path.exists():
+                continue
+            times, files, idx = [], [], []
+            for line in path.read_text().splitlines():
+                if "<Time Value" in line:
+                    times.append(float(re.findall('<Time Value="(.+?)"', line)[0]))
+                if "VisualisationVector" in line:
+                    files.append(re.findall('"HDF">(.+?):/', line)[0])
+                    idx.append(int(re.findall("VisualisationVector/(.+?)</DataItem", line)[0]))
+            self.entries[name] = list(zip(times, files, idx))
+
+    @property
+    def times(self):
+        return [e[0] for e in self.entries[FIELDS[0][0]]]
 
     def write(self, state: np.ndarray, t: float) -> None:
         d, v, p = self.mesh.split(state)
@@ -68,11 +105,16 @@ class VisualizationWriter:
             vals = (d, v, pn[:, None])
         else:
             vals = (d[:V], v[:V], p[:, None])
-        self.times.append(float(t))
         for (name, _, att), val in zip(FIELDS, vals):
+            self.entries[name].append((float(t), self._file(name, self.segment), len(self.frames[name])))
             self.frames[name].append(np.ascontiguousarray(val, dtype=np.float64).reshape(N, -1).copy())
         self._dirty = True
-        if len(self.times) <= 3 or len(self.times) % self.flush_every == 0:
+        nseg = len(self.frames[FIELDS[0][0]])
+        if nseg >= self.frames_per_segment:
+            self.flush()
+            self.frames = {name: [] for name, _, _ in FIELDS}
+            self.segment += 1
+        elif len(self.times) <= 3 or nseg % self.flush_every == 0:
             self.flush()
 
     def flush(self) -> None:
@@ -82,18 +124,22 @@ class VisualizationWriter:
             self._dirty = False
 
     def _flush(self, name: str, att: str) -> None:
-        root, meshg, zero, inner = Group(), Group(), Group(), Group()
-        inner["geometry"] = Dataset(np.ascontiguousarray(self.geometry))
-        inner["topology"] = Dataset(self.topology, {"celltype": "tetrahedron"})
-        zero["mesh"] = inner
-        meshg["0"] = zero
+        root = Group()
+        if self.segment == 0:
+            meshg, zero, inner = Group(), Group(), Group()
+            inner["geometry"] = Dataset(np.ascontiguousarray(self.geometry))
+            inner["topology"] = Dataset(self.topology, {"celltype": "tetrahedron"})
+            zero["mesh"] = inner
+            meshg["0"] = zero
+            root["Mesh"] = meshg
         vec = Group()
         for k, fr in enumerate(self.frames[name]):
             vec[str(k)] = Dataset(fr)
-        root["Mesh"], root["VisualisationVector"] = meshg, vec
-        tmp = self.folder / f"tmp_{name}.h5"
+        root["VisualisationVector"] = vec
+        fname = self._file(name, self.segment)
+        tmp = self.folder / f"tmp_{fname}"
         write_h5(tmp, root)
-        os.replace(tmp, self.folder / f"{name}.h5")
+        os.replace(tmp, self.folder / fname)
         N, M = len(self.geometry), len(self.topology)
         ndim = "3" if att == "Vector" else "1"
         lines = f'''<?xml version="1.0"?>
@@ -109,14 +155,14 @@ class VisualizationWriter:
           <DataItem Dimensions="{N} 3" Format="HDF">{name}.h5:/Mesh/0/mesh/geometry</DataItem>
         </Geometry>
 '''
-        for k, t in enumerate(self.times):
+        for k, (t, h5name, idx) in enumerate(self.entries[name]):
             if k > 0:
                 lines += f'''      <Grid>
         <xi:include xpointer="xpointer(//Grid[@Name=&quot;TimeSeries_{name}&quot;]/Grid[1]/*[self::Topology or self::Geometry])" />
 '''
             lines += f'''        <Time Value="{t!r}" />
         <Attribute Name="{name}" AttributeType="{att}" Center="Node">
-          <DataItem Dimensions="{N} {ndim}" Format="HDF">{name}.h5:/VisualisationVector/{k}</DataItem>
+          <DataItem Dimensions="{N} {ndim}" Format="HDF">{h5name}:/VisualisationVector/{idx}</DataItem>
         </Attribute>
       </Grid>
 '''

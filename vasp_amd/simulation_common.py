@@ -112,18 +112,25 @@ def dg0_jacobian(mesh: FsiMesh, d_nodal: np.ndarray) -> np.ndarray:
     return np.einsum("q,cq->c", g["qw"], np.linalg.det(np.eye(3) + gd)) * 6.0
 
 
-def inlet_flux(mesh: FsiMesh, v_nodal: np.ndarray, dsi) -> float:
-    """assemble(inner(v, n) * ds(inlet)); ``dsi`` = (facet ids, areas, outward normals)."""
+def inlet_flux(mesh: FsiMesh, v, dsi) -> float:
+    """assemble(inner(v, n) * ds(inlet)); ``dsi`` = (facet ids, areas, outward normals); ``v``: a velocity ``Function``
+    (only its values on the patch are fetched) or an (N2, 3) nodal array."""
     fids, area, normal = dsi
     tp, tw = tri_rule_deg6()
     Nf = tabulate_tri(tp)
     w = 2.0 * tw @ Nf                                    # ∫N_a / area
-    vn = np.einsum("fai,fi->fa", v_nodal[mesh.facet_nodes[fids]], normal)
+    fn = mesh.facet_nodes[fids]
+    if hasattr(v, "values_at_nodes"):
+        nodes, inv = np.unique(fn.ravel(), return_inverse=True)
+        vf = v.values_at_nodes(nodes)[inv].reshape(len(fids), 6, 3)
+    else:
+        vf = np.asarray(v)[fn]
+    vn = np.einsum("fai,fi->fa", vf, normal)
     return float(np.sum(area[:, None] * vn * w[None, :]))
 
 
 def calculate_and_print_flow_properties(dt, mesh, v, inlet_area, mu_f, rho_f, n, dsi, local_rhs=False) -> None:
-    flow_rate_inlet = abs(inlet_flux(mesh, v.nodal, dsi))
+    flow_rate_inlet = abs(inlet_flux(mesh, v, dsi))
     backend = getattr(v, "backend", None)
     if backend is not None and hasattr(backend, "flow_stats"):      # DG0 projection of |v| on the device (fsi_flow_stats)
         v_mean, v_min, v_max, _ = backend.flow_stats()
