@@ -177,6 +177,20 @@ int fsi_probe(FsiCtx* ctx, int64_t n, const int32_t* cells, const double* bary, 
  * out[0..3] = mean, min, max over the cells of the cell-mean |v|, and min over the cells of the cell-mean det(I + grad d). */
 int fsi_flow_stats(FsiCtx* ctx, double* out);
 
+/* ---- post-processing kernels on the resident state ------------------------------------- */
+/* Replaces the element loop of compute_stress_strain [REF src/vasp/postprocessing/postprocessing_fenics/
+ * compute_stress_strain.py:188-263]: for each listed SOLID cell (index in the mesh handed to fsi_create) the DG1
+ * coefficients (one per local vertex) of the L2-projected Cauchy stress 1/J F S F^T and Green-Lagrange strain E of
+ * dvp_["n"]'s displacement, and of the projected largest principal value of each.
+ * out[i][80] = TrueStress[4][3][3], GreenLagrangeStrain[4][3][3], MaxPrincipalStress[4], MaxPrincipalStrain[4]. */
+int fsi_stress_strain(FsiCtx* ctx, int64_t n, const int32_t* cells, double* out);
+/* Replaces Stress.__call__ of compute_hemodynamics [REF .../compute_hemodynamics.py:91-157]: tangential traction
+ * Ft = F - (F.n) n, F = -2 mu sym(grad v) n, on the listed exterior facets (cell + local index of the opposite vertex),
+ * projected with the surface mass matrix onto the DG1 space of each boundary cell; out[f][3][3] = value at the three
+ * facet vertices (local vertices of the cell in ascending order without the opposite one) x component. */
+int fsi_wall_shear_stress(FsiCtx* ctx, int64_t nf, const int32_t* facet_cells, const int32_t* facet_local, double mu,
+                          double* out);
+
 /* ---- timing of the device kernels (HIP events on the solver stream) ---------------------------------- */
 typedef struct FsiTimers {
   double residual_ms;  int64_t residual_calls;
@@ -210,6 +224,11 @@ typedef struct FsiTimers {
   int64_t schur_elem_bytes;                          /* 8: FP64 product, 4: FP32 fused sweep                          */
 } FsiTimers;
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
+/* Measurement aid: streams `bytes` of the (idle) Krylov store once per kernel with 4-, 8-, 16- and 32-byte loads and
+ * 4-, 8-, 16-byte stores per lane (kernels k_cal_read<...> / k_cal_write<...>), so that a rocprofv3 --pmc FETCH_SIZE /
+ * WRITE_SIZE pass can be calibrated against known byte counts at the access widths the solver kernels use.  Discards
+ * the recycled Krylov directions. */
+int fsi_calibration_streams(FsiCtx* ctx, int64_t bytes);
 
 #ifdef __cplusplus
 }

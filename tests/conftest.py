@@ -33,3 +33,28 @@ def cylinder_case(tmp_path_factory):
 def stenosis_case(tmp_path_factory):
     return prepare_case("offset_stenosis", GOLDEN / "offset_stenosis" / "offset_stenosis.h5",
                         tmp_path_factory.mktemp("os"), dt="0.01", T="0.04")
+
+
+def make_avf_case(tmp_path):
+    """The avf problem [REF src/vasp/simulations/avf.py] on a synthetic tube: the reference tree holds neither the AVF mesh
+    nor avf.csv, so the downstream half of a generated offset-stenosis tube carries the vein ids (1002 / 1011 / 1022 /
+    1033) and the patient table is a short ramp.  Returns prepare()'s tuple."""
+    import json
+    import numpy as np
+    from vasp_amd.mesh import FsiMesh
+    from vasp_amd.meshgen import generate
+    m = generate(6000)
+    x_c = m["coords"][m["tets"]].mean(axis=1)[:, 0]
+    x_f = m["coords"][m["facets"]].mean(axis=1)[:, 0]
+    cm, fm = m["cell_markers"].copy(), m["facet_markers"].copy()
+    mid = 0.008
+    cm[(cm == 2) & (x_c > mid)] = 1002
+    for a, b in ((11, 1011), (22, 1022), (33, 1033)):
+        fm[(fm == a) & (x_f > mid)] = b
+    mesh = FsiMesh.from_arrays(m["coords"], m["tets"], cm, m["facets"], fm)
+    tmp_path.mkdir(parents=True, exist_ok=True)
+    mesh.write(tmp_path / "avf.h5")
+    (tmp_path / "avf_probe_point.json").write_text(json.dumps([[0.0, 0.0, 0.0], [16.0, 0.0, 0.0]]))       # mm
+    (tmp_path / "avf.csv").write_text("v_PA,v_DA,PV\n" + "\n".join(f"{0.3 + 0.01 * i},{0.1 + 0.005 * i},{9000 + 50 * i}" for i in range(20)))
+    return prepare_case("avf", tmp_path / "avf.h5", tmp_path / "run", dt="0.0001", T="0.2", theta="0.501",
+                        extra=(f"patient_data_path={tmp_path / 'avf.csv'}", "fsi_region=[0.008,0,0,0.006]"))

@@ -25,6 +25,9 @@ from vasp_amd.monolithic import run  # noqa: E402
 CASES = {
     "stenosis": dict(problem="offset_stenosis", mesh="tests/golden/offset_stenosis/offset_stenosis.h5", dt="0.01", T="0.04"),
     "cylinder": dict(problem="cylinder", mesh="tests/golden/cylinder/cylinder.h5", dt="0.001", T="0.002"),
+    # REF tests/test_simulations.py:80-90: the aneurysm problem on its fixture, inlet_id=4 override, 3 steps
+    "aneurysm": dict(problem="aneurysm", mesh="tests/golden/aneurysm/small_aneurysm.h5", dt="0.001", T="0.002",
+                     more=["inlet_id=4"]),
 }
 
 
@@ -43,7 +46,7 @@ def main(name):
     t0 = time.time()
     with contextlib.redirect_stdout(buf):
         ns = run(["-p", c["problem"], "-dt", c["dt"], "-T", c["T"], "--theta", "0.51", "--folder", f"/tmp/golden_{name}",
-                  "--sub-folder", "1", "--new-arguments", f"mesh_path={ROOT / c['mesh']}"] + extra,
+                  "--sub-folder", "1"] + extra + ["--new-arguments", f"mesh_path={ROOT / c['mesh']}"] + c.get("more", []),
                  backend_factory=Recorder, out=print)
     log = [l for l in buf.getvalue().splitlines()
            if l.startswith(("Newton", "Probe", "Compute", "Solved", "ramp", "Instant", "  ", "Flow", "Minimum"))]

@@ -198,25 +198,9 @@ def test_avf_problem_two_solid_regions(tmp_path):
     """REF src/vasp/simulations/avf.py: two MooneyRivlin regions, list-valued ids, tabulated inlets and pressure.
     The reference tree holds neither the AVF mesh nor avf.csv, so the case is a synthetic tube whose downstream half
     carries the vein ids (1002 / 1011 / 1022 / 1033)."""
-    import json
-    from conftest import prepare_case
-    from vasp_amd.mesh import FsiMesh
-    from vasp_amd.meshgen import generate
-    m = generate(6000)
-    x_c = m["coords"][m["tets"]].mean(axis=1)[:, 0]
-    x_f = m["coords"][m["facets"]].mean(axis=1)[:, 0]
-    cm, fm = m["cell_markers"].copy(), m["facet_markers"].copy()
-    mid = 0.008
-    cm[(cm == 2) & (x_c > mid)] = 1002
-    for a, b in ((11, 1011), (22, 1022), (33, 1033)):
-        fm[(fm == a) & (x_f > mid)] = b
-    mesh = FsiMesh.from_arrays(m["coords"], m["tets"], cm, m["facets"], fm)
-    mesh.write(tmp_path / "avf.h5")
-    (tmp_path / "avf_probe_point.json").write_text(json.dumps([[0.0, 0.0, 0.0], [16.0, 0.0, 0.0]]))       # mm
-    (tmp_path / "avf.csv").write_text("v_PA,v_DA,PV\n" + "\n".join(f"{0.3 + 0.01 * i},{0.1 + 0.005 * i},{9000 + 50 * i}" for i in range(20)))
-    ns, desc, bc_values, pressure, hook = prepare_case(
-        "avf", tmp_path / "avf.h5", tmp_path / "run", dt="0.0001", T="0.2", theta="0.501",
-        extra=(f"patient_data_path={tmp_path / 'avf.csv'}", "fsi_region=[0.008,0,0,0.006]"))
+    from conftest import make_avf_case
+    ns, desc, bc_values, pressure, hook = make_avf_case(tmp_path)
+    mesh = ns["mesh"]
     assert desc["solid_models"] == [1, 1] and desc["solid_props"][1][3:] == (0.0, 0.003e6, 0.538e6)
     assert set(np.unique(desc["cell_region"][desc["cell_kind"] == 1])) == {0, 1}
     b = ns["boundaries"]

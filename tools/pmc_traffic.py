@@ -1,0 +1,49 @@
+"""Per-kernel HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of tools/pmc_driver.py.
+
+The counters are KiB at the L2's memory side (MI355X_MICROARCH.md §HBM).  Their scale depends on the access width, so
+the driver first streams a known number of bytes with 4-, 8-, 16- and 32-byte loads and 4-, 8-, 16-byte stores per lane
+(k_cal_read<T> / k_cal_write<T>); the factor bytes / (counter * 1024) of the matching width corrects every other kernel.
+
+    python tools/pmc_traffic.py FETCH_summary.csv WRITE_summary.csv CAL_BYTES > profiles/r02_pmc_traffic.json
+"""
+import csv, json, sys
+
+def load(path):
+    out = {}
+    for row in csv.DictReader(open(path)):
+        out[row["kernel"]] = (float(row["mean_value"]), int(row["dispatches"]))
+    return out
+
+fetch, write, cal_bytes = load(sys.argv[1]), load(sys.argv[2]), float(sys.argv[3])
+def factor(table, kern, typ):
+    for name, (v, n) in table.items():
+        if kern in name and typ in name and v > 0:
+            return cal_bytes / (v * 1024.0)
+    return None
+cal = {"read4": factor(fetch, "k_cal_read", "<float>"), "read8": factor(fetch, "k_cal_read", "<double>"),
+       "read16": factor(fetch, "k_cal_read", "<float, 4"), "read32": factor(fetch, "k_cal_read", "<double, 4"),
+       "write4": factor(write, "k_cal_write", "<float>"), "write8": factor(write, "k_cal_write", "<double>"),
+       "write16": factor(write, "k_cal_write", "<float, 4")}
+# dominant load / store width of the solver kernels (bytes per lane and instruction)
+WIDTH = [("k_gcr_dots<double>", "read32", "write8"), ("k_gcr_axpy<double>", "read32", "write16"),
+         ("k_gcr_dots<float>", "read16", "write8"), ("k_gcr_axpy<float>", "read16", "write16"),
+         ("k_gcr_flush", "read16", "write8"), ("k_gcr_update", "read8", "write8"), ("k_spmv_node6", "read8", "write8"),
+         ("k_spmv<", "read8", "write8"), ("k_spmv_tiled_f32", "read4", "write16"), ("k_sweep_sb_b3", "read16", "write16"),
+         ("k_sweep_csr_f32", "read4", "write4"), ("k_residual", "read8", "write8"), ("k_jacobian", "read8", "write8")]
+per_launch, detail = {}, {}
+for name in sorted(set(fetch) | set(write)):
+    if "k_cal_" in name:
+        continue
+    rk, wk = "read8", "write8"
+    for key, r_, w_ in WIDTH:
+        if key in name:
+            rk, wk = r_, w_
+            break
+    f = fetch.get(name, (0.0, 0))[0] * 1024.0 * (cal.get(rk) or 1.0)
+    w = write.get(name, (0.0, 0))[0] * 1024.0 * (cal.get(wk) or 1.0)
+    short = name.split("fsi::")[-1]
+    per_launch[short] = f + w
+    detail[short] = {"fetch_bytes": f, "write_bytes": w, "raw_fetch_KiB": fetch.get(name, (0.0, 0))[0],
+                     "raw_write_KiB": write.get(name, (0.0, 0))[0], "launches": fetch.get(name, (0, 0))[1], "widths": [rk, wk]}
+print(json.dumps({"unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, KiB counters x 1024 x calibration factor of the access width)",
+                  "calibration_bytes": cal_bytes, "calibration_factors": cal, "per_launch_bytes": per_launch, "detail": detail}, indent=1))

@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "fsi_set_pressure_facets", "fsi_set_interface_pressure", "fsi_set_robin_facets", "fsi_solver_setup",
     "fsi_assemble_residual", "fsi_assemble_jacobian", "fsi_solve", "fsi_newton_solve", "fsi_shift",
     "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_get_matrix", "fsi_spmv",
-    "fsi_get_timers", "fsi_get_values", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
+    "fsi_get_timers", "fsi_get_values", "fsi_stress_strain", "fsi_wall_shear_stress", "fsi_calibration_streams", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
 )
 
 
@@ -108,6 +108,9 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_get_state.argtypes = [vp, C.c_int, vp]
     lib.fsi_set_state.argtypes = [vp, C.c_int, vp]
     lib.fsi_get_values.argtypes = [vp, C.c_int, i64, vp, vp]
+    lib.fsi_calibration_streams.argtypes = [vp, i64]
+    lib.fsi_stress_strain.argtypes = [vp, i64, vp, vp]
+    lib.fsi_wall_shear_stress.argtypes = [vp, i64, vp, vp, dbl, vp]
     lib.fsi_num_dofs.argtypes = [vp]
     lib.fsi_num_dofs.restype = i64
     lib.fsi_matrix_nnz.argtypes = [vp]
@@ -301,6 +304,22 @@ class HipBackend:
         out = np.empty(4)
         self._check(self.lib.fsi_flow_stats(self.ctx, _ptr(out)))
         return tuple(out)
+
+    def stress_strain(self, cells):
+        """DG1 Cauchy stress / Green-Lagrange strain / largest principal values on solid ``cells`` of dvp_["n"]."""
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        out = np.empty((len(cells), 80))
+        self._check(self.lib.fsi_stress_strain(self.ctx, len(cells), _ptr(cells), _ptr(out)))
+        return dict(TrueStress=out[:, :36].reshape(-1, 4, 3, 3), GreenLagrangeStrain=out[:, 36:72].reshape(-1, 4, 3, 3),
+                    MaxPrincipalStress=out[:, 72:76].copy(), MaxPrincipalStrain=out[:, 76:80].copy())
+
+    def wall_shear_stress(self, facet_cells, facet_local, mu: float):
+        """(nf, 3, 3) projected tangential traction at the vertices of exterior facets (cell, opposite local vertex)."""
+        fc = np.ascontiguousarray(facet_cells, dtype=np.int32)
+        fl = np.ascontiguousarray(facet_local, dtype=np.int32)
+        out = np.empty((len(fc), 3, 3))
+        self._check(self.lib.fsi_wall_shear_stress(self.ctx, len(fc), _ptr(fc), _ptr(fl), float(mu), _ptr(out)))
+        return out
 
     def timers(self, reset=False) -> dict:
         t = FsiTimers()

@@ -62,7 +62,8 @@ hipError_t upload_tables() {
   if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_qw), qw, sizeof(qw))) != hipSuccess) return e;
   if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_N), N, sizeof(N))) != hipSuccess) return e;
   if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_dN), dN, sizeof(dN))) != hipSuccess) return e;
-  return hipMemcpyToSymbol(HIP_SYMBOL(c_L), L, sizeof(L));
+  if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_L), L, sizeof(L))) != hipSuccess) return e;
+  return upload_post_tables(qw, &dN[0][0][0], &L[0][0]);       // the same tables for the kernels of fsi_post.hip
 }
 
 // ---------------------------------------------------------------------------------------------------------

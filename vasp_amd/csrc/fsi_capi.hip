@@ -597,6 +597,9 @@ int spmv(FsiCtx* ctx, const double* x, double* y) {
 // Right-preconditioned, flexible; Q = A P orthonormal.  Per iteration only Q streams through HBM (two passes: the
 // coefficients and the update, fsi_gcr.hip) and the host reads two small results; P is touched once per solve.
 void gcr_reset(FsiCtx* ctx) {
+  ctx->gs_rtol = 0.0;
+  std::fill(ctx->hot_slots.begin(), ctx->hot_slots.end(), -1);
+  ctx->hot_next = 0;
   ctx->kry_m = 0;
   ctx->kry_hw = 0;
   ctx->kry_free.clear();
@@ -683,6 +686,8 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
   // what a single pass leaves behind, so only a cancellation beyond 100x asks for the second pass
   double reorth = ctx->kry_fp32 ? 0.01 : std::min(0.5, std::max(0.01, 1.0 / (rtol_floor * 9e10)));
   if (ctx->gcr_reorth > 0.0) reorth = ctx->gcr_reorth;
+  std::fill(ctx->hot_slots.begin(), ctx->hot_slots.end(), -1);      // FP64 window: directions of this cycle only
+  ctx->hot_next = 0;
   double rn2 = 0.0;
   {   // projection on the recycled space: r -= Q (Q^T r), x-coefficients y = Q^T r
     Phase ph(ctx, &ctx->t_ortho);
@@ -705,10 +710,11 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
     }
   }
   double rnorm = std::sqrt(std::max(rn2, 0.0));
-  // The first direction of a cycle is made from the residual, every later one from the latest q (Arnoldi: the Krylov
-  // space is the same, K(A M^-1, r), but A M^-1 q_k always has a healthy component outside the kept space, whereas
-  // A M^-1 r_k is nearly parallel to the previous direction whenever a step reduced the residual only a little - a
-  // cancellation of 1e5 and more that FP32 storage of Q cannot survive and FP64 pays for with a second pass).
+  // New directions are made from the residual (GCR).  FSI_GCR_ARNOLDI=1 makes them from the latest q instead (the same
+  // Krylov space in exact arithmetic, without the cancellation of A M^-1 r_k against the previous direction after a step
+  // of little progress) - measured on the 6.6 k-tet fixture: twice the iterations and stagnation near 1e-3, because the
+  // FP32 sweeps of the preconditioner resolve what is large in their input, and only the residual has the components
+  // that still matter as its large ones.
   double* qd = ctx->tmp5.p;
   const double* src = r;
   while (rnorm > target && *iters < max_it) {
@@ -731,6 +737,11 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
     if (ctx->kry_free.empty() && ctx->kry_hw == cap) {
       FSICHK(gcr_flush(ctx, cy, x));
       FSICHK(gcr_retire(ctx, batch));
+      for (int k = 0; k < 32; ++k)
+        if (ctx->hot_slots[k] >= 0 && ctx->kry_born[ctx->hot_slots[k]] < 0) {      // a retired direction leaves the window too
+          ctx->hot_slots[k] = -1;
+          if (ctx->KQh.p) HIPCHK(hipMemsetAsync(ctx->KQh.p + (size_t)k * ctx->ldq, 0, (size_t)ctx->ldq * sizeof(double), st));
+        }
     }
     int slot;
     if (!ctx->kry_free.empty()) { slot = ctx->kry_free.back(); ctx->kry_free.pop_back(); }
@@ -747,6 +758,26 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
       // classical Gram-Schmidt; a second pass when the first one cancelled w by more than 1 / reorth.  With recycled
       // directions w = A M^-1 r lies mostly IN the kept space, so the usual 2x criterion fires on most iterations; the
       // orthogonality lost in one pass only matters relative to the tolerance asked for.
+      if (f32) {
+        // exact (FP64) Gram-Schmidt against the window of this cycle's directions first
+        // columns [0, nh) of the window are in use (it fills from 0 and then turns into a ring)
+        int nh = 0;
+        for (int k = 0; k < 32; ++k)
+          if (ctx->hot_slots[k] >= 0) nh = k + 1;
+        if (nh > 0) {
+          launch_gcr_dots(st, false, ctx->KQh.p, ctx->ldq, n, nh, w, nullptr, ctx->scratch.p, ctx->hcoef_hot.p);
+          FSICHK(gcr_read(ctx, ctx->hcoef_hot.p, nh + 2, hh));
+          if (ctx->part) {
+            FSICHK(allreduce(ctx, hh, nh + 2));
+            HIPCHK(hipMemcpyAsync(ctx->hcoef_hot.p, hh, (size_t)nh * sizeof(double), hipMemcpyHostToDevice, st));
+          }
+          w0 = std::sqrt(std::max(hh[nh], 0.0));
+          for (int k = 0; k < nh; ++k)
+            if (ctx->hot_slots[k] >= 0) htot[ctx->hot_slots[k]] += hh[k];
+          launch_gcr_axpy(st, false, ctx->KQh.p, ctx->ldq, n, nh, ctx->hcoef_hot.p, w, nullptr, ctx->scratch.p, ctx->gcr_out.p);
+          ctx->ortho_q_cols += 2 * (int64_t)nh * 2; ctx->ortho_q_launches += 2;      // FP64 columns counted as two FP32 ones
+        }
+      }
       for (int pass = 0; pass < 2; ++pass) {
         launch_gcr_dots(st, f32, ctx->KQ.p, ctx->ldq, n, m, w, nullptr, ctx->scratch.p, ctx->hcoef.p);
         FSICHK(gcr_read(ctx, ctx->hcoef.p, m + 2, hh));
@@ -754,7 +785,7 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
           FSICHK(allreduce(ctx, hh, m + 2));
           HIPCHK(hipMemcpyAsync(ctx->hcoef.p, hh, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
         }
-        if (pass == 0) w0 = std::sqrt(std::max(hh[m], 0.0));
+        if (pass == 0 && w0 == 0.0) w0 = std::sqrt(std::max(hh[m], 0.0));
         for (int j = 0; j < m; ++j) htot[j] += hh[j];
         launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, w, r, ctx->scratch.p, ctx->gcr_out.p);
         FSICHK(gcr_read(ctx, ctx->gcr_out.p, 2, hh));
@@ -768,9 +799,14 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
     }
     if (!(wn > 0.0) || !std::isfinite(wn)) { ctx->err = "GCR breakdown (A M^-1 r vanished or is not finite)"; return FSI_ERR_LINEAR; }
     const double alpha = wr / wn;          // q . r with q = w / wn
+    if (f32) {                              // the exact q goes into the FP64 window (ring of 32)
+      qd = ctx->KQh.p + (size_t)ctx->hot_next * ctx->ldq;
+      ctx->hot_slots[ctx->hot_next] = slot;
+      ctx->hot_next = (ctx->hot_next + 1) % 32;
+    }
     launch_gcr_update(st, f32, ctx->KQ.p, ctx->ldq, ctx->KZ.p, ctx->ldz, slot, n, w, z, 1.0 / wn, alpha, r, qd, ctx->scratch.p,
                       ctx->gcr_out.p + 4);
-    src = ctx->gcr_arnoldi ? qd : r;
+    src = (ctx->gcr_arnoldi && !f32) ? qd : r;
     // coefficients of the new direction on the store:  p = (z - sum_j h_j p_j) / wn
     std::vector<double> c(cap, 0.0);
     c[slot] = 1.0;
@@ -823,7 +859,8 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
   if (!std::isfinite(bnorm)) { ctx->err = "non-finite right-hand side"; return FSI_ERR_LINEAR; }
   // the kept directions serve every later solve with this matrix, so the tightest tolerance that may still be asked
   // for (the floor of the inexact-Newton forcing term) decides the re-orthogonalisation criterion, not this solve's
-  const double tol_floor = ctx->gs_rtol > 0.0 ? std::min(ctx->gs_rtol, rtol) : rtol;
+  ctx->gs_rtol = ctx->gs_rtol > 0.0 ? std::min(ctx->gs_rtol, rtol) : rtol;
+  const double tol_floor = ctx->gs_rtol;
   // FP32 storage of Q: the residual recurrence of one cycle is exact to about 1e-6 of the residual the cycle started
   // from; a tighter request is met by restarting the cycle from the true residual b - A x (iterative refinement)
   const double cycle_red = ctx->kry_fp32 ? 1e-5 : 0.0;
@@ -1115,7 +1152,7 @@ int fsi_destroy(FsiCtx* ctx) {
   DevBuf<double>* dbl[] = {&ctx->geom, &ctx->A_pre, &ctx->A, &ctx->LU, &ctx->rowscale, &ctx->U, &ctx->U1, &ctx->F, &ctx->b,
                            &ctx->du, &ctx->bs, &ctx->tmp1, &ctx->tmp2, &ctx->tmp3, &ctx->tmp4, &ctx->tmp5, &ctx->tmp6,
                            &ctx->tmp7, &ctx->scratch, &ctx->bc_vals, &ctx->pf_coef, &ctx->rb_val, &ctx->KZ, &ctx->hcoef,
-                           &ctx->gcr_out, &ctx->gcr_y, &ctx->gcr_cn};
+                           &ctx->gcr_out, &ctx->gcr_y, &ctx->gcr_cn, &ctx->KQh, &ctx->hcoef_hot};
   for (auto* b : dbl) b->release();
   ctx->KQ.release();
   ctx->gcr_slots.release();
@@ -1838,7 +1875,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   // Krylov space: sized from free memory (the recycled directions are what 288 GB of HBM are used for)
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
-  ctx->kry_fp32 = getenv("FSI_KRYLOV_FP32") ? atoi(getenv("FSI_KRYLOV_FP32")) != 0 : 1;
+  ctx->kry_fp32 = getenv("FSI_KRYLOV_FP32") ? atoi(getenv("FSI_KRYLOV_FP32")) != 0 : 0;
   ctx->debug_gcr = getenv("FSI_DEBUG_GCR") != nullptr;
   if (getenv("FSI_NEWTON_FORCING")) ctx->newton_forcing = atof(getenv("FSI_NEWTON_FORCING"));
   if (getenv("FSI_GCR_REORTH")) ctx->gcr_reorth = atof(getenv("FSI_GCR_REORTH"));
@@ -1852,6 +1889,8 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   HIPCHK(ctx->KZ.alloc((size_t)cap * ctx->ldz));
   HIPCHK(ctx->KQ.alloc((size_t)cap * ctx->ldq * (ctx->kry_fp32 ? 4 : 8)));
   HIPCHK(ctx->hcoef.alloc(cap + 2));
+  if (ctx->kry_fp32) { HIPCHK(ctx->KQh.alloc((size_t)32 * ctx->ldq)); HIPCHK(ctx->hcoef_hot.alloc(40)); }
+  ctx->hot_slots.assign(32, -1);
   HIPCHK(ctx->gcr_out.alloc(8));
   HIPCHK(ctx->gcr_y.alloc(cap));
   HIPCHK(ctx->gcr_cn.alloc((size_t)32 * cap));
@@ -2127,9 +2166,7 @@ int fsi_newton_solve(FsiCtx* ctx, const FsiNewtonOpts* o, FsiNewtonIter* iters, 
     // than lin_rtol; without this the last iteration of every step solves a 1e-10-sized system to 1e-20
     double eta = o->lin_rtol;
     if (bnorm > 0.0 && o->atol > 0.0) eta = std::max(eta, std::min(1e-2, ctx->newton_forcing * o->atol / bnorm));
-    ctx->gs_rtol = o->lin_rtol;
     const int src = fsi_solve(ctx, eta, o->lin_max_it, o->lin_solver, &lit, &lrr);
-    ctx->gs_rtol = 0.0;
     FSICHK(src);
     launch_axpy(ctx->stream, ctx->U.p, o->lmbda, ctx->du.p, ctx->ndof);
     launch_bc_set(ctx->stream, ctx->U.p, ctx->bc_dofs.p, ctx->bc_vals.p, ctx->nbc);
@@ -2285,6 +2322,87 @@ int fsi_flow_stats(FsiCtx* ctx, double* out) {
   HIPCHK(hipMemcpyAsync(h, res, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   out[0] = h[0] / (double)ctx->C; out[1] = h[1]; out[2] = h[2]; out[3] = h[3];
+  return FSI_OK;
+}
+
+int fsi_calibration_streams(FsiCtx* ctx, int64_t bytes) {
+  if (!ctx || bytes <= 0) return FSI_ERR_INVALID;
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t have = (int64_t)ctx->KZ.n * 8;
+  if (bytes > have) bytes = have;
+  bytes &= ~(int64_t)255;
+  launch_calibration(ctx->stream, ctx->KZ.p, bytes, ctx->gcr_out.p);      // the direction store is scratch between solves
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  gcr_reset(ctx);
+  return FSI_OK;
+}
+
+int fsi_stress_strain(FsiCtx* ctx, int64_t n, const int32_t* cells, double* out) {
+  if (!ctx || n < 0 || (n > 0 && (!cells || !out))) return FSI_ERR_INVALID;
+  if (n == 0) return FSI_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  std::vector<int32_t> kinds((size_t)ctx->C);
+  HIPCHK(hipMemcpy(kinds.data(), ctx->cell_kind.p, (size_t)ctx->C * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < n; ++i) {
+    if (cells[i] < 0 || cells[i] >= ctx->C) { ctx->err = "fsi_stress_strain: cell out of range"; return FSI_ERR_INVALID; }
+    if (kinds[cells[i]] != 1) { ctx->err = "fsi_stress_strain: cell is not a solid cell"; return FSI_ERR_INVALID; }
+  }
+  DevBuf<int32_t> dc;
+  DevBuf<double> dout;
+  HIPCHK(dc.alloc((size_t)n));
+  HIPCHK(dout.alloc((size_t)n * 80));
+  HIPCHK(hipMemcpyAsync(dc.p, cells, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  launch_stress_strain(ctx->stream, n, elem_arrays(ctx), elem_params(ctx), ctx->U.p, dc.p, dout.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)n * 80 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  dc.release();
+  dout.release();
+  return FSI_OK;
+}
+
+int fsi_wall_shear_stress(FsiCtx* ctx, int64_t nf, const int32_t* facet_cells, const int32_t* facet_local, double mu,
+                          double* out) {
+  if (!ctx || nf < 0 || (nf > 0 && (!facet_cells || !facet_local || !out)) || !(mu > 0.0)) return FSI_ERR_INVALID;
+  if (nf == 0) return FSI_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  // one projection per boundary cell: a cell with several exterior facets couples them through its shared vertices
+  std::vector<int32_t> ucell, mask, slot((size_t)nf);
+  {
+    std::vector<std::pair<int32_t, int64_t>> order((size_t)nf);
+    for (int64_t f = 0; f < nf; ++f) {
+      if (facet_cells[f] < 0 || facet_cells[f] >= ctx->C || facet_local[f] < 0 || facet_local[f] > 3) {
+        ctx->err = "fsi_wall_shear_stress: facet cell / local index out of range";
+        return FSI_ERR_INVALID;
+      }
+      order[f] = {facet_cells[f], f};
+    }
+    std::sort(order.begin(), order.end());
+    for (int64_t k = 0; k < nf; ++k) {
+      if (k == 0 || order[k].first != order[k - 1].first) { ucell.push_back(order[k].first); mask.push_back(0); }
+      mask.back() |= 1 << facet_local[order[k].second];
+      slot[order[k].second] = (int32_t)ucell.size() - 1;
+    }
+  }
+  const int64_t nc = (int64_t)ucell.size();
+  DevBuf<int32_t> dc, dm;
+  DevBuf<double> dout;
+  HIPCHK(dc.alloc((size_t)nc));
+  HIPCHK(dm.alloc((size_t)nc));
+  HIPCHK(dout.alloc((size_t)nc * 12));
+  HIPCHK(hipMemcpyAsync(dc.p, ucell.data(), (size_t)nc * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dm.p, mask.data(), (size_t)nc * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+  launch_wss(ctx->stream, nc, elem_arrays(ctx), ctx->U.p, dc.p, dm.p, mu, dout.p);
+  HIPCHK(hipGetLastError());
+  std::vector<double> h((size_t)nc * 12);
+  HIPCHK(hipMemcpyAsync(h.data(), dout.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  static const int VERTS[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};
+  for (int64_t f = 0; f < nf; ++f)
+    for (int k = 0; k < 3; ++k)
+      for (int i = 0; i < 3; ++i) out[(f * 3 + k) * 3 + i] = h[((size_t)slot[f] * 4 + VERTS[facet_local[f]][k]) * 3 + i];
+  dc.release(); dm.release(); dout.release();
   return FSI_OK;
 }
 

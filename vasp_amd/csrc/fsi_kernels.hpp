@@ -32,6 +32,13 @@ void launch_l2norm(hipStream_t st, int64_t C, const ElemArrays& ea, const double
 void launch_jacobian(hipStream_t st, int part, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
                      const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals);
 
+// fsi_post.hip — solid stress / strain and wall shear stress (cell-local DG1 projections)
+hipError_t upload_post_tables(const double* qw, const double* dN, const double* L);
+void launch_stress_strain(hipStream_t st, int64_t ncell, const ElemArrays& ea, const ElemParams& ep, const double* U,
+                          const int32_t* cells, double* out);
+void launch_wss(hipStream_t st, int64_t ncell, const ElemArrays& ea, const double* U, const int32_t* cells, const int32_t* fmask,
+                double mu, double* out);
+
 // fsi_solver.hip — sparse / dense vector kernels
 void launch_expand_cols(hipStream_t st, int64_t N2, int64_t V, const int64_t* nadj_ptr, const int32_t* nadj,
                         const int64_t* padj_ptr, const int32_t* padj, const int32_t* prow_rank, const int64_t* rowptr,
@@ -60,6 +67,8 @@ void launch_spmv(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t
                  const double* x, double* y, int tag = SPMV_FIELD_BLOCK);
 // reductions: out[0] = x.y (deterministic two-stage); scratch must hold >= 4096 doubles
 void launch_dot(hipStream_t st, const double* x, const double* y, int64_t n, double* scratch, double* out);
+// known-byte read / write streams (4, 8, 16, 32 bytes per lane) over buf[0, bytes): PMC counter calibration
+void launch_calibration(hipStream_t st, void* buf, int64_t bytes, double* out);
 // fsi_gcr.hip — orthogonalisation against the kept directions of the recycled GCR (Q in FP32 or FP64, see there)
 // out[k] = Q_k . w (k < m), out[m] = w . w, out[m+1] = w . r (r may be null); scratch >= (m + 2) * 64 doubles
 void launch_gcr_dots(hipStream_t st, bool fp32, const void* Q, int64_t ldq, int64_t n, int m, const double* w,

@@ -441,4 +441,34 @@ void launch_sptrsv_levels(hipStream_t st, const std::vector<Level>& levels, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Known-byte streams for calibrating the rocprofv3 FETCH_SIZE / WRITE_SIZE counters at the access widths the solver
+// kernels use (MI355X_MICROARCH.md: exact for some widths, half for 16-byte-per-lane reads, uncalibrated otherwise).
+// Each kernel reads (writes) exactly `bytes` once, W bytes per lane and instruction, grid-stride.
+// ---------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_cal_read(const T* __restrict__ src, int64_t count, double* __restrict__ out) {
+  double acc = 0.0;
+  GRID_STRIDE(i, count) {
+    const T v = src[i];
+    acc += (double)reinterpret_cast<const float*>(&v)[0];
+  }
+  if (acc == 12345.678) out[0] = acc;         // keeps the loads alive without a store per thread
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_cal_write(T* __restrict__ dst, int64_t count) {
+  T v;
+  for (size_t b = 0; b < sizeof(T) / 4; ++b) reinterpret_cast<float*>(&v)[b] = 1.0f;
+  GRID_STRIDE(i, count) dst[i] = v;
+}
+void launch_calibration(hipStream_t st, void* buf, int64_t bytes, double* out) {
+  LAUNCH1D(k_cal_read<float>, st, bytes / 4, static_cast<const float*>(buf), bytes / 4, out);
+  LAUNCH1D(k_cal_read<double>, st, bytes / 8, static_cast<const double*>(buf), bytes / 8, out);
+  LAUNCH1D(k_cal_read<float4>, st, bytes / 16, static_cast<const float4*>(buf), bytes / 16, out);
+  LAUNCH1D(k_cal_read<double4>, st, bytes / 32, static_cast<const double4*>(buf), bytes / 32, out);
+  LAUNCH1D(k_cal_write<float>, st, bytes / 4, static_cast<float*>(buf), bytes / 4);
+  LAUNCH1D(k_cal_write<double>, st, bytes / 8, static_cast<double*>(buf), bytes / 8);
+  LAUNCH1D(k_cal_write<float4>, st, bytes / 16, static_cast<float4*>(buf), bytes / 16);
+}
+
 }  // namespace fsi

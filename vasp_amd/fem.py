@@ -88,12 +88,18 @@ def resolve_bcs(bcs: Sequence[DirichletBC], ndof: int):
     for i, bc in enumerate(bcs):
         owner[bc.dofs] = i
     dofs = np.nonzero(owner >= 0)[0]
+    # per condition: which of its dofs it still owns (a later condition may have taken them) and where they sit in `dofs`;
+    # the per-step evaluation then touches only the Dirichlet dofs, not a vector of the size of the problem
+    own = []
+    for i, bc in enumerate(bcs):
+        mine = owner[bc.dofs] == i
+        own.append((mine, np.searchsorted(dofs, bc.dofs[mine])))
 
     def values() -> np.ndarray:
-        g = np.zeros(ndof)
-        for bc in bcs:
-            g[bc.dofs] = bc.values()
-        return g[dofs]
+        out = np.zeros(len(dofs))
+        for bc, (mine, pos) in zip(bcs, own):
+            out[pos] = bc.values()[mine]
+        return out
 
     return dofs, values
 

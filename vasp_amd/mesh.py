@@ -201,7 +201,11 @@ class FsiMesh:
         return area, n
 
     def hmin(self) -> float:
-        """DOLFIN ``mesh.hmin()``: min over cells of the circumradius*2 (cell diameter)."""
+        """DOLFIN ``mesh.hmin()``: min over cells of the circumradius*2 (cell diameter).  The mesh never moves (ALE on the
+        reference configuration), so the value is computed once."""
+        cached = getattr(self, "_hmin", None)
+        if cached is not None:
+            return cached
         x = self.coords[self.tets]
         a = x[:, 1] - x[:, 0]
         b = x[:, 2] - x[:, 0]
@@ -211,7 +215,8 @@ class FsiMesh:
                + np.einsum("ij,ij->i", c, c)[:, None] * np.cross(a, b))
         den = 2.0 * np.einsum("ij,ij->i", a, np.cross(b, c))
         r = np.linalg.norm(num, axis=1) / np.abs(den)
-        return float(2.0 * r.min())
+        self._hmin = float(2.0 * r.min())
+        return self._hmin
 
     # ---- point location (probes) -----------------------------------------------------------------
     def locate(self, pts: np.ndarray, tol: float = 1e-12):

@@ -87,7 +87,9 @@ class WomersleyComponent:
 
     def eval_nodes(self, x: np.ndarray) -> np.ndarray:
         co = self._r_dependent_coeffs(np.ascontiguousarray(x, dtype=float))
-        wom = (co[:, 0] + co[:, 1:] @ self._expnt).real
+        # (an explicit sum: the complex matrix-vector product of this small shape goes through a threaded BLAS path that
+        # costs 30 ms per call - per component and time step)
+        wom = (co[:, 0] + (co[:, 1:] * self._expnt[None, :]).sum(axis=1)).real
         return -self.normal_component * self.scale_value * wom
 
 
