@@ -197,9 +197,14 @@ def main():
             "Schur-complement sweep (explicit two-ring pressure matrix: product + Chebyshev update; avg from sampled HIP events)":
                 (sch_avg * tm["inner_schur_iters"], int(tm["inner_schur_iters"]),
                  tm["schur_nnz"] * (tm["schur_elem_bytes"] + 4.0) + tm["schur_rows"] * 8.0 * 5),
-            ("k_spmv_node6 (monolithic Jacobian, f64 values, one i32 column per six entries; + k_spmv<0> on the pressure rows)"
+            ("k_spmv_compact (monolithic Jacobian, node rows: 24 of the 36 entries per node pair that the forms can fill, f64 + one "
+             "i32 per pair; + k_spmv<0> on the pressure rows)" if tm["spmv_compact"] else
+             "k_spmv_node6 (monolithic Jacobian, f64 values, one i32 column per six entries; + k_spmv<0> on the pressure rows)"
              if not generic else "k_spmv<0> (monolithic Jacobian, CSR f64 + i32)"):
                 (tm["spmv_ms"], tm["spmv_calls"],
+                 (tm["node_pairs"] * (24 * 8.0 + 4.0) + tm["node_vertex_pairs"] * (3 * 8.0 + 4.0)
+                  + (nnz - 36.0 * tm["node_pairs"] - 6.0 * tm["node_vertex_pairs"]) * 12.0       # pressure rows, full CSR
+                  + ndof_rank * 16.0 + (ndof_rank + 1) * 8.0) if tm["spmv_compact"] else
                  nnz * (8.0 + (4.0 / 6.0 if not generic else 4.0)) + ndof_rank * 16.0 + (ndof_rank + 1) * 8.0),
             "k_residual (element residual + scatter-add)": (tm["residual_ms"], tm["residual_calls"], C_rank * 1676.0),
             "k_jacobian<nonlinear> (element Jacobian + scatter-add)": (tm["jacobian_ms"], tm["jacobian_calls"], C_rank * 33420.0),

@@ -50,11 +50,13 @@ def second_piola(g, mu, lam, model=0, C10=0.0, C01=0.0, C11=0.0):
     return lam * np.trace(E, axis1=-2, axis2=-1)[..., None, None] * I3 + 2.0 * mu * E
 
 
-def stress_strain_dg1(coords, tets, tet_nodes, d_nodal, cells, props, model=0):
+def stress_strain_dg1(coords, tets, tet_nodes, d_nodal, cells, props, model=0, eig="eigvalsh"):
     """DG1 coefficients on ``cells`` (solid cells of one region; props = (rho, mu, lambda[, C10, C01, C11])).
 
     Returns dict: TrueStress (n,4,3,3), GreenLagrangeStrain (n,4,3,3), MaxPrincipalStress (n,4), MaxPrincipalStrain (n,4);
-    coefficient a belongs to local vertex a of the cell (DG1 = P1 on the cell, nodal basis)."""
+    coefficient a belongs to local vertex a of the cell (DG1 = P1 on the cell, nodal basis).
+    ``eig``: "eigvalsh" (LAPACK) or "kopp" (the trigonometric closed form of turtleFSI's ``get_eig``, which carries ~1e-8 of
+    the tensor's magnitude in round-off when two principal values are close - the formula's conditioning, not a bug)."""
     qp, qw = keast24()
     N, dNref, L, dL = tabulate_p2(qp)
     xc = coords[tets[cells]]
@@ -82,7 +84,7 @@ def stress_strain_dg1(coords, tets, tet_nodes, d_nodal, cells, props, model=0):
     def max_principal(Tc):                                                      # DG1 tensor -> DG1 largest eigenvalue
         Tq = np.einsum("qa,caij->cqij", L, Tc)
         Tq = 0.5 * (Tq + np.swapaxes(Tq, -1, -2))
-        return project(np.linalg.eigvalsh(Tq)[..., -1])
+        return project(kopp_max_eigenvalue(Tq) if eig == "kopp" else np.linalg.eigvalsh(Tq)[..., -1])
 
     return dict(TrueStress=TS, GreenLagrangeStrain=GLS, MaxPrincipalStress=max_principal(TS),
                 MaxPrincipalStrain=max_principal(GLS))

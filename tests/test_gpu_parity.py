@@ -121,31 +121,38 @@ def test_cylinder_three_steps_match_converged_golden(cylinder_case):
 
 
 def test_offset_stenosis_known_answer_on_gpu(stenosis_case):
-    """The reference's primary known-answer test [REF tests/test_simulations.py:17-57] through the HIP path, with the
-    reference's Newton tolerances; compared with the pins at the oracle's tolerance."""
+    """The reference's primary known-answer test [REF tests/test_simulations.py:17-57] through the HIP path with the
+    reference's Newton policy: tolerances 1e-6, Jacobian reuse, and every Newton system solved (forcing = 0: to 1e-10, the
+    stand-in for the reference's direct LU).  The HIP path must then follow the ORACLE's run of the same policy
+    (tests/golden/stenosis_ref.npz) iteration by iteration; against the reference's pins it inherits the oracle's
+    measured gap (tests/test_oracle_pins.py), bounded here at the same values."""
     from test_oracle_pins import PIN_D, PIN_P, PIN_V, probe
     from vasp_amd.capi import HipBackend
     ns, desc, bc_values, pressure, hook = stenosis_case
     mesh = ns["mesh"]
-    hb = HipBackend(desc, lin_rtol=1e-9)
+    hb = HipBackend(desc, lin_rtol=1e-10, newton_forcing=0.0)
+    gold = np.load(GOLDEN / "stenosis_ref.npz")
+    its = []
     for k in range(5):
         g, P = boundary_data(stenosis_case, 0.01 * (k + 1))
         hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
-        hb.newton_solve(counter=k, first_step_num=0, atol=ns["atol"], rtol=ns["rtol"], max_it=ns["max_it"], lmbda=1.0,
-                        recompute=ns["recompute"], recompute_tstep=ns["recompute_tstep"])
+        h = hb.newton_solve(counter=k, first_step_num=0, atol=ns["atol"], rtol=ns["rtol"], max_it=ns["max_it"], lmbda=1.0,
+                            recompute=ns["recompute"], recompute_tstep=ns["recompute_tstep"])
+        its.append(len(h))
         hb.shift()
     U = hb.get_state("n")
+    assert its == [int(i) for i in gold["iterations"]], (its, gold["iterations"])      # same quasi-Newton trajectory: 3 4 8 11 5
+    G = gold["states"][4]
+    N2 = mesh.num_nodes
+    for name, sl in (("d", slice(0, 3 * N2)), ("v", slice(3 * N2, 6 * N2)), ("p", slice(6 * N2, None))):
+        err = np.linalg.norm(U[sl] - G[sl]) / np.linalg.norm(G[sl])
+        assert err < 2e-6, (name, err)                        # the last Newton update of the policy is ~1e-6; both runs stop there
     v = probe(mesh, U, ns["probe_points"][5], 1)
     p = probe(mesh, U, ns["probe_points"][5], 2)
     d = probe(mesh, U, ns["solid_probe_points"][5], 0)
-    assert np.abs(v - PIN_V).max() < 5e-5 * np.abs(PIN_V).max(), (v, PIN_V)
-    assert np.abs(d - PIN_D).max() < 3e-4 * np.abs(PIN_D).max(), (d, PIN_D)
-    assert abs(p - PIN_P) < 5e-4 * 1.6, (p, PIN_P)
-    gold = GOLDEN / "stenosis_ref.npz"
-    if gold.exists():
-        G = np.load(gold)["states"][4]
-        N2 = mesh.num_nodes
-        assert np.linalg.norm(U[3 * N2:6 * N2] - G[3 * N2:6 * N2]) < 2e-4 * np.linalg.norm(G[3 * N2:6 * N2])
+    assert np.abs(v - PIN_V).max() < 4.8e-7, (v, PIN_V)
+    assert abs(p - PIN_P) < 3.9e-4, (p, PIN_P)
+    assert np.abs(d - PIN_D).max() < 1.4e-8, (d, PIN_D)
     hb.close()
 
 
@@ -459,10 +466,16 @@ def test_stress_strain_kernel_matches_oracle(cyl, cylinder_case):
     cyl.set_state("n", U)
     solid = np.nonzero(np.asarray(desc["cell_kind"]) == 1)[0]
     got = cyl.stress_strain(solid)
-    ref = stress_strain_dg1(mesh.coords, mesh.tets, mesh.tet_nodes, U[:3 * N2].reshape(N2, 3), solid, desc["solid_props"][0])
+    dn = U[:3 * N2].reshape(N2, 3)
+    ref = stress_strain_dg1(mesh.coords, mesh.tets, mesh.tet_nodes, dn, solid, desc["solid_props"][0], eig="kopp")
+    lap = stress_strain_dg1(mesh.coords, mesh.tets, mesh.tet_nodes, dn, solid, desc["solid_props"][0])
     for key in ("TrueStress", "GreenLagrangeStrain", "MaxPrincipalStress", "MaxPrincipalStrain"):
         scale = np.abs(ref[key]).max()
-        assert np.abs(got[key] - ref[key]).max() <= 1e-10 * scale, key
+        # tensors: same arithmetic, round-off; principal values: the kernel uses get_eig's closed form, whose own round-off
+        # is ~1e-8 of the tensor (acos of a ratio near 1), so it is held to the same formula at 1e-7 and to LAPACK at 1e-6
+        tol = 1e-10 if key in ("TrueStress", "GreenLagrangeStrain") else 1e-7
+        assert np.abs(got[key] - ref[key]).max() <= tol * scale, key
+        assert np.abs(got[key] - lap[key]).max() <= 1e-6 * scale, key
     with pytest.raises(Exception):
         cyl.stress_strain(np.nonzero(np.asarray(desc["cell_kind"]) == 0)[0][:2])       # fluid cells are refused
     cyl.set_state("n", np.zeros(cyl.ndof))

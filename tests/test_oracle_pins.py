@@ -6,7 +6,9 @@ after one to a dozen quasi-Newton steps with a direct solve of a matrix whose en
 loop stops, not only on the discrete equations.  What the restatement can and does reproduce is the solution of the
 same discrete equations: the committed runs of the oracle (tests/golden/*.npz, made by tests/golden/make_golden.py)
 agree with every pinned value to a few 1e-5 relative to the field's magnitude - that is the tolerance written below,
-looser than the reference's own np.isclose(rtol=1e-5) / atol=1e-10, and recorded as such in DESIGN.md.
+looser than the reference's own np.isclose(rtol=1e-5) / atol=1e-10, and recorded as such in DESIGN.md.  The bounds below are
+the MEASURED gaps (so that they cannot drift), the reference's own tolerances are held by strict-xfail tests here and in
+tests/test_pin_gap_study.py, which also shows what the gap is not.
 """
 import numpy as np
 import pytest
@@ -29,24 +31,38 @@ def probe(mesh, state, point, fld):
     return MixedFunction(mesh, state).sub(fld)(point)
 
 
-@pytest.mark.parametrize("run", ["stenosis_ref", "stenosis_tight"])
-def test_offset_stenosis_known_answer(stenosis_case, run):
+def _stenosis_probe_values(stenosis_case, run):
     path = GOLDEN / f"{run}.npz"
     if not path.exists():
         pytest.skip(f"{path.name} not generated")
     ns = stenosis_case[0]
     mesh = ns["mesh"]
     U = np.load(path)["states"][4]                      # after step 5 (t = 0.05)
-    v = probe(mesh, U, ns["probe_points"][5], 1)
-    p = probe(mesh, U, ns["probe_points"][5], 2)
-    d = probe(mesh, U, ns["solid_probe_points"][5], 0)
-    vscale, dscale = np.abs(PIN_V).max(), np.abs(PIN_D).max()
-    assert np.abs(v - PIN_V).max() < 5e-5 * vscale, (v, PIN_V)
-    assert np.abs(d - PIN_D).max() < 3e-4 * dscale, (d, PIN_D)
-    if run.endswith("tight"):
+    return (probe(mesh, U, ns["probe_points"][5], 1), probe(mesh, U, ns["probe_points"][5], 2),
+            probe(mesh, U, ns["solid_probe_points"][5], 0))
+
+
+@pytest.mark.parametrize("run", ["stenosis_ref", "stenosis_tight"])
+def test_offset_stenosis_known_answer(stenosis_case, run):
+    """Where the restatement stands against REF tests/test_simulations.py:34-57, bounded by what was measured (not by
+    what would be convenient): the converged run misses the pins by 2.6e-5 (v_x), 7.1e-4 (p) and 1.8e-4 (d_z) relative;
+    p amplifies the velocity gap by rho L / dt.  tests/test_pin_gap_study.py shows on the cylinder case that the gap is
+    neither solver round-off nor stopping noise."""
+    v, p, d = _stenosis_probe_values(stenosis_case, run)
+    tight = run.endswith("tight")
+    assert np.abs(v - PIN_V).max() < (3.4e-7 if tight else 4.8e-7), (v, PIN_V)
+    assert abs(p - PIN_P) < (3.1e-4 if tight else 3.9e-4), (p, PIN_P)
+    assert np.abs(d - PIN_D).max() < (8.3e-9 if tight else 1.4e-8), (d, PIN_D)
+    if tight:
         assert np.allclose(d, PIN_D, rtol=1e-5, atol=1e-8)          # the reference's own tolerance holds for converged d
-    # the probe pressure crosses zero during these steps (-1.6 .. +0.43 Pa); compare on that scale
-    assert abs(p - PIN_P) < 5e-4 * 1.6, (p, PIN_P)
+
+
+@pytest.mark.xfail(strict=True, reason="oracle vs reference pins of the primary known-answer test: v_x off by 3.3e-7 (allowed 1.4e-7), "
+                                       "p by 3.0e-4 (allowed 4.3e-6); tests/test_pin_gap_study.py, DESIGN.md §2")
+def test_reference_tolerance_on_offset_stenosis_pins(stenosis_case):
+    """REF tests/test_simulations.py:43-44, verbatim: np.isclose defaults (rtol 1e-5, atol 1e-8) on v and p of probe 5."""
+    v, p, d = _stenosis_probe_values(stenosis_case, "stenosis_tight")
+    assert np.isclose(v, PIN_V).all() and np.isclose(p, PIN_P)
 
 
 @pytest.mark.parametrize("run", ["cylinder_ref", "cylinder_tight"])
@@ -55,8 +71,8 @@ def test_cylinder_known_answers(cylinder_case, run):
     S = np.load(GOLDEN / f"{run}.npz")["states"]
     N2 = mesh.num_nodes
     vx, dx = S[:, 3 * N2], S[:, 0]
-    assert np.abs(vx / PIN_CYL_VX - 1).max() < 3e-4, vx
-    assert np.abs(dx / PIN_CYL_DX - 1).max() < 1e-4, dx
+    assert np.abs(vx / PIN_CYL_VX - 1).max() < (9e-5 if run.endswith("tight") else 2.9e-4), vx     # measured: 8.6e-5 / 2.8e-4
+    assert np.abs(dx / PIN_CYL_DX - 1).max() < 7e-5, dx                                             # measured: 6.0e-5 / 6.8e-5
     assert np.allclose(dx, PIN_CYL_DX, rtol=0, atol=1e-10)          # the reference's own tolerance holds for d_x
     # d_x(t1) = dt theta v_x(t1) for an interface vertex, zero initial state
     assert np.isclose(dx[0], 1e-3 * 0.51 * vx[0], rtol=1e-9)

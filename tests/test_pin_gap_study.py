@@ -1,0 +1,160 @@
+"""Where the oracle stands against the reference's known answers, as checks instead of prose.
+
+The reference cannot run here, so what can be established about the remaining gap between the oracle and
+the pinned numbers of REF tests/test_create_hdf5_and_separate_viz.py:40-51,196-206 / tests/test_predeform.py:32-33 is
+established on the cylinder case (1 647 tets, 3 steps), where every step is cheap enough to perturb:
+
+1. the linear solves are not the source: one SuperLU solve of the first Newton system is accurate to 1e-10 of v_x;
+2. the structure of the discrete equations is right where the pins can see it: the pinned pairs (v_x, d_x) at the interface
+   vertex violate d = dt (theta v^n + (1 - theta) v^{n-1}) by 2.695e-5 d - the footprint of the fluid's Laplace lifting
+   term (alfa = 1) on a d-row whose penalty is delta rho_s / k - and the oracle reproduces that number to five digits at all
+   three steps (delta = 1e7, alfa, theta, the P2 mass and stiffness matrices are therefore the reference's);
+3. stopping noise is not the source either: after the first Newton iteration from rest (exact Jacobian) v_x is 6.1e-5 above
+   the pin, after the second it has converged and is 2.1e-5 below; no iteration count of the restated algorithm lands on
+   the pin, so the difference is in the discrete equations or their data, at the 2e-5 level (8e-5 at step 2);
+4. it is not one of the obvious candidates: no single physical parameter (rho_f, mu_f, rho_s, mu_s, lambda_s, the load, the
+   inlet amplitude, delta) moved within a linear fit closes the nine gaps.  (Also tried in round 2, not part of this
+   file: the docs' Nanson-formula variant of the interface load, REF docs/aneurysm.md:126-135, moves step 1 from -2.1e-5
+   to -2.7e-5, i.e. away from the pin; rho_f = 1000; partial-nonlinearity variants of the solid stress.)
+
+What follows from 1-4 for the parity status is written in DESIGN.md §2; the strict-xfail tests at the end hold the
+reference's own tolerances and will flip the day the gap is closed.
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from conftest import GOLDEN
+
+PIN_V = np.array([4.38261949610407e-6, 5.244315455211961e-6, 8.137814761280497e-6])
+PIN_D = np.array([2.235075700301419e-9, 7.0569699656660426e-9, 1.3776599148439903e-8])
+PIN_PRE = np.array([7.382372340085156e-5, -1.1083576098054155e-4, 4.930899508039441e-4])
+DT, THETA = 1e-3, 0.51
+
+
+@pytest.fixture(scope="module")
+def study(cylinder_case):
+    """The cylinder problem with the Jacobian at rest factorised once; run(policy) replays the three steps."""
+    from oracle.fsi_oracle import FsiOracle
+    ns, desc, bc_values, pressure, hook = cylinder_case
+    o = FsiOracle(desc)
+    Z = np.zeros(o.ndof)
+    o.solver_setup(Z, Z)
+    A = o.jacobian(Z, Z)
+    lu = spla.splu(A.tocsc())
+    N2 = o.N2
+
+    def data(k):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ns["t"] = DT * (k + 1)
+            hook("pre_solve")(**ns)
+        return bc_values(), float(pressure.P)
+
+    def run(max_newton, oracle=o, pscale=1.0, vscale=1.0):
+        U, U1 = np.zeros(o.ndof), np.zeros(o.ndof)
+        vs, ds = [], []
+        for k in range(3):
+            g, P = data(k)
+            g, P = g * vscale, P * pscale
+            for it in range(max_newton[k]):
+                dU = lu.solve(oracle.rhs(U, U1, P, g))
+                U += dU
+                U[o.bc_dofs] = g
+            vs.append(U[3 * N2]); ds.append(U[0])
+            U1[:] = U
+        return np.array(vs), np.array(ds), U[:3].copy()
+
+    return dict(o=o, A=A, lu=lu, run=run, data=data, ns=ns, desc=desc)
+
+
+def test_linear_solve_is_accurate(study):
+    o, A, lu = study["o"], study["A"], study["lu"]
+    g, P = study["data"](0)
+    Z = np.zeros(o.ndof)
+    b = o.rhs(Z, Z, P, g)
+    x = lu.solve(b)
+    r = b - A @ x
+    dx = lu.solve(r)                                    # one step of iterative refinement
+    assert abs(dx[3 * o.N2]) <= 1e-10 * abs(x[3 * o.N2])
+
+
+def test_pins_carry_the_laplace_footprint_and_the_oracle_reproduces_it(study):
+    def violation(v, d):
+        vbar = np.array([THETA * v[0], THETA * v[1] + (1 - THETA) * v[0], THETA * v[2] + (1 - THETA) * v[1]])
+        inc = np.array([d[0], d[1] - d[0], d[2] - d[1]])
+        return (DT * vbar - inc) / d
+    pin = violation(PIN_V, PIN_D)
+    v, d, _ = study["run"]([3, 3, 3])
+    ours = violation(v, d)
+    assert np.allclose(pin, 2.695e-5, rtol=2e-3)         # the pins themselves: 2.6953e-5, 2.6948e-5, 2.6924e-5
+    assert np.abs(ours / pin - 1).max() < 5e-5           # same number from the restated equations, five digits
+
+
+def test_no_iteration_count_lands_on_the_pin(study):
+    v1, _, _ = study["run"]([1, 0, 0])
+    v2, _, _ = study["run"]([2, 0, 0])
+    v3, _, _ = study["run"]([3, 0, 0])
+    assert abs(v3[0] / v2[0] - 1) < 1e-7                                  # two iterations have converged (to 5e-8)
+    above, below = v1[0] / PIN_V[0] - 1, v2[0] / PIN_V[0] - 1
+    assert 5.5e-5 < above < 6.7e-5 and -2.4e-5 < below < -1.8e-5            # +6.1e-5 / -2.1e-5: the pin lies strictly between
+
+
+def test_no_single_parameter_closes_the_gaps(study):
+    import copy
+    from oracle.fsi_oracle import FsiOracle
+    import oracle.fsi_oracle as fo
+    X0 = study["ns"]["mesh"].coords[0]
+
+    def obs(res):
+        v, d, d3 = res
+        return np.concatenate([v / PIN_V - 1, d / PIN_D - 1, (d3 - (X0 - PIN_PRE)) / d3])
+
+    run, desc = study["run"], study["desc"]
+    y0 = obs(run([3, 4, 4]))
+    assert 1.4e-4 < np.linalg.norm(y0) < 1.7e-4          # the nine gaps: 2e-5 ... 8.6e-5 each
+    eps = 1e-3
+    cols = []
+
+    def variant(key, idx):
+        d2 = copy.deepcopy(desc)
+        rows = [list(p) for p in d2[key]]
+        for p in rows:
+            p[idx] *= 1 + eps
+        d2[key] = [tuple(p) for p in rows]
+        return FsiOracle(d2)
+
+    for key, idx in (("fluid_props", 0), ("fluid_props", 1), ("solid_props", 0), ("solid_props", 1), ("solid_props", 2)):
+        cols.append((obs(run([4, 5, 5], oracle=variant(key, idx))) - y0) / eps)
+    cols.append((obs(run([3, 4, 4], pscale=1 + eps)) - y0) / eps)
+    cols.append((obs(run([3, 4, 4], vscale=1 + eps)) - y0) / eps)
+    fo.DELTA = 1e7 * (1 + eps)
+    try:
+        cols.append((obs(run([4, 5, 5])) - y0) / eps)
+    finally:
+        fo.DELTA = 1e7
+    for c in cols:                                        # best single-parameter fit leaves more than 60 % of the gap
+        a = -(c @ y0) / (c @ c)
+        assert np.linalg.norm(y0 + a * c) > 0.6 * np.linalg.norm(y0)
+
+
+@pytest.mark.xfail(strict=True, reason="oracle vs reference pin: 4.5e-10 / 5.7e-10 against the reference's atol 1e-10 (+ rtol 1e-5); "
+                                       "see the module docstring and DESIGN.md §2")
+def test_reference_tolerance_on_cylinder_velocity_pins():
+    """REF tests/test_create_hdf5_and_separate_viz.py:40-46,196-201, verbatim tolerance."""
+    S = np.load(GOLDEN / "cylinder_tight.npz")["states"]
+    N2 = (S.shape[1] - 352) // 6
+    assert np.isclose(S[:, 3 * N2], PIN_V, atol=1e-10).all()
+
+
+def test_reference_tolerance_holds_for_the_displacement_pins_and_the_first_velocity_pin():
+    """REF tests/test_create_hdf5_and_separate_viz.py:47-51,202-206 and tests/test_predeform.py:32-33, verbatim tolerances."""
+    S = np.load(GOLDEN / "cylinder_tight.npz")["states"]
+    N2 = (S.shape[1] - 352) // 6
+    assert np.isclose(S[:, 0], PIN_D, atol=1e-10).all()
+    assert np.isclose(S[0, 3 * N2], PIN_V[0], atol=1e-10)
+    from vasp_amd.mesh import FsiMesh
+    x0 = FsiMesh.read(GOLDEN / "cylinder" / "cylinder.h5").coords[0]
+    assert np.allclose(x0 - S[2, :3], PIN_PRE, atol=1e-10)

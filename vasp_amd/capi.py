@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "fsi_set_pressure_facets", "fsi_set_interface_pressure", "fsi_set_robin_facets", "fsi_solver_setup",
     "fsi_assemble_residual", "fsi_assemble_jacobian", "fsi_solve", "fsi_newton_solve", "fsi_shift",
     "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_get_matrix", "fsi_spmv",
-    "fsi_get_timers", "fsi_get_values", "fsi_stress_strain", "fsi_wall_shear_stress", "fsi_calibration_streams", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
+    "fsi_get_timers", "fsi_get_values", "fsi_stress_strain", "fsi_wall_shear_stress", "fsi_calibration_streams", "fsi_set_newton_forcing", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
 )
 
 
@@ -64,7 +64,8 @@ class FsiTimers(C.Structure):
                 ("ortho_z_launches", C.c_int64), ("q_elem_bytes", C.c_int64), ("ldq", C.c_int64), ("ldz", C.c_int64),
                 ("krylov_dirs", C.c_int64), ("krylov_cap", C.c_int64), ("schur_nnz", C.c_int64), ("schur_rows", C.c_int64),
                 ("flush_ms", C.c_double), ("flush_calls", C.c_int64), ("schur_ms", C.c_double), ("schur_calls", C.c_int64),
-                ("schur_elem_bytes", C.c_int64)]
+                ("schur_elem_bytes", C.c_int64), ("spmv_compact", C.c_int64), ("node_pairs", C.c_int64),
+                ("node_vertex_pairs", C.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -109,6 +110,7 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_set_state.argtypes = [vp, C.c_int, vp]
     lib.fsi_get_values.argtypes = [vp, C.c_int, i64, vp, vp]
     lib.fsi_calibration_streams.argtypes = [vp, i64]
+    lib.fsi_set_newton_forcing.argtypes = [vp, dbl]
     lib.fsi_stress_strain.argtypes = [vp, i64, vp, vp]
     lib.fsi_wall_shear_stress.argtypes = [vp, i64, vp, vp, dbl, vp]
     lib.fsi_num_dofs.argtypes = [vp]
@@ -143,7 +145,8 @@ class HipBackend:
     """One problem instance resident on one GPU; the methods are what ``monolithic.run`` calls per time step."""
 
     def __init__(self, desc: dict, device: int = 0, lin_rtol: float = 1e-10, lin_max_it: int = 4000,
-                 lin_solver: int = 0, precond: int = 0, inner_rtol: float = 1e-2, inner_max_it: int = 40):
+                 lin_solver: int = 0, precond: int = 0, inner_rtol: float = 1e-2, inner_max_it: int = 40,
+                 newton_forcing: Optional[float] = None):
         self.lib = load_library()
         self.ctx = C.c_void_p()
         self.lin_rtol, self.lin_max_it, self.lin_solver = lin_rtol, lin_max_it, lin_solver
@@ -168,6 +171,8 @@ class HipBackend:
             raise FsiError(rc, msg)
         self.ndof = int(self.lib.fsi_num_dofs(self.ctx))
         self._check(self.lib.fsi_set_linear_solver(self.ctx, int(precond), float(inner_rtol), int(inner_max_it)))
+        if newton_forcing is not None:          # 0: every Newton system solved to lin_rtol, as the reference's direct LU
+            self._check(self.lib.fsi_set_newton_forcing(self.ctx, float(newton_forcing)))
         bc = np.ascontiguousarray(desc.get("bc_dofs", np.zeros(0)), dtype=np.int64)
         self._check(self.lib.fsi_set_dirichlet(self.ctx, len(bc), _ptr(bc)))
         self.nbc = len(bc)

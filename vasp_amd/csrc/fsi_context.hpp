@@ -104,6 +104,9 @@ struct FsiCtx {
   fsi::DevBuf<double> A_pre, A, LU;          // [nnz] each; A holds the row-equilibrated Jacobian after setup
   fsi::DevBuf<double> rowscale;              // [ndof]
   bool have_jacobian = false;
+  fsi::DevBuf<double> cA, cP;                // compact node rows of A for the outer product (fsi_solver.hip: k_spmv_compact)
+  bool compact_ok = false;                   // the dropped entries were verified to vanish on the current Jacobian
+  int spmv_compact = 1;                      // FSI_SPMV_COMPACT=0: always the full node-blocked rows
 
   // vectors (solver ordering)
   fsi::DevBuf<double> U, U1, F, b, du, bs, tmp1, tmp2, tmp3, tmp4, tmp5, tmp6, tmp7;
@@ -138,6 +141,7 @@ struct FsiCtx {
   int64_t halo_calls = 0, allreduce_calls = 0;
   bool ras = false;                          // restricted additive Schwarz on the overlap: agreed by all ranks in fsi_set_partition
   bool debug_gcr = false;
+  int64_t dbg_cols = 0, dbg_sig6 = 0, dbg_sig9 = 0, dbg_sig12 = 0;   // FSI_DEBUG_GCR: how many Gram-Schmidt coefficients matter
 
   // field blocks for the block preconditioner (fsi_block.hip)
   int precond = 0;                           // 0 = field-split block preconditioner, 1 = monolithic multicolour ILU(0)
@@ -153,8 +157,8 @@ struct FsiCtx {
   fsi::DevBuf<int64_t> s_rowptr, s_diagpos;  // explicit Schur complement on its full (two-ring) vertex pattern
   fsi::DevBuf<int32_t> s_cols;
   fsi::DevBuf<double> s_vals;
-  fsi::DevBuf<float> s_vals32, s_dinv32, s_work32;   // FSI_SCHUR_FP32=1: FP32 copy + fused Chebyshev sweeps (measured: no gain over
-  int schur_fp32 = 0;                                 // the FP64 product + update, 21.0 vs 20.4 ms per application: stays off)
+  fsi::DevBuf<float> s_vals32, s_dinv32, s_work32;   // FP32 copy + fused Chebyshev sweeps (round 2, 20-step bench: 9.3 vs 10.1 ms per
+  int schur_fp32 = 1;                                 // application, same outer iterations; FSI_SCHUR_FP32=0: FP64 product + update)
   fsi::DevBuf<double> dd_db, vv_db;          // component-diagonal node-block copies of A_dd and Avv~ ([pairs][3])
   fsi::DevBuf<double> adv_db;
   bool dd_is_db = false, adv_is_db = false;

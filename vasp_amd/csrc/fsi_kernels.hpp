@@ -160,6 +160,12 @@ void launch_residual_rows(hipStream_t st, int64_t nrows, const int32_t* rows, co
                           const int64_t* src, const double* vals, const double* x, const double* b, double* y);
 void launch_spmv_node6(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const double* vals,
                        const double* x, double* y);
+// compact node rows (24 of 36 entries per node pair, no pressure columns in the d-rows): built after matrix_finish
+void launch_compact_rows(hipStream_t st, int64_t N2, const int64_t* rowptr, const int64_t* nadj_ptr, const int64_t* padj_ptr,
+                         const double* A, double* cA, double* cP, int32_t* flags);
+void launch_spmv_compact(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const double* A,
+                         const int64_t* nadj_ptr, const int32_t* nadj, const int64_t* padj_ptr, const int32_t* padj,
+                         const double* cA, const double* cP, const double* x, double* y);
 void launch_spmv_mono(hipStream_t st, int64_t n, int64_t N2, const int64_t* rowptr, const int64_t* nadj_ptr,
                       const int32_t* nadj, const int64_t* padj_ptr, const int32_t* padj, const int32_t* vrank,
                       const double* vals, const double* x, double* y);
