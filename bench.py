@@ -217,13 +217,28 @@ def main():
                            "share_of_timed_region": ms / (1e3 * elapsed)}
         dom = max(table, key=lambda k: table[k]["gpu_ms"])
         d = table[dom]
+        # HBM traffic per launch from the PMC passes of this same command (tools/gpu_pmc_r2.sh -> profiles/r02_pmc_traffic.json:
+        # 2 x FETCH_SIZE + WRITE_SIZE, the factors calibrated on known-byte streams); a group of kernels is averaged over its
+        # launches
         traffic = None
-        pmc = ROOT / "profiles" / "r02_pmc_traffic.json"       # corrected FETCH_SIZE + WRITE_SIZE per launch (tools/pmc_traffic.py)
+        pmc = ROOT / "profiles" / "r02_pmc_traffic.json"
+        groups = {"k_gcr_dots": [f"k_gcr_dots<{'double' if qb == 8 else 'float'}>", f"k_gcr_axpy<{'double' if qb == 8 else 'float'}>"],
+                  "k_gcr_flush": ["k_gcr_flush<0>", "k_gcr_flush<4>", "k_gcr_flush<8>", "k_gcr_flush<16>", "k_gcr_flush<32>"],
+                  "k_spmv_node6": ["k_spmv_node6", "k_spmv<0>"], "k_spmv_compact": ["k_spmv_compact", "k_spmv<0>"],
+                  "k_spmv_tiled_f32<1>": ["k_spmv_tiled_f32<1>"], "k_spmv_tiled_f32<3>": ["k_spmv_tiled_f32<3>"],
+                  "k_sweep_sb_b3<0>": ["k_sweep_sb_b3<0>"], "Schur": ["k_sweep_csr_f32", "k_spmv<2>"],
+                  "k_residual": ["k_residual"], "k_jacobian": ["k_jacobian<2>"]}
         if pmc.exists():
             with contextlib.suppress(Exception):
-                for key, val in json.loads(pmc.read_text()).get("per_launch_bytes", {}).items():
+                det = json.loads(pmc.read_text()).get("detail", {})
+                for key, names in groups.items():
                     if dom.startswith(key):
-                        traffic = val
+                        rows = [det[nm] for nm in names if nm in det]
+                        if key in ("k_spmv_node6", "k_spmv_compact"):            # one product = one launch of each
+                            traffic = sum(r["fetch_bytes"] + r["write_bytes"] for r in rows)
+                        elif rows:
+                            nl = sum(r["launches"] for r in rows)
+                            traffic = sum((r["fetch_bytes"] + r["write_bytes"]) * r["launches"] for r in rows) / max(nl, 1)
         out = {
             "metric": "Newton-iterations/sec (offset_stenosis, monolithic ALE-FSI step)",
             "value": total_newton / elapsed, "unit": "Newton-iterations/s", "n_gpus": world, "steps": args.steps,

@@ -500,3 +500,23 @@ def test_wall_shear_stress_kernel_matches_oracle(cyl, cylinder_case):
     ref = wall_shear_stress(mesh.coords, mesh.tets, mesh.tet_nodes, U[3 * N2:6 * N2].reshape(N2, 3), cell, local, mu)
     assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
     cyl.set_state("n", np.zeros(cyl.ndof))
+
+
+def test_compact_rows_product_matches_oracle(cylinder_case, monkeypatch):
+    """FSI_SPMV_COMPACT=1 (opt-in): the outer product on the 24-of-36 compact node rows is the same operator."""
+    from oracle.fsi_oracle import FsiOracle
+    from vasp_amd.capi import HipBackend
+    monkeypatch.setenv("FSI_SPMV_COMPACT", "1")
+    ns, desc = cylinder_case[0], cylinder_case[1]
+    o = FsiOracle(desc)
+    hb = HipBackend(desc)
+    U, U1 = random_state(ns["mesh"], o.ndof, seed=9)
+    g, P = boundary_data(cylinder_case, 0.05)
+    hb.set_state("n", U); hb.set_state("n-1", U1); hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+    o.solver_setup(np.zeros(o.ndof), np.zeros(o.ndof))
+    A_ref = o.jacobian(U, U1)
+    hb.assemble_jacobian()
+    assert hb.timers()["spmv_compact"] == 1
+    x = np.random.default_rng(10).standard_normal(o.ndof)
+    assert np.abs(hb.spmv(x) - A_ref @ x).max() <= 1e-11 * np.abs(A_ref @ x).max()
+    hb.close()

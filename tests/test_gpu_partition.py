@@ -88,3 +88,46 @@ def test_partitioned_steps_match_single_context(world, tmp_path):
     assert b_part == pytest.approx(b_one, rel=1e-4, abs=1e-10 * r_one.max())
     print("krylov iterations per Newton iteration:", world, "ranks", [it[3] for h in hist_part for it in h], "single",
           [it[3] for h in hist_one for it in h])
+
+
+def _failing_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if rank == 1:
+        os.environ["FSI_DEBUG_FORCE_PREC_BAD"] = "1"        # only this rank's preconditioner self-test reports a failure
+    import tempfile
+    import torch.distributed as dist
+    from conftest import prepare_case
+    from vasp_amd.capi import FsiError
+    from vasp_amd.partition import DistBackend
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ns, desc, bc_values, pressure, hook = prepare_case("cylinder", GOLDEN / "cylinder" / "cylinder.h5", tempfile.mkdtemp(),
+                                                        T="0.003")
+    db = DistBackend(desc, dist, device=0, lin_rtol=1e-10)
+    outcome = "no error"
+    try:
+        _time_steps(db, ns, bc_values, pressure, hook)
+    except FsiError as e:
+        outcome = f"FsiError {e.code}"
+    q.put((rank, outcome))
+    dist.barrier()
+    db.close()
+    dist.destroy_process_group()
+
+
+def test_a_rank_local_failure_is_raised_on_every_rank_instead_of_hanging():
+    """a status decided from rank-local data must be agreed on before the next collective.  One of two ranks is
+    made to fail its preconditioner self-test; both must leave newton_solve with FSI_ERR_LINEAR (code 4), promptly."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert got == {0: "FsiError 4", 1: "FsiError 4"}, got

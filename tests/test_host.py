@@ -216,3 +216,88 @@ def test_avf_problem_two_solid_regions(tmp_path):
     g = np.zeros(mesh.num_dofs)
     g[desc["bc_dofs"]] = bc_values()
     assert np.abs(mesh.split(g)[1]).max() > 0                                              # inlets carry the table value
+
+
+class _StubBackend:
+    """Stands in for the time-step kernel where only the host driver is under test."""
+
+    def __init__(self, desc):
+        self.n = 6 * int(desc["num_nodes"]) + len(desc["coords"])
+        self.U = np.zeros(self.n)
+        self.steps = 0
+
+    def set_dirichlet_values(self, v): pass
+    def set_interface_pressure(self, P): pass
+
+    def newton_solve(self, **kw):
+        self.steps += 1
+        self.U[:] = self.steps
+        return [(1e-3, 1e-4, False, 3, 1e-9), (1e-8, 1e-9, False, 2, 1e-9)]
+
+    def shift(self): pass
+
+    def get_state(self, which, out=None):
+        out[:] = self.U
+        return out
+
+    def set_state(self, which, x): self.U[:] = x
+
+
+def _run_cylinder(tmp_path, extra=(), T="0.02"):
+    from vasp_amd import monolithic
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ns = monolithic.run(["-p", "cylinder", "-dt", "0.001", "-T", T, "--theta", "0.51", "--folder", str(tmp_path), "--sub-folder",
+                             "1", "--save-deg", "1", "--new-arguments", f"mesh_path={GOLDEN / 'cylinder' / 'cylinder.h5'}", *extra],
+                            backend_factory=_StubBackend, out=print)
+    return ns, buf.getvalue()
+
+
+def test_killturtle_sentinel_checkpoints_and_stops(tmp_path):
+    """turtleFSI's run controls: a ``killturtle`` file in the results folder -> checkpoint, stop."""
+    (tmp_path / "1").mkdir(parents=True)
+    (tmp_path / "1" / "killturtle").write_text("")
+    ns, out = _run_cylinder(tmp_path)
+    assert ns["backend"].steps == 1 and "killturtle found" in out and out.count("Solved for timestep") == 1
+    assert not (tmp_path / "1" / "killturtle").exists()
+    import json
+    meta = json.loads((tmp_path / "1" / "Checkpoint" / "default_variables.json").read_text())
+    assert meta["counter"] == 0 and abs(meta["t"] - 1e-3) < 1e-12
+
+
+def test_killtime_stops_the_loop_and_restart_continues_the_series(tmp_path):
+    ns, out = _run_cylinder(tmp_path, extra=("killtime=0",))
+    assert ns["backend"].steps == 1 and "Reached killtime" in out
+    # restart from that folder: same folder, run file 1, counter and time carried over
+    ns2, out2 = _run_cylinder(tmp_path / "unused", extra=("--restart-folder", str(tmp_path / "1")), T="0.003")
+    assert ns2["results_folder"] == tmp_path / "1"
+    assert (tmp_path / "1" / "Visualization" / "velocity_run_1.h5").exists()
+    text = (tmp_path / "1" / "Visualization" / "velocity.xdmf").read_text()
+    assert "velocity.h5:/VisualisationVector/0" in text and "velocity_run_1.h5:/VisualisationVector/0" in text
+
+
+def test_host_state_is_fetched_only_when_a_hook_reads_it(tmp_path):
+    """post_solve of the cylinder problem needs probes / cell statistics / the inlet patch only: the driver must not pull the
+    whole state vector off the device every step (it did in round 1: 74 MB per step at 1 M tets)."""
+    calls = []
+
+    class Counting(_StubBackend):
+        def get_state(self, which, out=None):
+            calls.append(which)
+            return super().get_state(which, out)
+
+        def get_values(self, which, dofs):
+            return self.U[dofs]
+
+        def flow_stats(self):
+            return (0.1, 0.0, 0.2, 1.0)
+
+        def probe(self, cells, bary):
+            return np.zeros((len(cells), 7))
+
+    from vasp_amd import monolithic
+    with contextlib.redirect_stdout(io.StringIO()):
+        monolithic.run(["-p", "cylinder", "-dt", "0.001", "-T", "0.004", "--theta", "0.51", "--folder", str(tmp_path), "--sub-folder", "1",
+                        "--save-step", "1000", "--checkpoint-step", "1000", "--new-arguments",
+                        f"mesh_path={GOLDEN / 'cylinder' / 'cylinder.h5'}"], backend_factory=Counting, out=print)
+    assert calls.count("n") <= 1 and "n-1" not in calls          # only the checkpoint / frame of step 0 reads the vector

@@ -75,3 +75,33 @@ def test_checkpoint_round_trip(tmp_path):
     assert sorted(g) == ["cell_dofs", "cells", "mesh", "vector", "x_cell_dofs"]
     assert g["vector"].data.shape == (3 * m.num_nodes, 1) and g["x_cell_dofs"].data.shape == (m.num_cells + 1,)
     assert g["cell_dofs"].data.shape == (30 * m.num_cells,) and not (tmp_path / "tmp_checkpoint_v1.h5").exists()
+
+
+def test_visualization_series_is_streamed_in_segments_and_continues_after_a_restart(tmp_path):
+    """A long series never sits in memory as a whole: frames go to <name>.h5, <name>_run_1.h5, ... in bounded segments,
+    and the XDMF names file and index per time step - what the reference's output_file_lists reads
+    [REF src/vasp/postprocessing/postprocessing_common.py:63-121] (a restarted turtleFSI run leaves the same pattern)."""
+    m = FsiMesh.read(GOLDEN / "cylinder" / "cylinder.h5")
+    rng = np.random.default_rng(2)
+    frame = 8 * 3 * m.num_nodes
+    w = VisualizationWriter(tmp_path, m, save_deg=2, segment_bytes=2 * frame + 1)       # two frames per file
+    states = [rng.standard_normal(m.num_dofs) for _ in range(5)]
+    for k, s in enumerate(states):
+        w.write(s, 1e-3 * (k + 1))
+        assert sum(len(v) for v in w.frames.values()) <= 3 * 2                           # never more than one segment held
+    w.flush()
+    files, times, idx = parse_xdmf(tmp_path / "velocity.xdmf")
+    assert files == ["velocity.h5", "velocity.h5", "velocity_run_1.h5", "velocity_run_1.h5", "velocity_run_2.h5"]
+    assert idx == [0, 1, 0, 1, 0] and np.allclose(times, 1e-3 * np.arange(1, 6))
+    for k, (f, i) in enumerate(zip(files, idx)):
+        arr = read_h5(tmp_path / f)["VisualisationVector"][str(i)].data
+        assert np.array_equal(arr, m.split(states[k])[1])
+    assert "Mesh" in read_h5(tmp_path / "velocity.h5") and "Mesh" not in read_h5(tmp_path / "velocity_run_1.h5")
+    # --restart-folder: a new writer adopts the series and goes on in the next run file
+    w2 = VisualizationWriter(tmp_path, m, save_deg=2, run_index=3)
+    extra = rng.standard_normal(m.num_dofs)
+    w2.write(extra, 6e-3)
+    w2.flush()
+    files, times, idx = parse_xdmf(tmp_path / "velocity.xdmf")
+    assert files[-1] == "velocity_run_3.h5" and idx[-1] == 0 and len(times) == 6 and times[-1] == 6e-3
+    assert np.array_equal(read_h5(tmp_path / "velocity_run_3.h5")["VisualisationVector"]["0"].data, m.split(extra)[1])

@@ -4,7 +4,9 @@ The counters are KiB at the L2's memory side (MI355X_MICROARCH.md §HBM).  Their
 the driver first streams a known number of bytes with 4-, 8-, 16- and 32-byte loads and 4-, 8-, 16-byte stores per lane
 (k_cal_read<T> / k_cal_write<T>); the factor bytes / (counter * 1024) of the matching width corrects every other kernel.
 
-    python tools/pmc_traffic.py FETCH_summary.csv WRITE_summary.csv CAL_BYTES > profiles/r02_pmc_traffic.json
+    python tools/pmc_traffic.py FETCH_summary.csv WRITE_summary.csv CAL_BYTES [CAL_FETCH_summary.csv CAL_WRITE_summary.csv]
+        > profiles/r02_pmc_traffic.json
+(the calibration kernels may come from a separate, short run of tools/pmc_driver.py: last two arguments)
 """
 import csv, json, sys
 
@@ -15,15 +17,16 @@ def load(path):
     return out
 
 fetch, write, cal_bytes = load(sys.argv[1]), load(sys.argv[2]), float(sys.argv[3])
+cal_fetch, cal_write = (load(sys.argv[4]), load(sys.argv[5])) if len(sys.argv) > 5 else (fetch, write)
 def factor(table, kern, typ):
     for name, (v, n) in table.items():
         if kern in name and typ in name and v > 0:
             return cal_bytes / (v * 1024.0)
     return None
-cal = {"read4": factor(fetch, "k_cal_read", "<float>"), "read8": factor(fetch, "k_cal_read", "<double>"),
-       "read16": factor(fetch, "k_cal_read", "<float, 4"), "read32": factor(fetch, "k_cal_read", "<double, 4"),
-       "write4": factor(write, "k_cal_write", "<float>"), "write8": factor(write, "k_cal_write", "<double>"),
-       "write16": factor(write, "k_cal_write", "<float, 4")}
+cal = {"read4": factor(cal_fetch, "k_cal_read", "<float>"), "read8": factor(cal_fetch, "k_cal_read", "<double>"),
+       "read16": factor(cal_fetch, "k_cal_read", "<float, 4"), "read32": factor(cal_fetch, "k_cal_read", "<double, 4"),
+       "write4": factor(cal_write, "k_cal_write", "<float>"), "write8": factor(cal_write, "k_cal_write", "<double>"),
+       "write16": factor(cal_write, "k_cal_write", "<float, 4")}
 # dominant load / store width of the solver kernels (bytes per lane and instruction)
 WIDTH = [("k_gcr_dots<double>", "read32", "write8"), ("k_gcr_axpy<double>", "read32", "write16"),
          ("k_gcr_dots<float>", "read16", "write8"), ("k_gcr_axpy<float>", "read16", "write16"),

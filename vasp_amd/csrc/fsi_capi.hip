@@ -1913,7 +1913,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   // Krylov space: sized from free memory (the recycled directions are what 288 GB of HBM are used for)
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
-  ctx->spmv_compact = getenv("FSI_SPMV_COMPACT") ? atoi(getenv("FSI_SPMV_COMPACT")) : 1;
+  ctx->spmv_compact = getenv("FSI_SPMV_COMPACT") ? atoi(getenv("FSI_SPMV_COMPACT")) : 0;
   if (ctx->spmv_compact) {
     HIPCHK(ctx->cA.alloc((size_t)24 * ctx->h_nadj.size()));
     HIPCHK(ctx->cP.alloc((size_t)3 * std::max<size_t>(1, ctx->h_padj.size())));
@@ -2166,6 +2166,7 @@ int fsi_assemble_jacobian(FsiCtx* ctx) {
   ctx->have_jacobian = true;
   ctx->have_monolithic_lu = false;
   const int rc = refresh_preconditioner(ctx);
+  if (getenv("FSI_DEBUG_FORCE_PREC_BAD")) ctx->prec_bad = true;     // test hook: this rank's self-test "fails"
   if (!ctx->part) return rc;
   // the self-test and the pivot checks above are rank-local: all ranks leave with the same verdict, so that either all
   // of them enter the collectives of the next solve or none does

@@ -106,7 +106,7 @@ struct FsiCtx {
   bool have_jacobian = false;
   fsi::DevBuf<double> cA, cP;                // compact node rows of A for the outer product (fsi_solver.hip: k_spmv_compact)
   bool compact_ok = false;                   // the dropped entries were verified to vanish on the current Jacobian
-  int spmv_compact = 1;                      // FSI_SPMV_COMPACT=0: always the full node-blocked rows
+  int spmv_compact = 0;                      // FSI_SPMV_COMPACT=1: outer product on the compact node rows (measured slower, see fsi_solver.hip)
 
   // vectors (solver ordering)
   fsi::DevBuf<double> U, U1, F, b, du, bs, tmp1, tmp2, tmp3, tmp4, tmp5, tmp6, tmp7;

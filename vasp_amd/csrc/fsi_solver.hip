@@ -256,6 +256,9 @@ __global__ __launch_bounds__(256) void k_spmv_node6(int64_t N2, const int64_t* _
 // the six value rows of k_spmv_node6): cA[24 nadj_ptr[r] + k L + t], k = 0..2 dd_c, 3..5 dv_c, 6..14 vd[c][j], 15..23
 // vv[c][j]; cP[3 padj_ptr[r] + c np + u] the pressure columns of the three v-rows.
 // k_compact_rows verifies what it drops: flags[0] |= 1 if a dropped entry exceeds 1e-13 (rows are equilibrated to max 1).
+// Measured on MI355X (1.12 M tets, 20-step bench): 3.46 ms per product against 3.20 ms for k_spmv_node6 on the full rows,
+// with 12.7 GB of HBM traffic (PMC, calibrated) against 19 GB - fewer bytes, but 24 short (27-element) value runs per node
+// and the gathers of x leave the half-waves waiting on latency.  Kept behind FSI_SPMV_COMPACT=1; the default stays node6.
 __global__ __launch_bounds__(256) void k_compact_rows(int64_t N2, const int64_t* __restrict__ rowptr,
                                                       const int64_t* __restrict__ nadj_ptr, const int64_t* __restrict__ padj_ptr,
                                                       const double* __restrict__ A, double* __restrict__ cA,
@@ -295,15 +298,16 @@ __global__ __launch_bounds__(256) void k_spmv_compact(int64_t N2, const int64_t*
                                                       const int32_t* __restrict__ padj, const double* __restrict__ cA,
                                                       const double* __restrict__ cP, const double* __restrict__ x,
                                                       double* __restrict__ y) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  // half a wave per node: a node has ~27 neighbours, a full wave would leave most lanes idle
+  const int lane = threadIdx.x & 31;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 5;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 5;
   const double* xp = x + 6 * N2;
-  for (int64_t r = wave; r < N2; r += nwaves) {
+  for (int64_t r = grp; r < N2; r += ngrp) {
     const int64_t a = nadj_ptr[r], L = nadj_ptr[r + 1] - a;
     const double* v = cA + 24 * a;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
-    for (int64_t t = lane; t < L; t += 64) {
+    for (int64_t t = lane; t < L; t += 32) {
       const double2* xb = reinterpret_cast<const double2*>(x + 6 * (int64_t)nadj[a + t]);
       const double2 x01 = xb[0], x23 = xb[1], x45 = xb[2];          // d_x d_y | d_z v_x | v_y v_z of the neighbour
       const double d0 = x01.x, d1 = x01.y, d2 = x23.x, u0 = x23.y, u1 = x45.x, u2 = x45.y;
@@ -316,11 +320,14 @@ __global__ __launch_bounds__(256) void k_spmv_compact(int64_t N2, const int64_t*
     }
     const int64_t pa = padj_ptr[r], np = padj_ptr[r + 1] - pa;
     const double* w = cP + 3 * pa;
-    for (int64_t u = lane; u < np; u += 64) {
+    for (int64_t u = lane; u < np; u += 32) {
       const double pv = xp[padj[pa + u]];
       a3 += w[u] * pv; a4 += w[np + u] * pv; a5 += w[2 * np + u] * pv;
     }
-    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3); a4 = wave_sum(a4); a5 = wave_sum(a5);
+    for (int off = 16; off > 0; off >>= 1) {
+      a0 += __shfl_xor(a0, off, 32); a1 += __shfl_xor(a1, off, 32); a2 += __shfl_xor(a2, off, 32);
+      a3 += __shfl_xor(a3, off, 32); a4 += __shfl_xor(a4, off, 32); a5 += __shfl_xor(a5, off, 32);
+    }
     if (lane == 0) { double* o = y + 6 * r; o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5; }
   }
 }
@@ -333,8 +340,8 @@ void launch_compact_rows(hipStream_t st, int64_t N2, const int64_t* rowptr, cons
 void launch_spmv_compact(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const double* A,
                          const int64_t* nadj_ptr, const int32_t* nadj, const int64_t* padj_ptr, const int32_t* padj,
                          const double* cA, const double* cP, const double* x, double* y) {
-  int64_t blocks = (N2 + 3) / 4;
-  if (blocks > 8192) blocks = 8192;
+  int64_t blocks = (N2 + 7) / 8;
+  if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(k_spmv_compact, dim3((unsigned)blocks), dim3(256), 0, st, N2, nadj_ptr, nadj, padj_ptr, padj, cA, cP, x, y);
   if (V > 0) {                                                  // pressure rows: the generic kernel on the tail of the full matrix
     int64_t pb = (V + 3) / 4;
