@@ -222,8 +222,8 @@ def main():
         # launches
         traffic = None
         pmc = ROOT / "profiles" / "r02_pmc_traffic.json"
-        groups = {"k_gcr_dots": [f"k_gcr_dots<{'double' if qb == 8 else 'float'}>", f"k_gcr_axpy<{'double' if qb == 8 else 'float'}>"],
-                  "k_gcr_flush": ["k_gcr_flush<0>", "k_gcr_flush<4>", "k_gcr_flush<8>", "k_gcr_flush<16>", "k_gcr_flush<32>"],
+        groups = {"k_gcr_dots": [f"k_gcr_dots<{'double' if qb == 8 else 'float'}", f"k_gcr_axpy<{'double' if qb == 8 else 'float'}"],
+                  "k_gcr_flush": ["k_gcr_flush<"],
                   "k_spmv_node6": ["k_spmv_node6", "k_spmv<0>"], "k_spmv_compact": ["k_spmv_compact", "k_spmv<0>"],
                   "k_spmv_tiled_f32<1>": ["k_spmv_tiled_f32<1>"], "k_spmv_tiled_f32<3>": ["k_spmv_tiled_f32<3>"],
                   "k_sweep_sb_b3<0>": ["k_sweep_sb_b3<0>"], "Schur": ["k_sweep_csr_f32", "k_spmv<2>"],
@@ -233,7 +233,9 @@ def main():
                 det = json.loads(pmc.read_text()).get("detail", {})
                 for key, names in groups.items():
                     if dom.startswith(key):
-                        rows = [det[nm] for nm in names if nm in det]
+                        # a name that ends inside its template argument list matches every instantiation
+                        rows = [v for k, v in det.items()
+                                if any(k == nm or ("<" in nm and not nm.endswith(">") and k.startswith(nm)) for nm in names)]
                         if key in ("k_spmv_node6", "k_spmv_compact"):            # one product = one launch of each
                             traffic = sum(r["fetch_bytes"] + r["write_bytes"] for r in rows)
                         elif rows:

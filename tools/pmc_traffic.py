@@ -28,8 +28,8 @@ cal = {"read4": factor(cal_fetch, "k_cal_read", "<float>"), "read8": factor(cal_
        "write4": factor(cal_write, "k_cal_write", "<float>"), "write8": factor(cal_write, "k_cal_write", "<double>"),
        "write16": factor(cal_write, "k_cal_write", "<float, 4")}
 # dominant load / store width of the solver kernels (bytes per lane and instruction)
-WIDTH = [("k_gcr_dots<double>", "read32", "write8"), ("k_gcr_axpy<double>", "read32", "write16"),
-         ("k_gcr_dots<float>", "read16", "write8"), ("k_gcr_axpy<float>", "read16", "write16"),
+WIDTH = [("k_gcr_dots<double", "read32", "write8"), ("k_gcr_axpy<double", "read32", "write16"),
+         ("k_gcr_dots<float", "read16", "write8"), ("k_gcr_axpy<float", "read16", "write16"),
          ("k_gcr_flush", "read16", "write8"), ("k_gcr_update", "read8", "write8"), ("k_spmv_node6", "read8", "write8"),
          ("k_spmv<", "read8", "write8"), ("k_spmv_tiled_f32", "read4", "write16"), ("k_sweep_sb_b3", "read16", "write16"),
          ("k_sweep_csr_f32", "read4", "write4"), ("k_residual", "read8", "write8"), ("k_jacobian", "read8", "write8")]

@@ -157,8 +157,9 @@ struct FsiCtx {
   fsi::DevBuf<int64_t> s_rowptr, s_diagpos;  // explicit Schur complement on its full (two-ring) vertex pattern
   fsi::DevBuf<int32_t> s_cols;
   fsi::DevBuf<double> s_vals;
-  fsi::DevBuf<float> s_vals32, s_dinv32, s_work32;   // FP32 copy + fused Chebyshev sweeps (round 2, 20-step bench: 9.3 vs 10.1 ms per
-  int schur_fp32 = 1;                                 // application, same outer iterations; FSI_SCHUR_FP32=0: FP64 product + update)
+  fsi::DevBuf<float> s_vals32, s_dinv32, s_work32;   // FSI_SCHUR_FP32=1: FP32 copy + fused Chebyshev sweeps.  Round 2: 9.3 vs 10.1 ms per
+  int schur_fp32 = 0;                                 // application on the 1.12 M-tet bench (same outer iterations), but on the 50 k-tet
+                                                      // generated mesh the outer GCR then makes no progress at all: stays off
   fsi::DevBuf<double> dd_db, vv_db;          // component-diagonal node-block copies of A_dd and Avv~ ([pairs][3])
   fsi::DevBuf<double> adv_db;
   bool dd_is_db = false, adv_is_db = false;
@@ -228,7 +229,9 @@ struct FsiCtx {
   // (kry_cn), and become explicit at the next flush (fsi_gcr.hip).
   int64_t kry_cap = 0, kry_m = 0;            // kry_m: directions made since the last Jacobian (statistics / ring age)
   int64_t kry_hw = 0;                        // slots in use (columns scanned by the kernels), <= kry_cap
-  int kry_fp32 = 0;                          // storage of Q: FP64; FSI_KRYLOV_FP32=1 stores it in FP32 (see solve_gcr)
+  int kry_fp32 = 0;                          // storage of Q during the current Jacobian lifetime: 0 FP64, 1 FP32
+  int kry_fp32_policy = 2;                   // (3: was 2, fell back to FP64 after a failed cycle)  FSI_KRYLOV_FP32: 0 never, 1 always, 2 (default) decided by the first solve after a
+                                             // Jacobian refresh: FP32 iff that solve's tolerance is >= 1e-7 (see solve_gcr)
   int64_t ldq = 0, ldz = 0;                  // column strides (elements)
   fsi::DevBuf<unsigned char> KQ;             // [kry_cap][ldq] float or double
   fsi::DevBuf<double> KZ;                    // [kry_cap][ldz]
@@ -248,6 +251,7 @@ struct FsiCtx {
   double gs_rtol = 0.0;                      // tightest linear tolerance asked for since the last Jacobian (re-orthogonalisation criterion)
   int64_t ortho_q_cols = 0, ortho_z_cols = 0, ortho_q_launches = 0, ortho_z_launches = 0;   // columns streamed (exact bytes of the orthogonalisation)
   bool gcr_arnoldi = false;                  // FSI_GCR_ARNOLDI=1: new directions from the latest q instead of the residual (measured: worse)
+  double tol_hint = 0.0, bnorm_max = 0.0;     // fsi_newton_solve -> solve_gcr: lowest linear tolerance to expect; largest |b| seen
   double gcr_reorth = 0.0;                   // FSI_GCR_REORTH: second Gram-Schmidt pass when |w'| < reorth |w| (0: automatic)
   double newton_forcing = 1e-2;              // inexact Newton: linear tolerance = forcing * atol / |b| (FSI_NEWTON_FORCING; 1e-2: same Newton counts as 1e-3 on the bench, 18 % fewer Krylov iterations)
 

@@ -48,15 +48,16 @@ __device__ inline void load4(const QT* p, double& a, double& b, double& c, doubl
 }
 
 // part[k * gridDim.x + bx] = partial of Q_k . w (k < m);  k = m: w . w;  k = m + 1: w . r (0 when r == nullptr).
-// blockIdx.y selects four directions (or, in the last row, the two vector products).
-template <class QT>
+// blockIdx.y selects NC directions (or, in the last row, the two vector products): one read of w feeds NC products, so
+// the FP32 form takes eight columns per block (w is FP64: with four, re-reading it would add half of Q's bytes again).
+template <class QT, int NC>
 __global__ __launch_bounds__(256) void k_gcr_dots(const QT* __restrict__ Q, int64_t ldq, int64_t n, int m,
                                                   const double* __restrict__ w, const double* __restrict__ r,
                                                   double* __restrict__ part) {
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const int ngroups = (m + 3) >> 2;
+  const int ngroups = (m + NC - 1) / NC;
   if ((int)blockIdx.y == ngroups) {
     double sww = 0.0, swr = 0.0;
     for (int64_t i = t0; i < n; i += stride) {
@@ -72,33 +73,32 @@ __global__ __launch_bounds__(256) void k_gcr_dots(const QT* __restrict__ Q, int6
     }
     return;
   }
-  const int k0 = 4 * blockIdx.y;
-  const QT* q0 = Q + (int64_t)k0 * ldq;
-  const QT* q1 = Q + (int64_t)(k0 + 1 < m ? k0 + 1 : k0) * ldq;
-  const QT* q2 = Q + (int64_t)(k0 + 2 < m ? k0 + 2 : k0) * ldq;
-  const QT* q3 = Q + (int64_t)(k0 + 3 < m ? k0 + 3 : k0) * ldq;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const int k0 = NC * blockIdx.y;
+  const QT* q[NC];
+  double s[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { q[c] = Q + (int64_t)(k0 + c < m ? k0 + c : k0) * ldq; s[c] = 0.0; }
   for (int64_t t = t0; t < n4; t += stride) {
     const int64_t i = t << 2;
     const double2 wa = *reinterpret_cast<const double2*>(w + i);
     const double2 wb = *reinterpret_cast<const double2*>(w + i + 2);
-    double a, b, c, d;
-    load4<QT>(q0 + i, a, b, c, d); s0 += (a * wa.x + b * wa.y) + (c * wb.x + d * wb.y);
-    load4<QT>(q1 + i, a, b, c, d); s1 += (a * wa.x + b * wa.y) + (c * wb.x + d * wb.y);
-    load4<QT>(q2 + i, a, b, c, d); s2 += (a * wa.x + b * wa.y) + (c * wb.x + d * wb.y);
-    load4<QT>(q3 + i, a, b, c, d); s3 += (a * wa.x + b * wa.y) + (c * wb.x + d * wb.y);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      double a, b, cc, d;
+      load4<QT>(q[c] + i, a, b, cc, d);
+      s[c] += (a * wa.x + b * wa.y) + (cc * wb.x + d * wb.y);
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {       // the last n mod 4 entries
     const int64_t i = (n4 << 2) + threadIdx.x;
     const double wv = w[i];
-    s0 += (double)q0[i] * wv; s1 += (double)q1[i] * wv; s2 += (double)q2[i] * wv; s3 += (double)q3[i] * wv;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) s[c] += (double)q[c][i] * wv;
   }
-  s0 = block_sum256(s0); s1 = block_sum256(s1); s2 = block_sum256(s2); s3 = block_sum256(s3);
-  if (threadIdx.x == 0) {
-    part[(int64_t)k0 * gridDim.x + blockIdx.x] = s0;
-    if (k0 + 1 < m) part[(int64_t)(k0 + 1) * gridDim.x + blockIdx.x] = s1;
-    if (k0 + 2 < m) part[(int64_t)(k0 + 2) * gridDim.x + blockIdx.x] = s2;
-    if (k0 + 3 < m) part[(int64_t)(k0 + 3) * gridDim.x + blockIdx.x] = s3;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const double v = block_sum256(s[c]);
+    if (threadIdx.x == 0 && k0 + c < m) part[(int64_t)(k0 + c) * gridDim.x + blockIdx.x] = v;
   }
 }
 
@@ -234,8 +234,9 @@ void dots_t(hipStream_t st, const void* Q, int64_t ldq, int64_t n, int m, const 
   int np = (int)((n + 16383) / 16384);
   if (np < 1) np = 1;
   if (np > 64) np = 64;
-  const int ngroups = (m + 3) / 4;
-  hipLaunchKernelGGL(k_gcr_dots<QT>, dim3(np, ngroups + 1), dim3(256), 0, st, static_cast<const QT*>(Q), ldq, n, m, w, r, scratch);
+  constexpr int NC = sizeof(QT) == 4 ? 8 : 4;
+  const int ngroups = (m + NC - 1) / NC;
+  hipLaunchKernelGGL((k_gcr_dots<QT, NC>), dim3(np, ngroups + 1), dim3(256), 0, st, static_cast<const QT*>(Q), ldq, n, m, w, r, scratch);
   hipLaunchKernelGGL(k_gcr_sum, dim3(m + 2), dim3(256), 0, st, scratch, np, out);
 }
 template <class QT>
