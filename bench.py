@@ -176,6 +176,7 @@ def main():
         z_launches = max(1, tm["ortho_z_launches"])
         z_bytes = (tm["ortho_z_cols"] * tm["ldz"] * 8.0) / z_launches + ndof_rank * 24.0
         generic = bool(os.environ.get("FSI_SPMV_GENERIC"))
+        op32 = int(tm.get("spmv_fp32_calls", 0))
         kernels = {
             f"k_gcr_dots + k_gcr_axpy (Gram-Schmidt against the kept directions: Q in FP{8 * qb} streamed once per launch, "
             f"mean {tm['ortho_q_cols'] / q_launches:.0f} columns)":
@@ -199,13 +200,15 @@ def main():
                  tm["schur_nnz"] * (tm["schur_elem_bytes"] + 4.0) + tm["schur_rows"] * 8.0 * 5),
             ("k_spmv_compact (monolithic Jacobian, node rows: 24 of the 36 entries per node pair that the forms can fill, f64 + one "
              "i32 per pair; + k_spmv<0> on the pressure rows)" if tm["spmv_compact"] else
-             "k_spmv_node6 (monolithic Jacobian, f64 values, one i32 column per six entries; + k_spmv<0> on the pressure rows)"
+             f"k_spmv_node6 (monolithic Jacobian, one i32 column per six entries, {op32} of {int(tm['spmv_calls'])} products on the FP32 "
+             "copy of the values, the rest FP64; + k_spmv<0> on the pressure rows)"
              if not generic else "k_spmv<0> (monolithic Jacobian, CSR f64 + i32)"):
                 (tm["spmv_ms"], tm["spmv_calls"],
                  (tm["node_pairs"] * (24 * 8.0 + 4.0) + tm["node_vertex_pairs"] * (3 * 8.0 + 4.0)
                   + (nnz - 36.0 * tm["node_pairs"] - 6.0 * tm["node_vertex_pairs"]) * 12.0       # pressure rows, full CSR
                   + ndof_rank * 16.0 + (ndof_rank + 1) * 8.0) if tm["spmv_compact"] else
-                 nnz * (8.0 + (4.0 / 6.0 if not generic else 4.0)) + ndof_rank * 16.0 + (ndof_rank + 1) * 8.0),
+                 nnz * (8.0 - 4.0 * op32 / max(tm["spmv_calls"], 1) + (4.0 / 6.0 if not generic else 4.0))
+                 + ndof_rank * 16.0 + (ndof_rank + 1) * 8.0),
             "k_residual (element residual + scatter-add)": (tm["residual_ms"], tm["residual_calls"], C_rank * 1676.0),
             "k_jacobian<nonlinear> (element Jacobian + scatter-add)": (tm["jacobian_ms"], tm["jacobian_calls"], C_rank * 33420.0),
         }
@@ -224,9 +227,9 @@ def main():
         pmc = ROOT / "profiles" / "r02_pmc_traffic.json"
         groups = {"k_gcr_dots": [f"k_gcr_dots<{'double' if qb == 8 else 'float'}", f"k_gcr_axpy<{'double' if qb == 8 else 'float'}"],
                   "k_gcr_flush": ["k_gcr_flush<"],
-                  "k_spmv_node6": ["k_spmv_node6", "k_spmv<0>"], "k_spmv_compact": ["k_spmv_compact", "k_spmv<0>"],
+                  "k_spmv_node6": ["k_spmv_node6<", "k_spmv<0,"], "k_spmv_compact": ["k_spmv_compact", "k_spmv<0,"],
                   "k_spmv_tiled_f32<1>": ["k_spmv_tiled_f32<1>"], "k_spmv_tiled_f32<3>": ["k_spmv_tiled_f32<3>"],
-                  "k_sweep_sb_b3<0>": ["k_sweep_sb_b3<0>"], "Schur": ["k_sweep_csr_f32", "k_spmv<2>"],
+                  "k_sweep_sb_b3<0>": ["k_sweep_sb_b3<0>"], "Schur": ["k_sweep_csr_f32", "k_spmv<2,"],
                   "k_residual": ["k_residual"], "k_jacobian": ["k_jacobian<2>"]}
         if pmc.exists():
             with contextlib.suppress(Exception):
@@ -236,8 +239,12 @@ def main():
                         # a name that ends inside its template argument list matches every instantiation
                         rows = [v for k, v in det.items()
                                 if any(k == nm or ("<" in nm and not nm.endswith(">") and k.startswith(nm)) for nm in names)]
-                        if key in ("k_spmv_node6", "k_spmv_compact"):            # one product = one launch of each
-                            traffic = sum(r["fetch_bytes"] + r["write_bytes"] for r in rows)
+                        if key in ("k_spmv_node6", "k_spmv_compact"):            # one product = one launch of each part
+                            traffic = 0.0
+                            for nm in names:
+                                part = [v for k, v in det.items() if k.startswith(nm) or k == nm]
+                                nl = sum(r["launches"] for r in part)
+                                traffic += sum((r["fetch_bytes"] + r["write_bytes"]) * r["launches"] for r in part) / max(nl, 1)
                         elif rows:
                             nl = sum(r["launches"] for r in rows)
                             traffic = sum((r["fetch_bytes"] + r["write_bytes"]) * r["launches"] for r in rows) / max(nl, 1)

@@ -229,6 +229,7 @@ typedef struct FsiTimers {
   int64_t schur_elem_bytes;                          /* 8: FP64 product, 4: FP32 fused sweep                          */
   int64_t spmv_compact;                              /* 1: the outer product runs on the compact node rows            */
   int64_t node_pairs;    int64_t node_vertex_pairs;  /* P2 node pairs / node-vertex pairs of the matrix graph         */
+  int64_t spmv_fp32_calls;                           /* outer products that ran on the FP32 copy of the matrix        */
 } FsiTimers;
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
 /* Measurement aid: streams `bytes` of the (idle) Krylov store once per kernel with 4-, 8-, 16- and 32-byte loads and

@@ -1076,6 +1076,38 @@ __global__ __launch_bounds__(256) void k_sweep_csr_f32(int64_t n, const int64_t*
     }
   }
 }
+// The same sweep with only the matrix VALUES in FP32 and every vector in FP64.  A rounded matrix is still one fixed linear
+// operator, so the preconditioner stays a linear map (what the Krylov method assumes); FP32 vectors instead add 6e-8 |dp| of
+// noise per sweep, which on a coarse mesh with a pressure-dominated right-hand side exceeded the velocity residual the outer
+// iteration was trying to reduce (tests/test_gpu_parity.py::test_properties_on_generated_mesh made no progress at all).
+// The vectors are 5 V doubles against ~65 V matrix entries: the bytes per sweep are those of the all-FP32 form.
+__global__ __launch_bounds__(256) void k_sweep_csr_mixed(int64_t n, const int64_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ cols, const float* __restrict__ vals,
+                                                         const int64_t* __restrict__ diagpos, const double* __restrict__ dvals,
+                                                         double c1, double c2, const double* __restrict__ din,
+                                                         double* __restrict__ dout, double* __restrict__ x, double* __restrict__ r) {
+  const int sub = threadIdx.x & 15;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t i = grp; i < n; i += ngrp) {
+    double s = 0.0;
+    for (int64_t e = rowptr[i] + sub; e < rowptr[i + 1]; e += 16) s += (double)vals[e] * din[cols[e]];
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+    if (sub == 0) {
+      const double di = din[i], ri = r[i] - s;
+      x[i] += di;
+      r[i] = ri;
+      dout[i] = c1 * di + c2 * ri / dvals[diagpos[i]];
+    }
+  }
+}
+void launch_sweep_csr_mixed(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const float* vals,
+                            const int64_t* diagpos, const double* dvals, double c1, double c2, const double* din, double* dout,
+                            double* x, double* r) {
+  int64_t blocks = (n + 15) / 16;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_sweep_csr_mixed, dim3((unsigned)blocks), dim3(256), 0, st, n, rowptr, cols, vals, diagpos, dvals, c1, c2, din, dout, x, r);
+}
 __global__ void k_csr_dinv_f32(int64_t n, const int64_t* __restrict__ diagpos, const double* __restrict__ A, float* __restrict__ dinv) {
   GS(i, n) dinv[i] = (float)(1.0 / A[diagpos[i]]);
 }

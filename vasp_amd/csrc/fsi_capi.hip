@@ -406,21 +406,34 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   launch_pres_rows(st, V, ctx->rowptr_pp.p, ctx->cols_pp.p, ctx->App.p, nullptr, 0.0, ctx->rowptr_pv.p, ctx->cols_pv.p,
                    ctx->Apv.p, vs, -1.0, rp, 1.0, tp);
   if (ctx->cheb_its_p > 0 && ctx->schur_fp32 && ctx->s_vals32.p) {
-    float *fx = ctx->s_work32.p, *fr = fx + V, *fa = fx + 2 * V, *fb = fx + 3 * V;
+    // matrix values in FP32, vectors in FP64 (k_sweep_csr_mixed); schur_fp32 == 2: the all-FP32 sweep (measurement only)
     const double lmax = ctx->lmax_p, lmin = lmax / ctx->cheb_kappa_p, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
     double rho = 1.0 / sig;
-    launch_cheb_init_plain_f32(st, V, tp, ctx->s_dinv32.p, (float)(1.0 / th), fx, fr, fa, fb);
-    for (int k = 0; k < ctx->cheb_its_p; ++k) {
-      const double rn = 1.0 / (2.0 * sig - rho);
-      const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->sch_ev0[0];
-      if (timed) (void)hipEventRecord(ctx->sch_ev0[k], st);
-      launch_sweep_csr_f32(st, V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->s_vals32.p, ctx->s_dinv32.p, (float)(rn * rho),
-                           (float)(2.0 * rn / de), fa, fb, fx, fr);
-      if (timed) { (void)hipEventRecord(ctx->sch_ev1[k], st); ctx->sch_samples_pending = k + 1; }
-      std::swap(fa, fb);
-      rho = rn;
+    if (ctx->schur_fp32 == 2) {
+      float *fx = ctx->s_work32.p, *fr = fx + V, *fa = fx + 2 * V, *fb = fx + 3 * V;
+      launch_cheb_init_plain_f32(st, V, tp, ctx->s_dinv32.p, (float)(1.0 / th), fx, fr, fa, fb);
+      for (int k = 0; k < ctx->cheb_its_p; ++k) {
+        const double rn = 1.0 / (2.0 * sig - rho);
+        launch_sweep_csr_f32(st, V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->s_vals32.p, ctx->s_dinv32.p, (float)(rn * rho),
+                             (float)(2.0 * rn / de), fa, fb, fx, fr);
+        std::swap(fa, fb);
+        rho = rn;
+      }
+      launch_f32_to_f64(st, V, fx, dp);
+    } else {
+      double *pr = IW, *pa = IW + V, *pb = IW + 2 * V;
+      launch_cheb_init(st, V, nullptr, tp, ctx->s_diagpos.p, ctx->s_vals.p, 1.0 / th, dp, pr, pa);
+      for (int k = 0; k < ctx->cheb_its_p; ++k) {
+        const double rn = 1.0 / (2.0 * sig - rho);
+        const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->sch_ev0[0];
+        if (timed) (void)hipEventRecord(ctx->sch_ev0[k], st);
+        launch_sweep_csr_mixed(st, V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->s_vals32.p, ctx->s_diagpos.p, ctx->s_vals.p, rn * rho,
+                               2.0 * rn / de, pa, pb, dp, pr);
+        if (timed) { (void)hipEventRecord(ctx->sch_ev1[k], st); ctx->sch_samples_pending = k + 1; }
+        std::swap(pa, pb);
+        rho = rn;
+      }
     }
-    launch_f32_to_f64(st, V, fx, dp);
     ctx->inner_its[1] += ctx->cheb_its_p;
   } else if (ctx->cheb_its_p > 0) {
     int sample = 0;
@@ -532,6 +545,15 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
                           td, dd, IW, ctx->inner_rtol, ctx->inner_maxit, &ctx->inner_its[2]));
   }
   launch_merge(st, N2, V, dd, dv, dp, z);
+  if (ctx->debug_prec_apply > 0) {                 // FSI_DEBUG_PRECOND=2: non-finite entries of the parts, first applications only
+    ctx->debug_prec_apply -= 1;
+    auto bad = [&](const double* p, int64_t n) { std::vector<double> h(n); (void)hipMemcpy(h.data(), p, n * sizeof(double), hipMemcpyDeviceToHost);
+                                                  int64_t b = 0; double m = 0.0; for (double v : h) { if (!std::isfinite(v)) b++; else m = std::max(m, std::fabs(v)); }
+                                                  return std::make_pair(b, m); };
+    const auto bt = bad(tp, V), bp = bad(dp, V), bv = bad(dv, n3), bd = bad(dd, n3), bs = bad(vs, n3);
+    fprintf(stderr, "[precond] apply: rhs_p max %.3e (%lld bad)  dp max %.3e (%lld bad)  v* max %.3e (%lld bad)  dv max %.3e (%lld bad)  dd max %.3e (%lld bad)\n",
+            bt.second, (long long)bt.first, bp.second, (long long)bp.first, bs.second, (long long)bs.first, bv.second, (long long)bv.first, bd.second, (long long)bd.first);
+  }
   ctx->inner_calls += 1;
   if (ctx->sample_budget > 0) ctx->sample_budget -= 1;
   if (ctx->sc_samples_pending > 0) {      // sampled launch durations of the scalar-ratio displacement SpMV
@@ -575,8 +597,15 @@ int precondition(FsiCtx* ctx, const double* r, double* z) {
   launch_sptrsv_levels(ctx->stream, ctx->levels, ctx->rowptr.p, ctx->cols.p, ctx->diagpos.p, ctx->LU.p, r, ctx->tmp7.p, z);
   return FSI_OK;
 }
-int spmv(FsiCtx* ctx, const double* x, double* y) {
+// working = true: the product inside a Krylov iteration, which may run on the FP32 copy of the matrix while the basis of this
+// Jacobian's lifetime is kept in FP32 (see solve_gcr); every other product (true residuals, the other solvers) is FP64
+int spmv(FsiCtx* ctx, const double* x, double* y, bool working = false) {
   Phase ph(ctx, &ctx->t_spmv);
+  if (working && ctx->op32_ok && ctx->kry_fp32) {
+    ctx->op32_products += 1;
+    launch_spmv_node6_f32(ctx->stream, ctx->N2, ctx->V, ctx->rowptr.p, ctx->cols.p, ctx->A32.p, x, y);
+    return FSI_OK;
+  }
   // FSI_SPMV_MONO=1: column-array-free variant (8.7 instead of 12 bytes per entry); measured SLOWER on MI355X (6.6 vs
   // 5.5 ms at 1.7 G entries: the index chain nadj -> x and the t / 6 outweigh the bytes), so the CSR kernel stays
   static const bool generic = getenv("FSI_SPMV_MONO") == nullptr;
@@ -733,7 +762,7 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
       FSICHK(precondition(ctx, src, z));
     }
     FSICHK(halo_update(ctx, z));      // partitioned: the preconditioner is rank-local (additive Schwarz on the ghost layer)
-    FSICHK(spmv(ctx, z, w));
+    FSICHK(spmv(ctx, z, w, true));
     zero_ghost(ctx, w);               // ghost rows are identity rows; residual-type vectors carry zeros there
     // a free slot for the new direction; when the store is full everything is made explicit first, then the oldest
     // directions of its rotating part are retired in a batch
@@ -899,14 +928,15 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
   };
   for (int cyc = 0; cyc < 8 && *iters < max_it; ++cyc) {
     // FP32 storage of Q: the residual recurrence of one cycle is good to about 1e-6 of the residual the cycle started from;
-    // a tighter request is met by restarting the cycle from the true residual b - A x (iterative refinement), and every
-    // answer asked for below 1e-4 is judged on the true residual
+    // a tighter request is met by restarting the cycle from the true residual b - A x (iterative refinement).  With the FP32
+    // copy of the matrix in the iterations every answer is judged on the residual of the FP64 matrix before it is returned
+    // (one FP64 product per cycle); without it, every answer asked for below 1e-4
     const bool f32 = ctx->kry_fp32 != 0;
     const double target = f32 ? std::max(rtol * bnorm, 1e-5 * rstart) : rtol * bnorm;
     FSICHK(gcr_cycle(ctx, r, x, target, ctx->gs_rtol, max_it, iters, &rnorm));
     if (!f32) break;
     const bool final_cycle = target <= rtol * bnorm * (1.0 + 1e-12);
-    if (final_cycle && rtol >= 1e-4) break;
+    if (final_cycle && rtol >= 1e-4 && !ctx->op32_ok) break;
     FSICHK(true_residual());
     if (rnorm <= rtol * bnorm) break;
     if (!(rnorm < 0.5 * rstart)) {
@@ -1105,6 +1135,16 @@ int refresh_preconditioner(FsiCtx* ctx) {
       }
       launch_to_f32(st, (int64_t)ctx->s_vals.n, ctx->s_vals.p, ctx->s_vals32.p);
       launch_csr_dinv_f32(st, ctx->V, ctx->s_diagpos.p, ctx->s_vals.p, ctx->s_dinv32.p);
+      if (getenv("FSI_DEBUG_PRECOND")) {
+        std::vector<float> h(ctx->V), hv(ctx->s_vals.n);
+        HIPCHK(hipMemcpy(h.data(), ctx->s_dinv32.p, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hv.data(), ctx->s_vals32.p, hv.size() * sizeof(float), hipMemcpyDeviceToHost));
+        double lo = 1e300, hi = 0.0, vhi = 0.0; int64_t bad = 0, vbad = 0, neg = 0;
+        for (float f : h) { if (!std::isfinite(f)) { bad++; continue; } lo = std::min(lo, (double)std::fabs(f)); hi = std::max(hi, (double)std::fabs(f)); neg += f < 0; }
+        for (float f : hv) { if (!std::isfinite(f)) vbad++; else vhi = std::max(vhi, (double)std::fabs(f)); }
+        fprintf(stderr, "[precond] schur fp32: 1/diag in [%.3e, %.3e], %lld negative, %lld non-finite; values max %.3e, %lld non-finite\n",
+                lo, hi, (long long)neg, (long long)bad, vhi, (long long)vbad);
+      }
     }
     for (SubMat* M : {&ctx->Mdd, &ctx->Ms}) {
       if ((M == &ctx->Mdd && ctx->cheb_its_d > 0) || (M == &ctx->Ms && ctx->cheb_its_p > 0)) continue;   // Jacobi-Chebyshev: no factors
@@ -1932,7 +1972,13 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   }
   ctx->kry_fp32_policy = getenv("FSI_KRYLOV_FP32") ? atoi(getenv("FSI_KRYLOV_FP32")) : 2;
   ctx->kry_fp32 = ctx->kry_fp32_policy == 1;
+  ctx->op32_policy = getenv("FSI_OPERATOR_FP32") ? atoi(getenv("FSI_OPERATOR_FP32")) : 1;
+  if (ctx->op32_policy && ctx->kry_fp32_policy != 0) {
+    HIPCHK(ctx->A32.alloc(ctx->nnz));
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  }
   ctx->debug_gcr = getenv("FSI_DEBUG_GCR") != nullptr;
+  ctx->debug_prec_apply = (getenv("FSI_DEBUG_PRECOND") && atoi(getenv("FSI_DEBUG_PRECOND")) >= 2) ? 12 : 0;
   if (getenv("FSI_NEWTON_FORCING")) ctx->newton_forcing = atof(getenv("FSI_NEWTON_FORCING"));
   if (getenv("FSI_GCR_REORTH")) ctx->gcr_reorth = atof(getenv("FSI_GCR_REORTH"));
   if (getenv("FSI_GCR_ARNOLDI")) ctx->gcr_arnoldi = atoi(getenv("FSI_GCR_ARNOLDI")) != 0;
@@ -2174,6 +2220,11 @@ int fsi_assemble_jacobian(FsiCtx* ctx) {
       ctx->compact_ok = fl[0] == 0;
       HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), ctx->stream));
     }
+  }
+  ctx->op32_ok = false;
+  if (ctx->op32_policy && ctx->kry_fp32_policy != 0 && ctx->precond == 0 && ctx->A32.p) {
+    launch_round_to_f32(ctx->stream, ctx->nnz, ctx->A.p, ctx->A32.p);       // rows are equilibrated: |entries| <= 1
+    ctx->op32_ok = true;
   }
   gcr_reset(ctx);          // the recycled directions belong to the previous matrix
   ctx->have_jacobian = true;
@@ -2496,13 +2547,15 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
                    (int64_t)(ctx->kry_fp32 ? 4 : 8), ctx->ldq, ctx->ldz, ctx->kry_hw, ctx->kry_cap,
                    (int64_t)ctx->s_cols.n, ctx->V, ctx->t_flush.ms, ctx->t_flush.calls, ctx->t_sch.ms, ctx->t_sch.calls,
                    (int64_t)((ctx->schur_fp32 && ctx->s_vals32.p) ? 4 : 8),
-                   (int64_t)(ctx->compact_ok && ctx->spmv_compact ? 1 : 0), (int64_t)ctx->h_nadj.size(), (int64_t)ctx->h_padj.size()};
+                   (int64_t)(ctx->compact_ok && ctx->spmv_compact ? 1 : 0), (int64_t)ctx->h_nadj.size(), (int64_t)ctx->h_padj.size(),
+                   ctx->op32_products};
   if (reset) {
     for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_flush, &ctx->t_sch, &ctx->t_kry, &ctx->t_ss, &ctx->t_db, &ctx->t_sc}) {
       t->ms = 0.0;
       t->calls = 0;
     }
     ctx->kry_iters = 0;
+    ctx->op32_products = 0;
     ctx->inner_its[0] = ctx->inner_its[1] = ctx->inner_its[2] = 0;
     ctx->inner_calls = 0;
     ctx->ortho_q_cols = ctx->ortho_q_launches = ctx->ortho_z_cols = ctx->ortho_z_launches = 0;

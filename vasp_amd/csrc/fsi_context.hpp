@@ -157,9 +157,10 @@ struct FsiCtx {
   fsi::DevBuf<int64_t> s_rowptr, s_diagpos;  // explicit Schur complement on its full (two-ring) vertex pattern
   fsi::DevBuf<int32_t> s_cols;
   fsi::DevBuf<double> s_vals;
-  fsi::DevBuf<float> s_vals32, s_dinv32, s_work32;   // FSI_SCHUR_FP32=1: FP32 copy + fused Chebyshev sweeps.  Round 2: 9.3 vs 10.1 ms per
-  int schur_fp32 = 0;                                 // application on the 1.12 M-tet bench (same outer iterations), but on the 50 k-tet
-                                                      // generated mesh the outer GCR then makes no progress at all: stays off
+  fsi::DevBuf<float> s_vals32, s_dinv32, s_work32;   // FSI_SCHUR_FP32: 1 (default) matrix values in FP32, vectors FP64, product fused
+  int schur_fp32 = 1;                                 // with the Chebyshev update (k_sweep_csr_mixed); 0: FP64 product + update; 2: vectors
+                                                      // in FP32 too (on the 50 k-tet generated mesh the outer GCR then makes no progress:
+                                                      // rounding noise of the pressure exceeds the velocity residual; measurement only)
   fsi::DevBuf<double> dd_db, vv_db;          // component-diagonal node-block copies of A_dd and Avv~ ([pairs][3])
   fsi::DevBuf<double> adv_db;
   bool dd_is_db = false, adv_is_db = false;
@@ -251,6 +252,9 @@ struct FsiCtx {
   double gs_rtol = 0.0;                      // tightest linear tolerance asked for since the last Jacobian (re-orthogonalisation criterion)
   int64_t ortho_q_cols = 0, ortho_z_cols = 0, ortho_q_launches = 0, ortho_z_launches = 0;   // columns streamed (exact bytes of the orthogonalisation)
   bool gcr_arnoldi = false;                  // FSI_GCR_ARNOLDI=1: new directions from the latest q instead of the residual (measured: worse)
+  fsi::DevBuf<float> A32;                         // FP32 copy of A for the products inside the Krylov iterations (FSI_OPERATOR_FP32, default on)
+  bool op32_ok = false; int op32_policy = 1; int64_t op32_products = 0;
+  int debug_prec_apply = 0;
   double tol_hint = 0.0, bnorm_max = 0.0;     // fsi_newton_solve -> solve_gcr: lowest linear tolerance to expect; largest |b| seen
   double gcr_reorth = 0.0;                   // FSI_GCR_REORTH: second Gram-Schmidt pass when |w'| < reorth |w| (0: automatic)
   double newton_forcing = 1e-2;              // inexact Newton: linear tolerance = forcing * atol / |b| (FSI_NEWTON_FORCING; 1e-2: same Newton counts as 1e-3 on the bench, 18 % fewer Krylov iterations)

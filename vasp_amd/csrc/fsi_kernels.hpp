@@ -63,6 +63,9 @@ void launch_robin_residual(hipStream_t st, int64_t n, const int32_t* row, const 
                            double th0, double th1, const double* U, const double* U1, double* F);
 void launch_add_at(hipStream_t st, double* vals, const int64_t* pos, const double* v, double a, int64_t n);
 enum SpmvTag : int { SPMV_MONOLITHIC = 0, SPMV_SOLID_BLOCK = 1, SPMV_FIELD_BLOCK = 2 };
+void launch_spmv_node6_f32(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const float* vals,
+                           const double* x, double* y);
+void launch_round_to_f32(hipStream_t st, int64_t n, const double* a, float* b);
 void launch_spmv(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const double* vals,
                  const double* x, double* y, int tag = SPMV_FIELD_BLOCK);
 // reductions: out[0] = x.y (deterministic two-stage); scratch must hold >= 4096 doubles
@@ -174,6 +177,9 @@ void launch_sweep_csr_f32(hipStream_t st, int64_t n, const int64_t* rowptr, cons
 void launch_csr_dinv_f32(hipStream_t st, int64_t n, const int64_t* diagpos, const double* A, float* dinv);
 void launch_cheb_init_plain_f32(hipStream_t st, int64_t n, const double* rhs, const float* dinv, float inv_theta, float* x,
                                 float* r, float* d, float* d2);
+void launch_sweep_csr_mixed(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const float* vals,
+                            const int64_t* diagpos, const double* dvals, double c1, double c2, const double* din, double* dout,
+                            double* x, double* r);
 void launch_f32_to_f64(hipStream_t st, int64_t n, const float* a, double* b);
 void launch_sbmg_flags(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals, uint8_t* flag);
 void launch_sbmg_rap(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,

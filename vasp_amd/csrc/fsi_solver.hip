@@ -183,9 +183,9 @@ void launch_matrix_finish(hipStream_t st, int64_t n, const int64_t* rowptr, cons
 // SpMV, one wave per row (rows have ~100-400 entries)
 // ---------------------------------------------------------------------------------------------------------
 // TAG only names the instantiation (profiles list the monolithic, solid-block and other-block products separately)
-template <int TAG>
+template <int TAG, class VT = double>
 __global__ __launch_bounds__(256) void k_spmv(int64_t n, const int64_t* __restrict__ rowptr,
-                                              const int32_t* __restrict__ cols, const double* __restrict__ vals,
+                                              const int32_t* __restrict__ cols, const VT* __restrict__ vals,
                                               const double* __restrict__ x, double* __restrict__ y) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_spmv(int64_t n, const int64_t* __restri
   for (int64_t row = wave; row < n; row += nwaves) {
     const int64_t s = rowptr[row], e = rowptr[row + 1];
     double sum = 0.0;
-    for (int64_t t = s + lane; t < e; t += 64) sum += vals[t] * x[cols[t]];
+    for (int64_t t = s + lane; t < e; t += 64) sum += (double)vals[t] * x[cols[t]];
     sum = wave_sum(sum);
     if (lane == 0) y[row] = sum;
   }
@@ -228,21 +228,37 @@ __global__ __launch_bounds__(256) void k_spmv_mono(int64_t n, int64_t N2, const 
 // Monolithic SpMV, velocity / displacement rows: the six rows of a node share their column pattern (k_expand_cols), so
 // one wave takes a node, reads the column indices and gathers x ONCE and streams the six value rows against them -
 // 8 + 4/6 instead of 12 bytes per entry, a sixth of the gathers, and six independent value streams in flight per lane.
+// VT = float: the FP32 copy of the (row-equilibrated, |entries| <= 1) Jacobian that the Krylov iterations of a loose-tolerance
+// lifetime multiply with (4 + 4/6 bytes per entry); x, y and the accumulation stay FP64, and every answer is checked
+// against the FP64 matrix before it leaves solve_gcr (fsi_capi.hip).
+// XCD = true: workgroups are dealt round-robin to the 8 XCDs, each with its own L2; giving XCD k the k-th eighth of the
+// nodes (instead of every eighth workgroup of one sweep over all nodes) keeps the x entries a node's neighbours gather
+// inside ONE L2 instead of fetching them into all eight.
+template <class VT, bool XCD>
 __global__ __launch_bounds__(256) void k_spmv_node6(int64_t N2, const int64_t* __restrict__ rowptr,
-                                                    const int32_t* __restrict__ cols, const double* __restrict__ vals,
+                                                    const int32_t* __restrict__ cols, const VT* __restrict__ vals,
                                                     const double* __restrict__ x, double* __restrict__ y) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t r = wave; r < N2; r += nwaves) {
+  int64_t first, last, stride;
+  if (XCD) {                                                    // gridDim.x is a multiple of 8
+    const int64_t chunk = (N2 + 7) >> 3, k = blockIdx.x & 7;
+    first = k * chunk + (blockIdx.x >> 3) * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    last = (k + 1) * chunk < N2 ? (k + 1) * chunk : N2;
+    stride = (int64_t)(gridDim.x >> 3) * (blockDim.x >> 6);
+  } else {
+    first = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    last = N2;
+    stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  }
+  for (int64_t r = first; r < last; r += stride) {
     const int64_t s0 = rowptr[6 * r];
     const int64_t L = rowptr[6 * r + 1] - s0;                  // the six rows are stored back to back with equal lengths
-    const double* v = vals + s0;
+    const VT* v = vals + s0;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
     for (int64_t t = lane; t < L; t += 64) {
       const double xv = x[cols[s0 + t]];
-      a0 += v[t] * xv; a1 += v[L + t] * xv; a2 += v[2 * L + t] * xv;
-      a3 += v[3 * L + t] * xv; a4 += v[4 * L + t] * xv; a5 += v[5 * L + t] * xv;
+      a0 += (double)v[t] * xv; a1 += (double)v[L + t] * xv; a2 += (double)v[2 * L + t] * xv;
+      a3 += (double)v[3 * L + t] * xv; a4 += (double)v[4 * L + t] * xv; a5 += (double)v[5 * L + t] * xv;
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3); a4 = wave_sum(a4); a5 = wave_sum(a5);
     if (lane == 0) { double* o = y + 6 * r; o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5; }
@@ -349,16 +365,36 @@ void launch_spmv_compact(hipStream_t st, int64_t N2, int64_t V, const int64_t* r
     hipLaunchKernelGGL(k_spmv<SPMV_MONOLITHIC>, dim3((unsigned)pb), dim3(256), 0, st, V, rowptr + 6 * N2, cols, A, x, y + 6 * N2);
   }
 }
-void launch_spmv_node6(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const double* vals,
-                       const double* x, double* y) {
+template <class VT>
+static void spmv_node6_any(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const VT* vals,
+                           const double* x, double* y) {
+  static const bool xcd = !(getenv("FSI_SPMV_XCD") && atoi(getenv("FSI_SPMV_XCD")) == 0);
   int64_t blocks = (N2 + 3) / 4;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(k_spmv_node6, dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, cols, vals, x, y);
+  blocks = (blocks + 7) & ~(int64_t)7;
+  if (xcd) hipLaunchKernelGGL((k_spmv_node6<VT, true>), dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, cols, vals, x, y);
+  else hipLaunchKernelGGL((k_spmv_node6<VT, false>), dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, cols, vals, x, y);
   if (V > 0) {                                                  // pressure rows: the generic kernel on the tail of the matrix
     int64_t pb = (V + 3) / 4;
     if (pb > 8192) pb = 8192;
-    hipLaunchKernelGGL(k_spmv<SPMV_MONOLITHIC>, dim3((unsigned)pb), dim3(256), 0, st, V, rowptr + 6 * N2, cols, vals, x, y + 6 * N2);
+    hipLaunchKernelGGL((k_spmv<SPMV_MONOLITHIC, VT>), dim3((unsigned)pb), dim3(256), 0, st, V, rowptr + 6 * N2, cols, vals, x, y + 6 * N2);
   }
+}
+void launch_spmv_node6(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const double* vals,
+                       const double* x, double* y) {
+  spmv_node6_any<double>(st, N2, V, rowptr, cols, vals, x, y);
+}
+void launch_spmv_node6_f32(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const float* vals,
+                           const double* x, double* y) {
+  spmv_node6_any<float>(st, N2, V, rowptr, cols, vals, x, y);
+}
+__global__ __launch_bounds__(256) void k_round_to_f32(int64_t n, const double* __restrict__ a, float* __restrict__ b) {
+  GRID_STRIDE(i, n) b[i] = (float)a[i];
+}
+void launch_round_to_f32(hipStream_t st, int64_t n, const double* a, float* b) {
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k_round_to_f32, dim3((unsigned)blocks), dim3(256), 0, st, n, a, b);
 }
 void launch_spmv_mono(hipStream_t st, int64_t n, int64_t N2, const int64_t* rowptr, const int64_t* nadj_ptr,
                       const int32_t* nadj, const int64_t* padj_ptr, const int32_t* padj, const int32_t* vrank,
