@@ -168,6 +168,10 @@ def main():
                    (tm["db_pairs"] * 8.0 + tm["db_nodes"] * 43.0)
         dbf_bytes = (tm["db_pairs"] * 14.0 + tm["tile_entries"] * 20.0 + tm["db_nodes"] * 24.0) if tiled else \
                     (tm["db_pairs"] * 16.0 + tm["db_nodes"] * 40.0)
+        fused = tiled and os.environ.get("FSI_FUSED_SWEEPS") != "0"     # product + Chebyshev update in one launch (default)
+        if fused:                                                        # + d, r, x read, x, r, d' written, product not stored
+            sc_bytes += tm["db_nodes"] * 80.0
+            dbf_bytes += tm["db_nodes"] * 96.0                            # and the float4 Jacobi scaling
         qb = tm["q_elem_bytes"]
         # orthogonalisation: every launch of k_gcr_dots / k_gcr_axpy streams m columns of Q (ld * qb bytes each) plus
         # w (read, and written by the update) and r; the exact column count is kept by the library
@@ -183,10 +187,14 @@ def main():
                 (tm["ortho_ms"], int(tm["ortho_q_launches"]), q_bytes),
             f"k_gcr_flush (x and the new directions from the direction store, mean {tm['ortho_z_cols'] / z_launches:.0f} columns)":
                 (tm["flush_ms"], int(tm["ortho_z_launches"]), z_bytes),
-            ("k_spmv_tiled_f32<1>" if tiled else "k_spmv_sc_f32") + " (displacement block sweeps: one FP32 ratio per node pair"
-            + (", neighbour vector entries staged in LDS" if tiled else "") + "; avg from sampled HIP events)":
+            ("k_sweep_tiled_f32<1>" if fused else "k_spmv_tiled_f32<1>" if tiled else "k_spmv_sc_f32")
+            + " (displacement block sweeps: one FP32 ratio per node pair"
+            + (", neighbour vector entries staged in LDS" if tiled else "") + (", fused with the Chebyshev update" if fused else "")
+            + "; avg from sampled HIP events)":
                 (sc_avg * sc_launches, int(sc_launches), sc_bytes),
-            ("k_spmv_tiled_f32<3>" if tiled else "k_spmv_db_f32") + " (fluid velocity block sweeps, FP32 component-diagonal node blocks; avg from sampled HIP events)":
+            ("k_sweep_tiled_f32<3>" if fused else "k_spmv_tiled_f32<3>" if tiled else "k_spmv_db_f32")
+            + " (fluid velocity block sweeps, FP32 component-diagonal node blocks" + (", fused with the Chebyshev update" if fused else "")
+            + "; avg from sampled HIP events)":
                 (db_avg * db_launches, int(db_launches), dbf_bytes),
             (("k_sweep_sb_b3<0> (solid velocity block, fine level: FP32 3x3 block-CSR product fused with the Chebyshev update; avg from sampled HIP events)"
               if solid_fused else "k_spmv_sb (solid velocity block, FP32 3x3 block-CSR, Chebyshev sweeps; avg from sampled HIP events)")
@@ -229,7 +237,8 @@ def main():
                   "k_gcr_flush": ["k_gcr_flush<"],
                   "k_spmv_node6": ["k_spmv_node6<", "k_spmv<0,"], "k_spmv_compact": ["k_spmv_compact", "k_spmv<0,"],
                   "k_spmv_tiled_f32<1>": ["k_spmv_tiled_f32<1>"], "k_spmv_tiled_f32<3>": ["k_spmv_tiled_f32<3>"],
-                  "k_sweep_sb_b3<0>": ["k_sweep_sb_b3<0>"], "Schur": ["k_sweep_csr_f32", "k_spmv<2,"],
+                  "k_sweep_tiled_f32<1>": ["k_sweep_tiled_f32<1>"], "k_sweep_tiled_f32<3>": ["k_sweep_tiled_f32<3>"],
+                  "k_sweep_sb_b3<0>": ["k_sweep_sb_b3<0>"], "Schur": ["k_sweep_csr_mixed", "k_sweep_csr_f32", "k_spmv<2,"],
                   "k_residual": ["k_residual"], "k_jacobian": ["k_jacobian<2>"]}
         if pmc.exists():
             with contextlib.suppress(Exception):

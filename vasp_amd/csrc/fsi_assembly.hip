@@ -127,50 +127,61 @@ __device__ inline void interpolate(const double* __restrict__ sU, const double* 
 // ---------------------------------------------------------------------------------------------------------
 // residual: F += sum over cells of the element vector (un-negated, no boundary conditions)
 // ---------------------------------------------------------------------------------------------------------
+// Two cells per 64-lane workgroup: the quadrature phase (24 points, by far the longest part: two interpolations and the flux
+// per point) keeps lanes 0-23 on the first cell and lanes 32-55 on the second, so one instruction stream serves 48 lanes
+// instead of 24; the load and the contraction phases take the two cells one after the other with all 64 lanes.
 __global__ __launch_bounds__(64) void k_residual(ElemArrays ea, ElemParams ep, const double* __restrict__ U,
-                                                 const double* __restrict__ U1, double* __restrict__ F) {
-  const int64_t c = blockIdx.x;
+                                                 const double* __restrict__ U1, double* __restrict__ F, int64_t C) {
   const int lane = threadIdx.x;
-  __shared__ double sU[NLOC], sU1[NLOC], sJ[10];
-  __shared__ double sS[NQ][25];
-  const int32_t dof = ea.cell_dofs[c * NLOC + lane];
-  sU[lane] = U[dof];
-  sU1[lane] = U1[dof];
-  if (lane < 10) sJ[lane] = ea.geom[c * 10 + lane];
+  const int64_t c0 = 2 * (int64_t)blockIdx.x;
+  const int ncell = c0 + 1 < C ? 2 : 1;
+  __shared__ double sU[2][NLOC], sU1[2][NLOC], sJ[2][10];
+  __shared__ double sS[2][NQ][25];
+  int32_t dof[2] = {0, 0};
+  for (int t = 0; t < ncell; ++t) {
+    dof[t] = ea.cell_dofs[(c0 + t) * NLOC + lane];
+    sU[t][lane] = U[dof[t]];
+    sU1[t][lane] = U1[dof[t]];
+  }
+  if (lane < 10 * ncell) sJ[lane / 10][lane % 10] = ea.geom[c0 * 10 + lane];      // geom of consecutive cells is contiguous
   __syncthreads();
-  const int kind = ea.cell_kind[c], region = ea.cell_region[c];
-  if (lane < NQ) {
-    const int q = lane;
+  const int half = lane >> 5, q = lane & 31;
+  if (q < NQ && half < ncell) {
+    const int64_t c = c0 + half;
+    const int kind = ea.cell_kind[c], region = ea.cell_region[c];
+    const double* J = sJ[half];
     Kin<double> s, o;
-    interpolate(sU, sJ, q, s);
-    interpolate(sU1, sJ, q, o);
+    interpolate(sU[half], J, q, s);
+    interpolate(sU1[half], J, q, o);
     Slots<double> out;
     if (kind == 0) fluid_flux<double, PART_BOTH>(ep.fluid[region], ep.sc, s, o, out);
     else solid_flux<double, PART_BOTH>(ep.solid[region], ep.sc, s, o, out);
-    const double w = sJ[9] * c_qw[q];
-    double* S = sS[q];
+    const double w = J[9] * c_qw[q];
+    double* S = sS[half][q];
     for (int i = 0; i < 3; ++i) {
       S[i] = w * out.dval[i];
       S[12 + i] = w * out.vval[i];
       for (int k = 0; k < 3; ++k) {     // gradient slots pulled back to reference coordinates
-        S[3 + 3 * i + k] = w * (out.dgrd[i][0] * sJ[3 * k] + out.dgrd[i][1] * sJ[3 * k + 1] + out.dgrd[i][2] * sJ[3 * k + 2]);
-        S[15 + 3 * i + k] = w * (out.vgrd[i][0] * sJ[3 * k] + out.vgrd[i][1] * sJ[3 * k + 1] + out.vgrd[i][2] * sJ[3 * k + 2]);
+        S[3 + 3 * i + k] = w * (out.dgrd[i][0] * J[3 * k] + out.dgrd[i][1] * J[3 * k + 1] + out.dgrd[i][2] * J[3 * k + 2]);
+        S[15 + 3 * i + k] = w * (out.vgrd[i][0] * J[3 * k] + out.vgrd[i][1] * J[3 * k + 1] + out.vgrd[i][2] * J[3 * k + 2]);
       }
     }
     S[24] = w * out.pval;
   }
   __syncthreads();
-  double r = 0.0;
-  if (lane < 60) {
-    const int fld = lane / 30, comp = (lane % 30) / 10, a = lane % 10;
-    const int vo = fld * 12 + comp, go = fld * 12 + 3 + 3 * comp;
-    for (int q = 0; q < NQ; ++q)
-      r += sS[q][vo] * c_N[q][a] + sS[q][go] * c_dN[q][a][0] + sS[q][go + 1] * c_dN[q][a][1] + sS[q][go + 2] * c_dN[q][a][2];
-  } else {
-    const int a = lane - 60;
-    for (int q = 0; q < NQ; ++q) r += sS[q][24] * c_L[q][a];
+  for (int t = 0; t < ncell; ++t) {
+    double r = 0.0;
+    if (lane < 60) {
+      const int fld = lane / 30, comp = (lane % 30) / 10, a = lane % 10;
+      const int vo = fld * 12 + comp, go = fld * 12 + 3 + 3 * comp;
+      for (int k = 0; k < NQ; ++k)
+        r += sS[t][k][vo] * c_N[k][a] + sS[t][k][go] * c_dN[k][a][0] + sS[t][k][go + 1] * c_dN[k][a][1] + sS[t][k][go + 2] * c_dN[k][a][2];
+    } else {
+      const int a = lane - 60;
+      for (int k = 0; k < NQ; ++k) r += sS[t][k][24] * c_L[k][a];
+    }
+    unsafeAtomicAdd(&F[dof[t]], r);
   }
-  unsafeAtomicAdd(&F[dof], r);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -402,7 +413,7 @@ void launch_geometry(hipStream_t st, int64_t C, const double* coords, const int3
 }
 void launch_residual(hipStream_t st, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
                      const double* U1, double* F) {
-  hipLaunchKernelGGL(k_residual, dim3((unsigned)C), dim3(64), 0, st, ea, ep, U, U1, F);
+  hipLaunchKernelGGL(k_residual, dim3((unsigned)((C + 1) / 2)), dim3(64), 0, st, ea, ep, U, U1, F, C);
 }
 void launch_jacobian(hipStream_t st, int part, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
                      const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals) {

@@ -597,6 +597,163 @@ void launch_spmv_tiled_f32(hipStream_t st, int nv, int64_t N2, int max_nu, const
   else
     hipLaunchKernelGGL(k_spmv_tiled_f32<3>, dim3(tiles), dim3(256), lds, st, N2, nadj_ptr, vals, ploc, tile_uptr, ulist, rowflag, x, y);
 }
+// One Chebyshev sweep on the tiled operator in a single launch (the product never goes through memory):
+//   t = A d_in;  x += d_in;  r -= t;  d_out = c1 d_in + c2 dinv r      (d is ping-ponged: other tiles still gather d_in)
+// Workgroups of up to 1024 threads: the tile's LDS (up to 64 KB) allows two workgroups per CU whatever their size, and the
+// row loop is bound by load latency, so 32 waves per CU instead of 8 is what the kernel is after.
+template <int NV>
+__global__ __launch_bounds__(1024) void k_sweep_tiled_f32(int64_t N2, const int64_t* __restrict__ nadj_ptr,
+                                                          const float* __restrict__ vals, const uint16_t* __restrict__ ploc,
+                                                          const int64_t* __restrict__ tile_uptr, const int32_t* __restrict__ ulist,
+                                                          const uint8_t* __restrict__ rowflag, const float* __restrict__ dinv,
+                                                          float c1, float c2, const float* __restrict__ din, float* __restrict__ dout,
+                                                          float* __restrict__ x, float* __restrict__ r) {
+  extern __shared__ __attribute__((aligned(16))) float4 sx[];
+  __shared__ __attribute__((aligned(16))) int64_t sptr[TILE_NODES + 2];
+  __shared__ __attribute__((aligned(16))) float4 ssum[TILE_NODES];   // the tile's products; the update below reads them coalesced
+  const int64_t tile = blockIdx.x;
+  const int64_t u0 = tile_uptr[tile], nu = tile_uptr[tile + 1] - u0;
+  const float4* d4 = reinterpret_cast<const float4*>(din);
+  const int64_t r0 = tile * TILE_NODES;
+  const int nrows = (int)((r0 + TILE_NODES < N2 ? r0 + TILE_NODES : N2) - r0);
+  const int nth = blockDim.x, ngrp = nth >> 4;
+  for (int64_t i = threadIdx.x; i < nu; i += nth) sx[i] = d4[ulist[u0 + i]];
+  for (int i = threadIdx.x; i <= nrows; i += nth) sptr[i] = nadj_ptr[r0 + i];
+  __syncthreads();
+  const int sub = threadIdx.x & 15, g = threadIdx.x >> 4;
+  // The (value, local index) pairs of the group's NEXT node are in flight while the current node is multiplied and reduced.
+  // Four 16-pair strips are prefetched: a P2 edge node has ~22 neighbours, a vertex node ~65.  (Measured alternatives, all
+  // slower on MI355X: two strips + a loop of dependent loads for the long rows, 184 us; the rows of a tile sorted into long
+  // and short ones with five / two strips, 152 us; this form 142 us.)
+  constexpr int KS = 4;
+  float cv[KS][NV], nv_[KS][NV];
+  int cl[KS], nl[KS];
+  auto prefetch = [&](int i, float (&v)[KS][NV], int (&l)[KS]) {
+    const int64_t e0 = sptr[i], e1 = sptr[i + 1];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int64_t e = e0 + sub + 16 * k;
+      const bool in = e < e1;
+      l[k] = in ? (int)ploc[e] : 0;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) v[k][c] = in ? vals[NV * e + c] : 0.f;
+    }
+  };
+  int i = g;
+  if (i < nrows) prefetch(i, cv, cl);
+  while (i < nrows) {
+    const int ni = i + ngrp;
+    if (ni < nrows) prefetch(ni, nv_, nl);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    auto strip = [&](int k) {
+      const float4 xv = sx[cl[k]];
+      if (NV == 1) { s0 += cv[k][0] * xv.x; s1 += cv[k][0] * xv.y; s2 += cv[k][0] * xv.z; }
+      else { s0 += cv[k][0] * xv.x; s1 += cv[k][NV > 1 ? 1 : 0] * xv.y; s2 += cv[k][NV > 2 ? 2 : 0] * xv.z; }
+    };
+    strip(0);
+    strip(1);
+    const int len = (int)(sptr[i + 1] - sptr[i]);
+    if (__builtin_amdgcn_ballot_w64(len > 32) != 0) { strip(2); strip(3); }        // wave-uniform: some node of the wave is long
+    for (int64_t e = sptr[i] + sub + 16 * KS; e < sptr[i + 1]; e += 16) {           // rows with more than 64 pairs
+      const float4 xv = sx[ploc[e]];
+      if (NV == 1) { const float c = vals[e]; s0 += c * xv.x; s1 += c * xv.y; s2 += c * xv.z; }
+      else { const float* c = vals + NV * e; s0 += c[0] * xv.x; s1 += c[NV > 1 ? 1 : 0] * xv.y; s2 += c[NV > 2 ? 2 : 0] * xv.z; }
+    }
+    for (int off = 8; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
+    }
+    if (sub == 0) ssum[i] = make_float4(s0, s1, s2, 0.f);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      cl[k] = nl[k];
+#pragma unroll
+      for (int c = 0; c < NV; ++c) cv[k][c] = nv_[k][c];
+    }
+    i = ni;
+  }
+  // Chebyshev update of the tile's rows, one float per thread and round: the tile's entries of d, r, x are 4 KB of
+  // consecutive memory, read and written by full waves (done per row by the lane that holds the sum, these nine accesses
+  // with 4 of 64 lanes active cost more address-unit cycles than the product itself)
+  __syncthreads();
+  const float* sflat = reinterpret_cast<const float*>(ssum);
+  for (int idx = threadIdx.x; idx < 4 * nrows; idx += nth) {
+    const int64_t gi = 4 * r0 + idx;
+    const int comp = idx & 3;
+    const float di = din[gi];
+    float t = sflat[idx];
+    if (rowflag && comp < 3 && rowflag[3 * (r0 + (idx >> 2)) + comp]) t = di;      // identity (Dirichlet) rows of the scaled operator
+    const float ri = r[gi] - t;
+    x[gi] += di;
+    r[gi] = ri;
+    dout[gi] = comp < 3 ? c1 * di + c2 * ri * (dinv ? dinv[gi] : 1.f) : 0.f;
+  }
+}
+// (The dynamic LDS is sized for the largest tile; on the 1.12 M-tet mesh the tiles gather 889 distinct neighbours in the
+// median and 1325 at most, 21 KB, so LDS does not limit the occupancy.  Splitting the tiles into two launches by size was
+// measured: slower, 159 against 143 us.)
+void launch_sweep_tiled_f32(hipStream_t st, int nv, int64_t N2, int max_nu, const int64_t* nadj_ptr, const float* vals,
+                            const uint16_t* ploc, const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag,
+                            const float* dinv, float c1, float c2, const float* din, float* dout, float* x, float* r) {
+  static const int threads = getenv("FSI_TILE_THREADS") ? atoi(getenv("FSI_TILE_THREADS")) : 512;
+  const int th = threads >= 1024 ? 1024 : (threads >= 512 ? 512 : 256);
+  const unsigned tiles = (unsigned)((N2 + TILE_NODES - 1) / TILE_NODES);
+  const size_t lds = (size_t)max_nu * sizeof(float4);
+  if (nv == 1)
+    hipLaunchKernelGGL(k_sweep_tiled_f32<1>, dim3(tiles), dim3(th), lds, st, N2, nadj_ptr, vals, ploc, tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
+  else
+    hipLaunchKernelGGL(k_sweep_tiled_f32<3>, dim3(tiles), dim3(th), lds, st, N2, nadj_ptr, vals, ploc, tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
+}
+// The same fused sweep without tiles (coarse level of the displacement block: the vertex graph, L2-resident)
+__global__ __launch_bounds__(256) void k_sweep_sc_f32(int64_t N2, const int64_t* __restrict__ nadj_ptr,
+                                                      const int32_t* __restrict__ nadj, const float* __restrict__ chat,
+                                                      const uint8_t* __restrict__ rowflag, float c1, float c2,
+                                                      const float* __restrict__ din, float* __restrict__ dout,
+                                                      float* __restrict__ x, float* __restrict__ r) {
+  // vertex graph: ~15 entries per row.  4 lanes per row and the four strips of a row issued together: a quarter of the waves
+  // of the 16-lane form, and 3 dependent latencies per row (pointer -> index -> gathered d) whatever its length up to 16.
+  const int sub = threadIdx.x & 3;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 2;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 2;
+  const float4* d4 = reinterpret_cast<const float4*>(din);
+  for (int64_t row = grp; row < N2; row += ngrp) {
+    const int64_t b = nadj_ptr[row + 1];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int64_t e = nadj_ptr[row] + sub; e < b; e += 16) {
+      const bool p1 = e + 4 < b, p2 = e + 8 < b, p3 = e + 12 < b;
+      const int64_t e1 = p1 ? e + 4 : e, e2 = p2 ? e + 8 : e, e3 = p3 ? e + 12 : e;
+      const int k0 = nadj[e], k1 = nadj[e1], k2 = nadj[e2], k3 = nadj[e3];
+      const float a0 = chat[e];
+      float a1 = chat[e1], a2 = chat[e2], a3 = chat[e3];
+      if (!p1) a1 = 0.f;
+      if (!p2) a2 = 0.f;
+      if (!p3) a3 = 0.f;
+      const float4 x0 = d4[k0], x1 = d4[k1], x2 = d4[k2], x3 = d4[k3];
+      s0 += (a0 * x0.x + a1 * x1.x) + (a2 * x2.x + a3 * x3.x);
+      s1 += (a0 * x0.y + a1 * x1.y) + (a2 * x2.y + a3 * x3.y);
+      s2 += (a0 * x0.z + a1 * x1.z) + (a2 * x2.z + a3 * x3.z);
+    }
+    for (int off = 2; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 4); s1 += __shfl_xor(s1, off, 4); s2 += __shfl_xor(s2, off, 4);
+    }
+    if (sub == 0) {
+      const float4 dr = d4[row], xr = reinterpret_cast<const float4*>(x)[row];
+      float4 rr = reinterpret_cast<const float4*>(r)[row];
+      if (rowflag[3 * row]) s0 = dr.x;
+      if (rowflag[3 * row + 1]) s1 = dr.y;
+      if (rowflag[3 * row + 2]) s2 = dr.z;
+      rr.x -= s0; rr.y -= s1; rr.z -= s2;
+      reinterpret_cast<float4*>(x)[row] = make_float4(xr.x + dr.x, xr.y + dr.y, xr.z + dr.z, 0.f);
+      reinterpret_cast<float4*>(r)[row] = make_float4(rr.x, rr.y, rr.z, 0.f);
+      reinterpret_cast<float4*>(dout)[row] = make_float4(c1 * dr.x + c2 * rr.x, c1 * dr.y + c2 * rr.y, c1 * dr.z + c2 * rr.z, 0.f);
+    }
+  }
+}
+void launch_sweep_sc_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const float* chat,
+                         const uint8_t* rowflag, float c1, float c2, const float* din, float* dout, float* x, float* r) {
+  int64_t blocks = (N2 + 63) / 64;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_sweep_sc_f32, dim3((unsigned)blocks), dim3(256), 0, st, N2, nadj_ptr, nadj, chat, rowflag, c1, c2, din, dout, x, r);
+}
 int tile_nodes() { return TILE_NODES; }
 int tile_limit() { return TILE_LIMIT; }
 
@@ -1081,32 +1238,70 @@ __global__ __launch_bounds__(256) void k_sweep_csr_f32(int64_t n, const int64_t*
 // noise per sweep, which on a coarse mesh with a pressure-dominated right-hand side exceeded the velocity residual the outer
 // iteration was trying to reduce (tests/test_gpu_parity.py::test_properties_on_generated_mesh made no progress at all).
 // The vectors are 5 V doubles against ~65 V matrix entries: the bytes per sweep are those of the all-FP32 form.
+template <int LPR, int KS>       // lanes per row, strips issued together: LPR x KS entries per round
 __global__ __launch_bounds__(256) void k_sweep_csr_mixed(int64_t n, const int64_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ cols, const float* __restrict__ vals,
                                                          const int64_t* __restrict__ diagpos, const double* __restrict__ dvals,
                                                          double c1, double c2, const double* __restrict__ din,
                                                          double* __restrict__ dout, double* __restrict__ x, double* __restrict__ r) {
-  const int sub = threadIdx.x & 15;
-  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
-  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
-  for (int64_t i = grp; i < n; i += ngrp) {
+  // The sweep is a chain of dependent loads (row pointer -> column index -> gathered d) per row, so all strips of a ~65-entry
+  // row are issued together (3 latencies per row whatever its length up to LPR x KS), and a workgroup's rows are consecutive:
+  // their sums go through LDS to the first lanes of the workgroup, which do the Chebyshev update on consecutive entries
+  // (one lane per row doing it costs 8 memory instructions with 1 lane in LPR active).  Strips past the end re-read the
+  // first strip (cache hit) with weight zero.
+  constexpr int RPB = 256 / LPR;                 // rows per workgroup and round
+  __shared__ double ssum[RPB];
+  const int sub = threadIdx.x & (LPR - 1), g = threadIdx.x / LPR;
+  for (int64_t base = (int64_t)blockIdx.x * RPB; base < n; base += (int64_t)gridDim.x * RPB) {
+    const int64_t i = base + g;
     double s = 0.0;
-    for (int64_t e = rowptr[i] + sub; e < rowptr[i + 1]; e += 16) s += (double)vals[e] * din[cols[e]];
-    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
-    if (sub == 0) {
-      const double di = din[i], ri = r[i] - s;
-      x[i] += di;
-      r[i] = ri;
-      dout[i] = c1 * di + c2 * ri / dvals[diagpos[i]];
+    if (i < n) {
+      const int64_t b = rowptr[i + 1];
+      for (int64_t e = rowptr[i] + sub; e < b; e += LPR * KS) {
+        int k[KS];
+        float v[KS];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+          const bool in = e + j * LPR < b;
+          const int64_t ej = in ? e + j * LPR : e;
+          k[j] = cols[ej];
+          v[j] = vals[ej];
+          if (!in) v[j] = 0.f;
+        }
+        double dj[KS];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) dj[j] = din[k[j]];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) s += (double)v[j] * dj[j];
+      }
     }
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, LPR);
+    if (sub == 0) ssum[g] = s;
+    __syncthreads();
+    if (threadIdx.x < RPB && base + threadIdx.x < n) {
+      const int64_t row = base + threadIdx.x;
+      const double di = din[row], ri = r[row] - ssum[threadIdx.x];
+      x[row] += di;
+      r[row] = ri;
+      dout[row] = c1 * di + c2 * ri / dvals[diagpos[row]];
+    }
+    __syncthreads();
   }
 }
 void launch_sweep_csr_mixed(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const float* vals,
                             const int64_t* diagpos, const double* dvals, double c1, double c2, const double* din, double* dout,
                             double* x, double* r) {
-  int64_t blocks = (n + 15) / 16;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(k_sweep_csr_mixed, dim3((unsigned)blocks), dim3(256), 0, st, n, rowptr, cols, vals, diagpos, dvals, c1, c2, din, dout, x, r);
+  static const int lpr = getenv("FSI_SCHUR_LPR") ? atoi(getenv("FSI_SCHUR_LPR")) : 8;
+  const int rpb = 256 / (lpr == 16 ? 16 : (lpr == 4 ? 4 : 8));
+  int64_t blocks = (n + rpb - 1) / rpb;
+  if (blocks > 32768) blocks = 32768;
+  if (lpr == 16)
+    hipLaunchKernelGGL((k_sweep_csr_mixed<16, 4>), dim3((unsigned)blocks), dim3(256), 0, st, n, rowptr, cols, vals, diagpos, dvals, c1, c2, din, dout, x, r);
+  else if (lpr == 4)
+    hipLaunchKernelGGL((k_sweep_csr_mixed<4, 16>), dim3((unsigned)blocks), dim3(256), 0, st, n, rowptr, cols, vals, diagpos, dvals, c1, c2, din, dout, x, r);
+  else
+    hipLaunchKernelGGL((k_sweep_csr_mixed<8, 8>), dim3((unsigned)blocks), dim3(256), 0, st, n, rowptr, cols, vals, diagpos, dvals, c1, c2, din, dout, x, r);
 }
 __global__ void k_csr_dinv_f32(int64_t n, const int64_t* __restrict__ diagpos, const double* __restrict__ A, float* __restrict__ dinv) {
   GS(i, n) dinv[i] = (float)(1.0 / A[diagpos[i]]);
@@ -1146,13 +1341,35 @@ __global__ __launch_bounds__(256) void k_sweep_sb_b3(int64_t nS, const int64_t* 
   const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
   for (int64_t i = grp; i < nS; i += ngrp) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int64_t b = sb_ptr[i] + sub; b < sb_ptr[i + 1]; b += 16) {
-      const float4 xv = reinterpret_cast<const float4*>(din)[sb_col[b]];
-      const float* a = vals + 9 * b;
-      const float x0 = xv.x, x1 = xv.y, x2 = xv.z;
-      s0 += a[0] * x0 + a[1] * x1 + a[2] * x2;
-      s1 += a[3] * x0 + a[4] * x1 + a[5] * x2;
-      s2 += a[6] * x0 + a[7] * x1 + a[8] * x2;
+    const int64_t bend = sb_ptr[i + 1];
+    if (LEVEL == 0) {
+      // two 16-block strips per round, issued together (index -> gathered d is a dependent pair of loads; an edge node's ~22
+      // blocks take one round instead of two, a vertex node's ~65 three instead of five); the strip past the end re-reads
+      // the first one with its d zeroed
+      for (int64_t b = sb_ptr[i] + sub; b < bend; b += 32) {
+        const bool p1 = b + 16 < bend;
+        const int64_t b1 = p1 ? b + 16 : b;
+        const int k0 = sb_col[b], k1 = sb_col[b1];
+        const float* a = vals + 9 * b;
+        const float* q = vals + 9 * b1;
+        const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6], a7 = a[7], a8 = a[8];
+        const float q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7], q8 = q[8];
+        const float4 xv = reinterpret_cast<const float4*>(din)[k0];
+        float4 yv = reinterpret_cast<const float4*>(din)[k1];
+        if (!p1) yv = make_float4(0.f, 0.f, 0.f, 0.f);
+        s0 += (a0 * xv.x + a1 * xv.y + a2 * xv.z) + (q0 * yv.x + q1 * yv.y + q2 * yv.z);
+        s1 += (a3 * xv.x + a4 * xv.y + a5 * xv.z) + (q3 * yv.x + q4 * yv.y + q5 * yv.z);
+        s2 += (a6 * xv.x + a7 * xv.y + a8 * xv.z) + (q6 * yv.x + q7 * yv.y + q8 * yv.z);
+      }
+    } else {
+      for (int64_t b = sb_ptr[i] + sub; b < bend; b += 16) {
+        const float4 xv = reinterpret_cast<const float4*>(din)[sb_col[b]];
+        const float* a = vals + 9 * b;
+        const float x0 = xv.x, x1 = xv.y, x2 = xv.z;
+        s0 += a[0] * x0 + a[1] * x1 + a[2] * x2;
+        s1 += a[3] * x0 + a[4] * x1 + a[5] * x2;
+        s2 += a[6] * x0 + a[7] * x1 + a[8] * x2;
+      }
     }
     for (int off = 8; off > 0; off >>= 1) {
       s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);

@@ -264,6 +264,21 @@ void cheb_db_f32(FsiCtx* ctx, const float* db, const float* dinv, const double* 
   const double lmin = lmax / kappa, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
   double rho = 1.0 / sig;
   launch_cheb_init_f32(st, n, frhs, dinv, (float)(1.0 / th), fx, fr, fd);
+  if (ctx->tiled && ctx->fused_sweeps) {
+    float *da = fd, *db_ = ft;                   // d is ping-ponged; the product stays in registers
+    for (int k = 0; k < its; ++k) {
+      const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->db_ev0[0] && ctx->db_samples_pending < 8;
+      if (timed) (void)hipEventRecord(ctx->db_ev0[ctx->db_samples_pending], st);
+      const double rn = 1.0 / (2.0 * sig - rho);
+      launch_sweep_tiled_f32(st, 3, ctx->N2, ctx->tile_max_nu, ctx->nadj_ptr.p, db, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
+                             nullptr, dinv, (float)(rn * rho), (float)(2.0 * rn / de), da, db_, fx, fr);
+      if (timed) { (void)hipEventRecord(ctx->db_ev1[ctx->db_samples_pending], st); ctx->db_samples_pending += 1; }
+      std::swap(da, db_);
+      rho = rn;
+    }
+    launch_unpad_from_f32(st, ctx->N2, fx, x);
+    return;
+  }
   for (int k = 0; k < its; ++k) {
     const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->db_ev0[0] && ctx->db_samples_pending < 8;
     if (timed) (void)hipEventRecord(ctx->db_ev0[ctx->db_samples_pending], st);
@@ -467,6 +482,8 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
       launch_pad_to_f32(st, N2, td, ctx->dd_dinv32.p, frhs);
       const double lmax = ctx->lmax_d, lmin = lmax / ctx->cheb_kappa_d, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
       double rho = 1.0 / sig;
+      const bool fused = ctx->tiled && ctx->fused_sweeps;
+      float *dcur = fd, *dnext = ft;               // fused sweeps ping-pong the direction; ft is otherwise the product
       auto fine_spmv = [&](int k_sample) {
         const bool timed = ctx->sample_budget > 0 && k_sample >= 0 && k_sample < 4 && ctx->sc_ev0[0];
         if (timed) (void)hipEventRecord(ctx->sc_ev0[k_sample], st);
@@ -477,15 +494,28 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
           launch_spmv_sc_f32(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_chat.p, ctx->dd_rowflag.p, fd, ft);
         if (timed) { (void)hipEventRecord(ctx->sc_ev1[k_sample], st); ctx->sc_samples_pending = k_sample + 1; }
       };
+      // one sweep: product + Chebyshev update (one launch when fused)
+      auto fine_sweep = [&](float c1, float c2, int k_sample) {
+        if (!fused) {
+          fine_spmv(k_sample);
+          launch_cheb_step_f32(st, n, ft, ctx->ones32.p, c1, c2, fx, fr, fd);
+          return;
+        }
+        const bool timed = ctx->sample_budget > 0 && k_sample >= 0 && k_sample < 4 && ctx->sc_ev0[0];
+        if (timed) (void)hipEventRecord(ctx->sc_ev0[k_sample], st);
+        launch_sweep_tiled_f32(st, 1, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_chat.p, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
+                               ctx->dd_rowflag.p, nullptr, c1, c2, dcur, dnext, fx, fr);
+        if (timed) { (void)hipEventRecord(ctx->sc_ev1[k_sample], st); ctx->sc_samples_pending = k_sample + 1; }
+        std::swap(dcur, dnext);
+      };
       if (ctx->mg_ready) {
         // two-level cycle: Chebyshev smoothing on [lmax/alpha, lmax], coarse solve on the vertex graph, smoothing again
         const double slmin = lmax / ctx->mg_alpha, sth = 0.5 * (lmax + slmin), sde = 0.5 * (lmax - slmin), ssig = sth / sde;
         double srho = 1.0 / ssig;
         launch_cheb_init_f32(st, n, frhs, ctx->ones32.p, (float)(1.0 / sth), fx, fr, fd);
         for (int k = 0; k < ctx->mg_pre; ++k) {
-          fine_spmv(k);
           const double rn = 1.0 / (2.0 * ssig - srho);
-          launch_cheb_step_f32(st, n, ft, ctx->ones32.p, (float)(rn * srho), (float)(2.0 * rn / sde), fx, fr, fd);
+          fine_sweep((float)(rn * srho), (float)(2.0 * rn / sde), k);
           srho = rn;
         }
         const int64_t nc = ctx->mg_nc, n4c = 4 * nc;
@@ -495,39 +525,36 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
           const double cl = ctx->mg_clmax, clmin = cl / ctx->mg_ckappa, cth = 0.5 * (cl + clmin), cde = 0.5 * (cl - clmin), csig = cth / cde;
           double crho = 1.0 / csig;
           launch_cheb_init_f32(st, n4c, crhs, ctx->mg_cones.p, (float)(1.0 / cth), cx, cr, cd);
+          float *ca = cd, *cb = ct;
           for (int k = 0; k < ctx->mg_cits; ++k) {
-            launch_spmv_sc_f32(st, nc, ctx->mg_cptr.p, ctx->mg_ccol.p, ctx->mg_cc.p, ctx->mg_cflag.p, cd, ct);
             const double rn = 1.0 / (2.0 * csig - crho);
-            launch_cheb_step_f32(st, n4c, ct, ctx->mg_cones.p, (float)(rn * crho), (float)(2.0 * rn / cde), cx, cr, cd);
+            if (ctx->fused_sweeps) {
+              launch_sweep_sc_f32(st, nc, ctx->mg_cptr.p, ctx->mg_ccol.p, ctx->mg_cc.p, ctx->mg_cflag.p, (float)(rn * crho),
+                                  (float)(2.0 * rn / cde), ca, cb, cx, cr);
+              std::swap(ca, cb);
+            } else {
+              launch_spmv_sc_f32(st, nc, ctx->mg_cptr.p, ctx->mg_ccol.p, ctx->mg_cc.p, ctx->mg_cflag.p, cd, ct);
+              launch_cheb_step_f32(st, n4c, ct, ctx->mg_cones.p, (float)(rn * crho), (float)(2.0 * rn / cde), cx, cr, cd);
+            }
             crho = rn;
           }
         }
-        launch_mg_prolong(st, N2, ctx->mg_par.p, ctx->mg_pw.p, ctx->mg_d0.p, cx, fd);     // correction as the next direction
-        fine_spmv(-1);
-        launch_cheb_step_f32(st, n, ft, ctx->ones32.p, 0.f, (float)(1.0 / sth), fx, fr, fd);   // x += P x_c, r -= C P x_c, restart
+        launch_mg_prolong(st, N2, ctx->mg_par.p, ctx->mg_pw.p, ctx->mg_d0.p, cx, dcur);   // correction as the next direction
+        fine_sweep(0.f, (float)(1.0 / sth), -1);                                       // x += P x_c, r -= C P x_c, restart
         srho = 1.0 / ssig;
         for (int k = 0; k < ctx->mg_post; ++k) {
-          fine_spmv(-1);
           const double rn = 1.0 / (2.0 * ssig - srho);
-          launch_cheb_step_f32(st, n, ft, ctx->ones32.p, (float)(rn * srho), (float)(2.0 * rn / sde), fx, fr, fd);
+          fine_sweep((float)(rn * srho), (float)(2.0 * rn / sde), -1);
           srho = rn;
         }
         ctx->inner_its[2] += ctx->mg_pre + 1 + ctx->mg_post - ctx->cheb_its_d;     // counted below as cheb_its_d
       } else {
-      launch_cheb_init_f32(st, n, frhs, ctx->ones32.p, (float)(1.0 / th), fx, fr, fd);
-      for (int k = 0; k < ctx->cheb_its_d; ++k) {
-        const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->sc_ev0[0];
-        if (timed) (void)hipEventRecord(ctx->sc_ev0[k], st);
-        if (ctx->tiled)
-          launch_spmv_tiled_f32(st, 1, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_chat.p, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
-                                ctx->dd_rowflag.p, fd, ft);
-        else
-          launch_spmv_sc_f32(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_chat.p, ctx->dd_rowflag.p, fd, ft);
-        if (timed) { (void)hipEventRecord(ctx->sc_ev1[k], st); ctx->sc_samples_pending = k + 1; }
-        const double rn = 1.0 / (2.0 * sig - rho);
-        launch_cheb_step_f32(st, n, ft, ctx->ones32.p, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
-        rho = rn;
-      }
+        launch_cheb_init_f32(st, n, frhs, ctx->ones32.p, (float)(1.0 / th), fx, fr, fd);
+        for (int k = 0; k < ctx->cheb_its_d; ++k) {
+          const double rn = 1.0 / (2.0 * sig - rho);
+          fine_sweep((float)(rn * rho), (float)(2.0 * rn / de), k);
+          rho = rn;
+        }
       }
       launch_unpad_from_f32(st, N2, fx, dd);
     } else if (ctx->dd_is_db && ctx->sweeps_fp32)
@@ -1769,6 +1796,12 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
         FSICHK(upload(ctx, ctx->tile_uptr, uptr));
         FSICHK(upload(ctx, ctx->tile_ulist, ulist));
         FSICHK(upload(ctx, ctx->tile_ploc, ploc));
+        std::vector<int> sorted_nu(ntiles);
+        for (int64_t t = 0; t < ntiles; ++t) sorted_nu[t] = (int)(uptr[t + 1] - uptr[t]);
+        std::sort(sorted_nu.begin(), sorted_nu.end());
+        if (getenv("FSI_DEBUG_PRECOND"))
+          fprintf(stderr, "[precond] tiles: %lld, distinct neighbours median %d, 90%% %d, max %d\n", (long long)ntiles,
+                  sorted_nu[(size_t)(ntiles / 2)], sorted_nu[(size_t)((ntiles - 1) * 9 / 10)], ctx->tile_max_nu);
       }
     }
     {
@@ -1978,6 +2011,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
   }
   ctx->debug_gcr = getenv("FSI_DEBUG_GCR") != nullptr;
+  ctx->fused_sweeps = !(getenv("FSI_FUSED_SWEEPS") && atoi(getenv("FSI_FUSED_SWEEPS")) == 0);
   ctx->debug_prec_apply = (getenv("FSI_DEBUG_PRECOND") && atoi(getenv("FSI_DEBUG_PRECOND")) >= 2) ? 12 : 0;
   if (getenv("FSI_NEWTON_FORCING")) ctx->newton_forcing = atof(getenv("FSI_NEWTON_FORCING"));
   if (getenv("FSI_GCR_REORTH")) ctx->gcr_reorth = atof(getenv("FSI_GCR_REORTH"));

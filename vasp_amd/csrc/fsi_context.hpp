@@ -184,8 +184,8 @@ struct FsiCtx {
   fsi::DevBuf<double> mg_Ac;
   fsi::DevBuf<float> mg_cc, mg_d0, mg_dcinv4, mg_cones, mg_work;
   fsi::DevBuf<uint8_t> mg_cflag;
-  int mg_pre = 4, mg_post = 8, mg_cits = 40;  // fine Chebyshev sweeps before / after the coarse solve; coarse sweeps
-  double mg_alpha = 30.0, mg_ckappa = 250.0, mg_clmax = 2.0;   // smoothing interval [lmax/alpha, lmax]; coarse interval
+  int mg_pre = 4, mg_post = 6, mg_cits = 40;  // fine Chebyshev sweeps before / after the coarse solve; coarse sweeps
+  double mg_alpha = 20.0, mg_ckappa = 250.0, mg_clmax = 2.0;   // smoothing interval [lmax/alpha, lmax]; coarse interval
   fsi::SubMat Mdd, Mvv, Ms;                  // A_dd, Avv~, sparsified Schur complement (ILU only)
   fsi::DevBuf<double> blk;                   // work vectors of the block preconditioner
   int64_t nS = 0;                            // solid (incl. interface) nodes; compact velocity block A_SS on them
@@ -217,7 +217,7 @@ struct FsiCtx {
   fsi::DevBuf<float> sb_binv12;
   fsi::DevBuf<double> sb_binv9;
   fsi::DevBuf<double> mask_s, mask_f;        // [3 N2] 1 on velocity dofs of solid (incl. interface) / fluid-interior nodes
-  int cheb_its_s = 300, cheb_its_f = 4, cheb_its_p = 40, cheb_its_d = 60;     // Chebyshev sweeps on the solid / fluid part of the velocity block
+  int cheb_its_s = 300, cheb_its_f = 4, cheb_its_p = 30, cheb_its_d = 60;     // Chebyshev sweeps on the solid / fluid part of the velocity block
   double cheb_kappa_s = 1e4, cheb_kappa_f = 5.0, cheb_kappa_p = 100.0, lmax_s = 1.0, lmax_f = 1.0, lmax_p = 1.0, cheb_kappa_d = 1000.0, lmax_d = 1.0;
   double inner_rtol = 1e-2;
   int inner_maxit = 40, inner_maxit_p = 60;
@@ -255,6 +255,8 @@ struct FsiCtx {
   fsi::DevBuf<float> A32;                         // FP32 copy of A for the products inside the Krylov iterations (FSI_OPERATOR_FP32, default on)
   bool op32_ok = false; int op32_policy = 1; int64_t op32_products = 0;
   int debug_prec_apply = 0;
+  bool fused_sweeps = true;                  // FSI_FUSED_SWEEPS=0: product and Chebyshev update of the FP32 sweeps as two launches
+
   double tol_hint = 0.0, bnorm_max = 0.0;     // fsi_newton_solve -> solve_gcr: lowest linear tolerance to expect; largest |b| seen
   double gcr_reorth = 0.0;                   // FSI_GCR_REORTH: second Gram-Schmidt pass when |w'| < reorth |w| (0: automatic)
   double newton_forcing = 1e-2;              // inexact Newton: linear tolerance = forcing * atol / |b| (FSI_NEWTON_FORCING; 1e-2: same Newton counts as 1e-3 on the bench, 18 % fewer Krylov iterations)

@@ -135,6 +135,11 @@ int tile_nodes();
 int tile_limit();
 void launch_extract_chat(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
                          float* chat, uint8_t* rowflag, int32_t* flags);
+void launch_sweep_tiled_f32(hipStream_t st, int nv, int64_t N2, int max_nu, const int64_t* nadj_ptr, const float* vals,
+                            const uint16_t* ploc, const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag,
+                            const float* dinv, float c1, float c2, const float* din, float* dout, float* x, float* r);
+void launch_sweep_sc_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const float* chat,
+                         const uint8_t* rowflag, float c1, float c2, const float* din, float* dout, float* x, float* r);
 void launch_spmv_sc_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const float* chat,
                         const uint8_t* rowflag, const float* x, float* y);
 void launch_spmv_db_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const float* db,
