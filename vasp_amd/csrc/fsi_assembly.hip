@@ -124,63 +124,110 @@ __device__ inline void interpolate(const double* __restrict__ sU, const double* 
   for (int a = 0; a < 4; ++a) s.p += c_L[q][a] * sU[60 + a];
 }
 
+// Both states (n and n-1) in one pass over the ten nodes: a node's table entries and physical gradient serve the two
+// interpolations and are dead afterwards - with two separate passes the compiler keeps the 40 table values of a point in
+// registers across both (k_residual then needs 302 VGPRs: one wave per SIMD).  sT[q][a] = (N, dN/dxi_0..2) in LDS.
+__device__ inline void interpolate2(const double* __restrict__ sU, const double* __restrict__ sO,
+                                    const double* __restrict__ Jinv, const double4* __restrict__ sTq, const double* __restrict__ Lq,
+                                    Kin<double>& s, Kin<double>& o) {
+  for (int i = 0; i < 3; ++i) {
+    s.d[i] = 0.0; s.v[i] = 0.0; o.d[i] = 0.0; o.v[i] = 0.0;
+    for (int j = 0; j < 3; ++j) { s.gd[i][j] = 0.0; s.gv[i][j] = 0.0; o.gd[i][j] = 0.0; o.gv[i][j] = 0.0; }
+  }
+  s.p = 0.0; o.p = 0.0;
+#pragma unroll 1
+  for (int a = 0; a < 10; ++a) {
+    const double4 t = sTq[a];
+    const double N = t.x;
+    double G[3];
+    for (int j = 0; j < 3; ++j) G[j] = t.y * Jinv[j] + t.z * Jinv[3 + j] + t.w * Jinv[6 + j];
+    for (int i = 0; i < 3; ++i) {
+      const double dv = sU[i * 10 + a], vv = sU[30 + i * 10 + a], dw = sO[i * 10 + a], vw = sO[30 + i * 10 + a];
+      s.d[i] += N * dv; s.v[i] += N * vv;
+      o.d[i] += N * dw; o.v[i] += N * vw;
+      for (int j = 0; j < 3; ++j) {
+        s.gd[i][j] += dv * G[j]; s.gv[i][j] += vv * G[j];
+        o.gd[i][j] += dw * G[j]; o.gv[i][j] += vw * G[j];
+      }
+    }
+  }
+  for (int a = 0; a < 4; ++a) { s.p += Lq[a] * sU[60 + a]; o.p += Lq[a] * sO[60 + a]; }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // residual: F += sum over cells of the element vector (un-negated, no boundary conditions)
 // ---------------------------------------------------------------------------------------------------------
-// Two cells per 64-lane workgroup: the quadrature phase (24 points, by far the longest part: two interpolations and the flux
-// per point) keeps lanes 0-23 on the first cell and lanes 32-55 on the second, so one instruction stream serves 48 lanes
-// instead of 24; the load and the contraction phases take the two cells one after the other with all 64 lanes.
-__global__ __launch_bounds__(64) void k_residual(ElemArrays ea, ElemParams ep, const double* __restrict__ U,
-                                                 const double* __restrict__ U1, double* __restrict__ F, int64_t C) {
+// Two cells per 64-lane workgroup and round: the quadrature phase (24 points, by far the longest part: two interpolations
+// and the flux per point) keeps lanes 0-23 on the first cell and lanes 32-55 on the second, so one instruction stream
+// serves 48 lanes instead of 24; the load and the contraction phases take the two cells one after the other with all 64
+// lanes.  Workgroups are persistent (a grid-stride loop over the cell pairs) and hold the basis tables in LDS: read from
+// constant memory with a lane-dependent index they are vector loads, 96 per cell in the contraction alone, and each costs
+// address-unit cycles that an LDS read does not.
+template <int WAVES>      // waves per SIMD the register budget is set for (2: no spills; 3: 56 VGPRs spilled, measured slower)
+__global__ __launch_bounds__(64, WAVES) void k_residual(ElemArrays ea, ElemParams ep, const double* __restrict__ U,
+                                                        const double* __restrict__ U1, double* __restrict__ F, int64_t C) {
   const int lane = threadIdx.x;
-  const int64_t c0 = 2 * (int64_t)blockIdx.x;
-  const int ncell = c0 + 1 < C ? 2 : 1;
+  __shared__ __attribute__((aligned(32))) double4 sT[NQ][10];        // (N, dN/dxi) per point and node
+  __shared__ double sL[NQ][4], sW[NQ];
   __shared__ double sU[2][NLOC], sU1[2][NLOC], sJ[2][10];
   __shared__ double sS[2][NQ][25];
-  int32_t dof[2] = {0, 0};
-  for (int t = 0; t < ncell; ++t) {
-    dof[t] = ea.cell_dofs[(c0 + t) * NLOC + lane];
-    sU[t][lane] = U[dof[t]];
-    sU1[t][lane] = U1[dof[t]];
+  for (int t = lane; t < NQ * 10; t += 64) {
+    const int q = t / 10, a = t % 10;
+    sT[q][a] = make_double4(c_N[q][a], c_dN[q][a][0], c_dN[q][a][1], c_dN[q][a][2]);
   }
-  if (lane < 10 * ncell) sJ[lane / 10][lane % 10] = ea.geom[c0 * 10 + lane];      // geom of consecutive cells is contiguous
-  __syncthreads();
+  for (int t = lane; t < NQ * 4; t += 64) sL[t / 4][t % 4] = c_L[t / 4][t % 4];
+  if (lane < NQ) sW[lane] = c_qw[lane];
+  const int64_t npairs = (C + 1) / 2;
   const int half = lane >> 5, q = lane & 31;
-  if (q < NQ && half < ncell) {
-    const int64_t c = c0 + half;
-    const int kind = ea.cell_kind[c], region = ea.cell_region[c];
-    const double* J = sJ[half];
-    Kin<double> s, o;
-    interpolate(sU[half], J, q, s);
-    interpolate(sU1[half], J, q, o);
-    Slots<double> out;
-    if (kind == 0) fluid_flux<double, PART_BOTH>(ep.fluid[region], ep.sc, s, o, out);
-    else solid_flux<double, PART_BOTH>(ep.solid[region], ep.sc, s, o, out);
-    const double w = J[9] * c_qw[q];
-    double* S = sS[half][q];
-    for (int i = 0; i < 3; ++i) {
-      S[i] = w * out.dval[i];
-      S[12 + i] = w * out.vval[i];
-      for (int k = 0; k < 3; ++k) {     // gradient slots pulled back to reference coordinates
-        S[3 + 3 * i + k] = w * (out.dgrd[i][0] * J[3 * k] + out.dgrd[i][1] * J[3 * k + 1] + out.dgrd[i][2] * J[3 * k + 2]);
-        S[15 + 3 * i + k] = w * (out.vgrd[i][0] * J[3 * k] + out.vgrd[i][1] * J[3 * k + 1] + out.vgrd[i][2] * J[3 * k + 2]);
+  for (int64_t pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+    const int64_t c0 = 2 * pair;
+    const int ncell = c0 + 1 < C ? 2 : 1;
+    int32_t dof[2] = {0, 0};
+    __syncthreads();                                 // the previous pair's contraction has finished with sS / sU
+    for (int t = 0; t < ncell; ++t) {
+      dof[t] = ea.cell_dofs[(c0 + t) * NLOC + lane];
+      sU[t][lane] = U[dof[t]];
+      sU1[t][lane] = U1[dof[t]];
+    }
+    if (lane < 10 * ncell) sJ[lane / 10][lane % 10] = ea.geom[c0 * 10 + lane];      // geom of consecutive cells is contiguous
+    __syncthreads();
+    if (q < NQ && half < ncell) {
+      const int64_t c = c0 + half;
+      const int kind = ea.cell_kind[c], region = ea.cell_region[c];
+      const double* J = sJ[half];
+      Kin<double> s, o;
+      interpolate2(sU[half], sU1[half], J, sT[q], sL[q], s, o);
+      Slots<double> out;
+      if (kind == 0) fluid_flux<double, PART_BOTH>(ep.fluid[region], ep.sc, s, o, out);
+      else solid_flux<double, PART_BOTH>(ep.solid[region], ep.sc, s, o, out);
+      const double w = J[9] * sW[q];
+      double* S = sS[half][q];
+      for (int i = 0; i < 3; ++i) {
+        S[i] = w * out.dval[i];
+        S[12 + i] = w * out.vval[i];
+        for (int k = 0; k < 3; ++k) {     // gradient slots pulled back to reference coordinates
+          S[3 + 3 * i + k] = w * (out.dgrd[i][0] * J[3 * k] + out.dgrd[i][1] * J[3 * k + 1] + out.dgrd[i][2] * J[3 * k + 2]);
+          S[15 + 3 * i + k] = w * (out.vgrd[i][0] * J[3 * k] + out.vgrd[i][1] * J[3 * k + 1] + out.vgrd[i][2] * J[3 * k + 2]);
+        }
       }
+      S[24] = w * out.pval;
     }
-    S[24] = w * out.pval;
-  }
-  __syncthreads();
-  for (int t = 0; t < ncell; ++t) {
-    double r = 0.0;
-    if (lane < 60) {
-      const int fld = lane / 30, comp = (lane % 30) / 10, a = lane % 10;
-      const int vo = fld * 12 + comp, go = fld * 12 + 3 + 3 * comp;
-      for (int k = 0; k < NQ; ++k)
-        r += sS[t][k][vo] * c_N[k][a] + sS[t][k][go] * c_dN[k][a][0] + sS[t][k][go + 1] * c_dN[k][a][1] + sS[t][k][go + 2] * c_dN[k][a][2];
-    } else {
-      const int a = lane - 60;
-      for (int k = 0; k < NQ; ++k) r += sS[t][k][24] * c_L[k][a];
+    __syncthreads();
+    for (int t = 0; t < ncell; ++t) {
+      double r = 0.0;
+      if (lane < 60) {
+        const int fld = lane / 30, comp = (lane % 30) / 10, a = lane % 10;
+        const int vo = fld * 12 + comp, go = fld * 12 + 3 + 3 * comp;
+        for (int k = 0; k < NQ; ++k) {
+          const double4 tb = sT[k][a];
+          r += sS[t][k][vo] * tb.x + sS[t][k][go] * tb.y + sS[t][k][go + 1] * tb.z + sS[t][k][go + 2] * tb.w;
+        }
+      } else {
+        const int a = lane - 60;
+        for (int k = 0; k < NQ; ++k) r += sS[t][k][24] * sL[k][a];
+      }
+      unsafeAtomicAdd(&F[dof[t]], r);
     }
-    unsafeAtomicAdd(&F[dof[t]], r);
   }
 }
 
@@ -413,7 +460,8 @@ void launch_geometry(hipStream_t st, int64_t C, const double* coords, const int3
 }
 void launch_residual(hipStream_t st, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
                      const double* U1, double* F) {
-  hipLaunchKernelGGL(k_residual, dim3((unsigned)((C + 1) / 2)), dim3(64), 0, st, ea, ep, U, U1, F, C);
+  const int64_t grid = std::min<int64_t>((C + 1) / 2, 256 * 8 * 4);      // persistent: a few rounds of the resident workgroups
+  hipLaunchKernelGGL(k_residual<2>, dim3((unsigned)grid), dim3(64), 0, st, ea, ep, U, U1, F, C);
 }
 void launch_jacobian(hipStream_t st, int part, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
                      const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals) {

@@ -101,6 +101,26 @@ __host__ __device__ inline void fluid_flux(const FluidProps& fp, const Scheme& s
                                            const Kin<double>& o, Slots<T>& out) {
   const double rho = fp.rho, mu = fp.mu, rk = fp.rho / sc.k;
   zero_slots(out);
+  // the n-1 part first: the gradients of the old state are dead before the nonlinear part needs its registers
+  if (PART & PART_LINEAR) {
+    double Fi1[3][3];
+    double J1 = inv_det_F(o.gd, Fi1);
+    double A1[3][3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) A1[i][j] = o.gv[i][0] * Fi1[0][j] + o.gv[i][1] * Fi1[1][j] + o.gv[i][2] * Fi1[2][j];
+    for (int i = 0; i < 3; ++i) {
+      double conv1 = A1[i][0] * o.v[0] + A1[i][1] * o.v[1] + A1[i][2] * o.v[2];
+      out.vval[i] = (rk * J1 * sc.th1) * (s.v[i] - o.v[i]) + sc.th1 * rho * J1 * conv1;
+    }
+    double sg1[3][3];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) sg1[i][j] = (sc.th1 * mu) * (A1[i][j] + A1[j][i]);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        out.vgrd[i][j] = T(J1 * (sg1[i][0] * Fi1[j][0] + sg1[i][1] * Fi1[j][1] + sg1[i][2] * Fi1[j][2]));
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) out.dgrd[i][j] = sc.alpha * s.gd[i][j];
+  }
   if (PART & PART_NONLINEAR) {
     T Fi[3][3];
     T J = inv_det_F(s.gd, Fi);
@@ -111,7 +131,7 @@ __host__ __device__ inline void fluid_flux(const FluidProps& fp, const Scheme& s
     for (int j = 0; j < 3; ++j) w[j] = sc.th0 * s.v[j] - (s.d[j] - o.d[j]) * (1.0 / sc.k);
     for (int i = 0; i < 3; ++i) {
       T conv = A[i][0] * w[0] + A[i][1] * w[1] + A[i][2] * w[2];
-      out.vval[i] = J * (rk * sc.th0 * (s.v[i] - o.v[i]) + rho * conv);
+      out.vval[i] = J * (rk * sc.th0 * (s.v[i] - o.v[i]) + rho * conv) + out.vval[i];
     }
     // J (-p I + theta0 mu (A + A^T)) F^-T
     T sg[3][3];
@@ -120,27 +140,8 @@ __host__ __device__ inline void fluid_flux(const FluidProps& fp, const Scheme& s
     for (int i = 0; i < 3; ++i) sg[i][i] = sg[i][i] - s.p;
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j)
-        out.vgrd[i][j] = J * (sg[i][0] * Fi[j][0] + sg[i][1] * Fi[j][1] + sg[i][2] * Fi[j][2]);
+        out.vgrd[i][j] = J * (sg[i][0] * Fi[j][0] + sg[i][1] * Fi[j][1] + sg[i][2] * Fi[j][2]) + out.vgrd[i][j];
     out.pval = J * (A[0][0] + A[1][1] + A[2][2]);  // div(J F^-1 v) = J tr(grad(v) F^-1)  (Piola identity)
-  }
-  if (PART & PART_LINEAR) {
-    double Fi1[3][3];
-    double J1 = inv_det_F(o.gd, Fi1);
-    double A1[3][3];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) A1[i][j] = o.gv[i][0] * Fi1[0][j] + o.gv[i][1] * Fi1[1][j] + o.gv[i][2] * Fi1[2][j];
-    for (int i = 0; i < 3; ++i) {
-      double conv1 = A1[i][0] * o.v[0] + A1[i][1] * o.v[1] + A1[i][2] * o.v[2];
-      out.vval[i] = out.vval[i] + (rk * J1 * sc.th1) * (s.v[i] - o.v[i]) + sc.th1 * rho * J1 * conv1;
-    }
-    double sg1[3][3];
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) sg1[i][j] = (sc.th1 * mu) * (A1[i][j] + A1[j][i]);
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j)
-        out.vgrd[i][j] = out.vgrd[i][j] + J1 * (sg1[i][0] * Fi1[j][0] + sg1[i][1] * Fi1[j][1] + sg1[i][2] * Fi1[j][2]);
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) out.dgrd[i][j] = sc.alpha * s.gd[i][j];
   }
 }
 
