@@ -617,7 +617,15 @@ __global__ __launch_bounds__(1024) void k_sweep_tiled_f32(int64_t N2, const int6
   const int64_t r0 = tile * TILE_NODES;
   const int nrows = (int)((r0 + TILE_NODES < N2 ? r0 + TILE_NODES : N2) - r0);
   const int nth = blockDim.x, ngrp = nth >> 4;
-  for (int64_t i = threadIdx.x; i < nu; i += nth) sx[i] = d4[ulist[u0 + i]];
+  for (int64_t i = threadIdx.x; i < nu; i += 4 * nth) {        // index -> entry is a dependent pair of loads: four pairs in flight
+    const int64_t i1 = i + nth, i2 = i + 2 * nth, i3 = i + 3 * nth;
+    const int32_t k0 = ulist[u0 + i], k1 = i1 < nu ? ulist[u0 + i1] : 0, k2 = i2 < nu ? ulist[u0 + i2] : 0, k3 = i3 < nu ? ulist[u0 + i3] : 0;
+    const float4 v0 = d4[k0], v1 = d4[k1], v2 = d4[k2], v3 = d4[k3];
+    sx[i] = v0;
+    if (i1 < nu) sx[i1] = v1;
+    if (i2 < nu) sx[i2] = v2;
+    if (i3 < nu) sx[i3] = v3;
+  }
   for (int i = threadIdx.x; i <= nrows; i += nth) sptr[i] = nadj_ptr[r0 + i];
   __syncthreads();
   const int sub = threadIdx.x & 15, g = threadIdx.x >> 4;

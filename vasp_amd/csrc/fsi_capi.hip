@@ -776,7 +776,14 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
   // that still matter as its large ones.
   double* qd = ctx->tmp5.p;
   const double* src = r;
+  // attainable accuracy: near round-off (a tolerance of 1e-11 on a system with the 1e7 penalty) the recurrence can hover just
+  // above the target for thousands of iterations; 40 iterations without a 10 % gain within a factor 100 of the target (FP32
+  // basis: anywhere - the restart from the true residual is harmless) end the cycle and solve_gcr decides
+  double best = rnorm;
+  int since_gain = 0;
+  ctx->gcr_stagnated = false;
   while (rnorm > target && *iters < max_it) {
+    if (since_gain >= 40 && (f32 || rnorm <= 100.0 * target)) { ctx->gcr_stagnated = true; break; }
     if (ctx->part && ctx->ras) {
       // restricted additive Schwarz: the local solve sees the residual on its overlap (complete ghost rows), zero on the
       // outermost layer; below, the owners' part of the result replaces whatever the overlap produced
@@ -911,6 +918,7 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
       fflush(stderr);
     }
     if (!std::isfinite(rnorm)) { ctx->err = "GCR diverged (non-finite residual)"; return FSI_ERR_LINEAR; }
+    if (rnorm < 0.9 * best) { best = rnorm; since_gain = 0; } else since_gain += 1;
     if ((int)cy.slots.size() == 32) FSICHK(gcr_flush(ctx, cy, x));
   }
   FSICHK(gcr_flush(ctx, cy, x));
@@ -976,6 +984,9 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
     rstart = rnorm;
   }
   *relres = rnorm / bnorm;
+  // stagnation within a factor 10 of a tolerance below 1e-9: the answer is as accurate as FP64 makes it on this system, and
+  // the caller (Newton's own residual check) judges the step; reported through relres
+  if (ctx->gcr_stagnated && rtol <= 1e-9 && rnorm <= 10.0 * rtol * bnorm) return FSI_OK;
   if (!(rnorm <= rtol * bnorm)) {
     char buf[160];
     snprintf(buf, sizeof buf, "GCR: no convergence in %d iterations (relres %.3e, tol %.1e)", *iters, *relres, rtol);
@@ -1035,6 +1046,9 @@ int solve_bicgstab(FsiCtx* ctx, const double* rhs, double* x, double rtol, int m
     if (!std::isfinite(rnorm)) { ctx->err = "BiCGStab diverged"; return FSI_ERR_LINEAR; }
   }
   *relres = rnorm / bnorm;
+  // stagnation within a factor 10 of a tolerance below 1e-9: the answer is as accurate as FP64 makes it on this system, and
+  // the caller (Newton's own residual check) judges the step; reported through relres
+  if (ctx->gcr_stagnated && rtol <= 1e-9 && rnorm <= 10.0 * rtol * bnorm) return FSI_OK;
   if (!(rnorm <= rtol * bnorm)) {
     char buf[160];
     snprintf(buf, sizeof buf, "BiCGStab: no convergence in %d iterations (relres %.3e, tol %.1e)", *iters, *relres, rtol);

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -22,7 +24,13 @@ struct DevBuf {
     release();
     n = count;
     if (count == 0) return hipSuccess;
-    return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e != hipSuccess) return e;
+    // Fresh device memory is whatever the previous owner left (another context of the same process included): every buffer
+    // starts from zeros, so that no result can depend on it.  FSI_DEBUG_POISON=1 fills the floating-point buffers with NaN
+    // bit patterns instead - a read before the first write then shows up in the first norm that is taken.
+    static const bool poison = getenv("FSI_DEBUG_POISON") != nullptr;
+    return hipMemset(p, (poison && std::is_floating_point<T>::value) ? 0xFF : 0, count * sizeof(T));
   }
   void release() {
     if (p) (void)hipFree(p);
@@ -254,6 +262,7 @@ struct FsiCtx {
   bool gcr_arnoldi = false;                  // FSI_GCR_ARNOLDI=1: new directions from the latest q instead of the residual (measured: worse)
   fsi::DevBuf<float> A32;                         // FP32 copy of A for the products inside the Krylov iterations (FSI_OPERATOR_FP32, default on)
   bool op32_ok = false; int op32_policy = 1; int64_t op32_products = 0;
+  bool gcr_stagnated = false;                // the last cycle ended on 40 iterations without a 10 % gain
   int debug_prec_apply = 0;
   bool fused_sweeps = true;                  // FSI_FUSED_SWEEPS=0: product and Chebyshev update of the FP32 sweeps as two launches
 
