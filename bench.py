@@ -172,6 +172,10 @@ def main():
         if fused:                                                        # + d, r, x read, x, r, d' written, product not stored
             sc_bytes += tm["db_nodes"] * 80.0
             dbf_bytes += tm["db_nodes"] * 96.0                            # and the float4 Jacobi scaling
+        fp16 = fused and os.environ.get("FSI_SWEEPS_FP16") != "0"        # packed FP16 records: 4 / 8 bytes per pair, 24 per solid block
+        if fp16:
+            sc_bytes -= tm["db_pairs"] * 2.0
+            dbf_bytes -= tm["db_pairs"] * 6.0
         qb = tm["q_elem_bytes"]
         # orthogonalisation: every launch of k_gcr_dots / k_gcr_axpy streams m columns of Q (ld * qb bytes each) plus
         # w (read, and written by the update) and r; the exact column count is kept by the library
@@ -187,20 +191,21 @@ def main():
                 (tm["ortho_ms"], int(tm["ortho_q_launches"]), q_bytes),
             f"k_gcr_flush (x and the new directions from the direction store, mean {tm['ortho_z_cols'] / z_launches:.0f} columns)":
                 (tm["flush_ms"], int(tm["ortho_z_launches"]), z_bytes),
-            ("k_sweep_tiled_f32<1>" if fused else "k_spmv_tiled_f32<1>" if tiled else "k_spmv_sc_f32")
-            + " (displacement block sweeps: one FP32 ratio per node pair"
+            ("k_sweep_tiled_h<1>" if fp16 else "k_sweep_tiled_f32<1>" if fused else "k_spmv_tiled_f32<1>" if tiled else "k_spmv_sc_f32")
+            + f" (displacement block sweeps: one {'FP16' if fp16 else 'FP32'} ratio per node pair"
             + (", neighbour vector entries staged in LDS" if tiled else "") + (", fused with the Chebyshev update" if fused else "")
             + "; avg from sampled HIP events)":
                 (sc_avg * sc_launches, int(sc_launches), sc_bytes),
-            ("k_sweep_tiled_f32<3>" if fused else "k_spmv_tiled_f32<3>" if tiled else "k_spmv_db_f32")
-            + " (fluid velocity block sweeps, FP32 component-diagonal node blocks" + (", fused with the Chebyshev update" if fused else "")
+            ("k_sweep_tiled_h<3>" if fp16 else "k_sweep_tiled_f32<3>" if fused else "k_spmv_tiled_f32<3>" if tiled else "k_spmv_db_f32")
+            + f" (fluid velocity block sweeps, {'FP16' if fp16 else 'FP32'} component-diagonal node blocks" + (", fused with the Chebyshev update" if fused else "")
             + "; avg from sampled HIP events)":
                 (db_avg * db_launches, int(db_launches), dbf_bytes),
-            (("k_sweep_sb_b3<0> (solid velocity block, fine level: FP32 3x3 block-CSR product fused with the Chebyshev update; avg from sampled HIP events)"
+            ((("k_sweep_sb_h (solid velocity block, fine level: 3x3 block-CSR with FP16 values in 24-byte records, product fused with the Chebyshev update; avg from sampled HIP events)"
+               if fp16 else "k_sweep_sb_b3<0> (solid velocity block, fine level: FP32 3x3 block-CSR product fused with the Chebyshev update; avg from sampled HIP events)")
               if solid_fused else "k_spmv_sb (solid velocity block, FP32 3x3 block-CSR, Chebyshev sweeps; avg from sampled HIP events)")
              if solid_fp32 else "k_spmv<1> (solid velocity block, CSR f64, Chebyshev sweeps; avg from sampled HIP events)"):
                 (ss_avg * sweeps, int(sweeps),
-                 (tm["solid_nnz"] * 4.0 + tm["solid_nnz"] / 9 * 4.0 + tm["solid_rows"] * 8.0 + (tm["solid_rows"] / 3 + 1) * 8.0
+                 (tm["solid_nnz"] / 9 * (24.0 if fp16 and solid_fused else 40.0) + tm["solid_rows"] * 8.0 + (tm["solid_rows"] / 3 + 1) * 8.0
                   + (tm["solid_rows"] / 3 * (5 * 16.0 + 48.0) if solid_fused else 0.0)) if solid_fp32
                  else (tm["solid_nnz"] * 12.0 + tm["solid_rows"] * 16.0 + (tm["solid_rows"] + 1) * 8.0)),
             "Schur-complement sweep (explicit two-ring pressure matrix: product + Chebyshev update; avg from sampled HIP events)":
@@ -238,6 +243,7 @@ def main():
                   "k_spmv_node6": ["k_spmv_node6<", "k_spmv<0,"], "k_spmv_compact": ["k_spmv_compact", "k_spmv<0,"],
                   "k_spmv_tiled_f32<1>": ["k_spmv_tiled_f32<1>"], "k_spmv_tiled_f32<3>": ["k_spmv_tiled_f32<3>"],
                   "k_sweep_tiled_f32<1>": ["k_sweep_tiled_f32<1>"], "k_sweep_tiled_f32<3>": ["k_sweep_tiled_f32<3>"],
+                  "k_sweep_tiled_h<1>": ["k_sweep_tiled_h<1>"], "k_sweep_tiled_h<3>": ["k_sweep_tiled_h<3>"], "k_sweep_sb_h": ["k_sweep_sb_h"],
                   "k_sweep_sb_b3<0>": ["k_sweep_sb_b3<0>"], "Schur": ["k_sweep_csr_mixed", "k_sweep_csr_f32", "k_spmv<2,"],
                   "k_residual": ["k_residual"], "k_jacobian": ["k_jacobian<2>"]}
         if pmc.exists():

@@ -9,5 +9,5 @@ for f in sys.argv[1:]:
     print(f"{f}: {d['value']:.3f} it/s {d['ms_per_step']:.1f} ms/step N{d['newton_iterations']} K{d['krylov_iterations']} "
           f"prec {ph['precond_ms']:.0f} spmv {ph['spmv_ms']:.0f} ortho {ph['ortho_ms']:.0f}")
     for k, v in d["kernels"].items():
-        if any(t in k for t in ("tiled", "Schur", "sb_b3", "node6")):
+        if any(t in k for t in ("tiled", "Schur", "sb_b3", "sb_h", "node6")):
             print(f"     {k[:34]:34s} {v['avg_launch_ms'] * 1e3:8.1f} us x {v['launches']:6d} = {v['gpu_ms']:7.1f} ms  {v['achieved_GBps']:6.0f} GB/s")

@@ -711,6 +711,188 @@ void launch_sweep_tiled_f32(hipStream_t st, int nv, int64_t N2, int max_nu, cons
   else
     hipLaunchKernelGGL(k_sweep_tiled_f32<3>, dim3(tiles), dim3(th), lds, st, N2, nadj_ptr, vals, ploc, tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
 }
+// ---- FP16 matrix values for the fine-level sweeps ---------------------------------------------------------------------
+// The sweeps are a fixed polynomial in a matrix that only has to resemble the block it preconditions; rounding its VALUES
+// to FP16 (11 bits; Jacobi-scaled ratios and row-equilibrated entries, |.| <= 1) changes the preconditioner by 5e-4 of
+// itself - nothing the outer iteration can see - while every vector stays FP32 / FP64.  What it buys is the record: value
+// and 16-bit local column index of a node pair in ONE 4-byte load (NV = 1; 6 bytes and two loads before), three values and
+// the index in ONE 8-byte load (NV = 3; 14 bytes and four loads), a 3x3 solid block and its column in three 8-byte loads
+// (24 bytes; 40 bytes and ten loads).  Fewer bytes and, what paces these kernels as much, fewer memory instructions.
+__device__ inline float h2f(uint32_t bits16) { return (float)__builtin_bit_cast(_Float16, (unsigned short)bits16); }
+__device__ inline uint32_t f2h(float v) { return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)v); }
+__global__ void k_pack_h1(int64_t n, const float* __restrict__ v, const uint16_t* __restrict__ loc, uint32_t* __restrict__ rec) {
+  GS(e, n) rec[e] = f2h(v[e]) | ((uint32_t)loc[e] << 16);
+}
+__global__ void k_pack_h3(int64_t n, const float* __restrict__ v, const uint16_t* __restrict__ loc, uint2* __restrict__ rec) {
+  GS(e, n) rec[e] = make_uint2(f2h(v[3 * e]) | (f2h(v[3 * e + 1]) << 16), f2h(v[3 * e + 2]) | ((uint32_t)loc[e] << 16));
+}
+// rec[3 b + 0..2]: (a0 a1 | a2 a3), (a4 a5 | a6 a7), (a8 0 | column)
+__global__ void k_pack_sb(int64_t nb, const float* __restrict__ v, const int32_t* __restrict__ col, uint2* __restrict__ rec) {
+  GS(b, nb) {
+    const float* a = v + 9 * b;
+    rec[3 * b] = make_uint2(f2h(a[0]) | (f2h(a[1]) << 16), f2h(a[2]) | (f2h(a[3]) << 16));
+    rec[3 * b + 1] = make_uint2(f2h(a[4]) | (f2h(a[5]) << 16), f2h(a[6]) | (f2h(a[7]) << 16));
+    rec[3 * b + 2] = make_uint2(f2h(a[8]), (uint32_t)col[b]);
+  }
+}
+void launch_pack_h1(hipStream_t st, int64_t n, const float* v, const uint16_t* loc, uint32_t* rec) {
+  hipLaunchKernelGGL(k_pack_h1, dim3(gridn(n)), dim3(256), 0, st, n, v, loc, rec);
+}
+void launch_pack_h3(hipStream_t st, int64_t n, const float* v, const uint16_t* loc, void* rec) {
+  hipLaunchKernelGGL(k_pack_h3, dim3(gridn(n)), dim3(256), 0, st, n, v, loc, static_cast<uint2*>(rec));
+}
+void launch_pack_sb(hipStream_t st, int64_t nb, const float* v, const int32_t* col, void* rec) {
+  hipLaunchKernelGGL(k_pack_sb, dim3(gridn(nb)), dim3(256), 0, st, nb, v, col, static_cast<uint2*>(rec));
+}
+template <int NV> struct TileRec;
+template <> struct TileRec<1> { using type = uint32_t; };
+template <> struct TileRec<3> { using type = uint2; };
+// k_sweep_tiled_f32 on the packed records
+template <int NV>
+__global__ __launch_bounds__(1024) void k_sweep_tiled_h(int64_t N2, const int64_t* __restrict__ nadj_ptr,
+                                                        const typename TileRec<NV>::type* __restrict__ rec,
+                                                        const int64_t* __restrict__ tile_uptr, const int32_t* __restrict__ ulist,
+                                                        const uint8_t* __restrict__ rowflag, const float* __restrict__ dinv,
+                                                        float c1, float c2, const float* __restrict__ din, float* __restrict__ dout,
+                                                        float* __restrict__ x, float* __restrict__ r) {
+  using Rec = typename TileRec<NV>::type;
+  extern __shared__ __attribute__((aligned(16))) float4 sx[];
+  __shared__ __attribute__((aligned(16))) int64_t sptr[TILE_NODES + 2];
+  __shared__ __attribute__((aligned(16))) float4 ssum[TILE_NODES];
+  const int64_t tile = blockIdx.x;
+  const int64_t u0 = tile_uptr[tile], nu = tile_uptr[tile + 1] - u0;
+  const float4* d4 = reinterpret_cast<const float4*>(din);
+  const int64_t r0 = tile * TILE_NODES;
+  const int nrows = (int)((r0 + TILE_NODES < N2 ? r0 + TILE_NODES : N2) - r0);
+  const int nth = blockDim.x, ngrp = nth >> 4;
+  for (int64_t i = threadIdx.x; i < nu; i += 4 * nth) {        // index -> entry is a dependent pair of loads: four pairs in flight
+    const int64_t i1 = i + nth, i2 = i + 2 * nth, i3 = i + 3 * nth;
+    const int32_t k0 = ulist[u0 + i], k1 = i1 < nu ? ulist[u0 + i1] : 0, k2 = i2 < nu ? ulist[u0 + i2] : 0, k3 = i3 < nu ? ulist[u0 + i3] : 0;
+    const float4 v0 = d4[k0], v1 = d4[k1], v2 = d4[k2], v3 = d4[k3];
+    sx[i] = v0;
+    if (i1 < nu) sx[i1] = v1;
+    if (i2 < nu) sx[i2] = v2;
+    if (i3 < nu) sx[i3] = v3;
+  }
+  for (int i = threadIdx.x; i <= nrows; i += nth) sptr[i] = nadj_ptr[r0 + i];
+  __syncthreads();
+  const int sub = threadIdx.x & 15, g = threadIdx.x >> 4;
+  constexpr int KS = 4;
+  Rec cr[KS], nr[KS];
+  auto zero = [](Rec& q) { if constexpr (NV == 1) q = 0u; else q = make_uint2(0u, 0u); };
+  auto prefetch = [&](int i, Rec (&q)[KS]) {
+    const int64_t e0 = sptr[i], e1 = sptr[i + 1];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int64_t e = e0 + sub + 16 * k;
+      if (e < e1) q[k] = rec[e]; else zero(q[k]);               // a zero record: value +0, local index 0
+    }
+  };
+  auto fma3 = [&](const Rec q, float& s0, float& s1, float& s2) {
+    if constexpr (NV == 1) {
+      const float c = h2f(q & 0xffffu);
+      const float4 xv = sx[q >> 16];
+      s0 += c * xv.x; s1 += c * xv.y; s2 += c * xv.z;
+    } else {
+      const float4 xv = sx[q.y >> 16];
+      s0 += h2f(q.x & 0xffffu) * xv.x; s1 += h2f(q.x >> 16) * xv.y; s2 += h2f(q.y & 0xffffu) * xv.z;
+    }
+  };
+  int i = g;
+  if (i < nrows) prefetch(i, cr);
+  while (i < nrows) {
+    const int ni = i + ngrp;
+    if (ni < nrows) prefetch(ni, nr);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    fma3(cr[0], s0, s1, s2);
+    fma3(cr[1], s0, s1, s2);
+    const int len = (int)(sptr[i + 1] - sptr[i]);
+    if (__builtin_amdgcn_ballot_w64(len > 32) != 0) { fma3(cr[2], s0, s1, s2); fma3(cr[3], s0, s1, s2); }
+    for (int64_t e = sptr[i] + sub + 16 * KS; e < sptr[i + 1]; e += 16) fma3(rec[e], s0, s1, s2);      // more than 64 pairs
+    for (int off = 8; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
+    }
+    if (sub == 0) ssum[i] = make_float4(s0, s1, s2, 0.f);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) cr[k] = nr[k];
+    i = ni;
+  }
+  __syncthreads();
+  const float* sflat = reinterpret_cast<const float*>(ssum);
+  for (int idx = threadIdx.x; idx < 4 * nrows; idx += nth) {
+    const int64_t gi = 4 * r0 + idx;
+    const int comp = idx & 3;
+    const float di = din[gi];
+    float t = sflat[idx];
+    if (rowflag && comp < 3 && rowflag[3 * (r0 + (idx >> 2)) + comp]) t = di;
+    const float ri = r[gi] - t;
+    x[gi] += di;
+    r[gi] = ri;
+    dout[gi] = comp < 3 ? c1 * di + c2 * ri * (dinv ? dinv[gi] : 1.f) : 0.f;
+  }
+}
+void launch_sweep_tiled_h(hipStream_t st, int nv, int64_t N2, int max_nu, const int64_t* nadj_ptr, const void* rec,
+                          const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag, const float* dinv, float c1,
+                          float c2, const float* din, float* dout, float* x, float* r) {
+  static const int threads = getenv("FSI_TILE_THREADS") ? atoi(getenv("FSI_TILE_THREADS")) : 512;
+  const int th = threads >= 1024 ? 1024 : (threads >= 512 ? 512 : 256);
+  const unsigned tiles = (unsigned)((N2 + TILE_NODES - 1) / TILE_NODES);
+  const size_t lds = (size_t)max_nu * sizeof(float4);
+  if (nv == 1)
+    hipLaunchKernelGGL(k_sweep_tiled_h<1>, dim3(tiles), dim3(th), lds, st, N2, nadj_ptr, static_cast<const uint32_t*>(rec), tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
+  else
+    hipLaunchKernelGGL(k_sweep_tiled_h<3>, dim3(tiles), dim3(th), lds, st, N2, nadj_ptr, static_cast<const uint2*>(rec), tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
+}
+// k_sweep_sb_b3<0> on the packed 24-byte block records
+__global__ __launch_bounds__(256) void k_sweep_sb_h(int64_t nS, const int64_t* __restrict__ sb_ptr, const uint2* __restrict__ rec,
+                                                    const float* __restrict__ binv12, float c1, float c2,
+                                                    const float* __restrict__ din, float* __restrict__ dout,
+                                                    float* __restrict__ x, float* __restrict__ r) {
+  const int sub = threadIdx.x & 15;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t i = grp; i < nS; i += ngrp) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    const int64_t bend = sb_ptr[i + 1];
+    for (int64_t b = sb_ptr[i] + sub; b < bend; b += 32) {
+      const bool p1 = b + 16 < bend;
+      const int64_t b1 = p1 ? b + 16 : b;
+      const uint2 a0 = rec[3 * b], a1 = rec[3 * b + 1], a2 = rec[3 * b + 2];
+      const uint2 q0 = rec[3 * b1], q1 = rec[3 * b1 + 1], q2 = rec[3 * b1 + 2];
+      const float4 xv = reinterpret_cast<const float4*>(din)[a2.y];
+      float4 yv = reinterpret_cast<const float4*>(din)[q2.y];
+      if (!p1) yv = make_float4(0.f, 0.f, 0.f, 0.f);
+      s0 += (h2f(a0.x & 0xffffu) * xv.x + h2f(a0.x >> 16) * xv.y + h2f(a0.y & 0xffffu) * xv.z) +
+            (h2f(q0.x & 0xffffu) * yv.x + h2f(q0.x >> 16) * yv.y + h2f(q0.y & 0xffffu) * yv.z);
+      s1 += (h2f(a0.y >> 16) * xv.x + h2f(a1.x & 0xffffu) * xv.y + h2f(a1.x >> 16) * xv.z) +
+            (h2f(q0.y >> 16) * yv.x + h2f(q1.x & 0xffffu) * yv.y + h2f(q1.x >> 16) * yv.z);
+      s2 += (h2f(a1.y & 0xffffu) * xv.x + h2f(a1.y >> 16) * xv.y + h2f(a2.x & 0xffffu) * xv.z) +
+            (h2f(q1.y & 0xffffu) * yv.x + h2f(q1.y >> 16) * yv.y + h2f(q2.x & 0xffffu) * yv.z);
+    }
+    for (int off = 8; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
+    }
+    float rc = 0.f, dc = 0.f;
+    if (sub < 3) {
+      dc = din[4 * i + sub];
+      rc = r[4 * i + sub] - (sub == 0 ? s0 : (sub == 1 ? s1 : s2));
+    }
+    const float r0 = __shfl(rc, 0, 16), r1 = __shfl(rc, 1, 16), r2 = __shfl(rc, 2, 16);
+    if (sub < 3) {
+      const float4 brow = reinterpret_cast<const float4*>(binv12 + 12 * i)[sub];
+      x[4 * i + sub] += dc;
+      r[4 * i + sub] = rc;
+      dout[4 * i + sub] = c1 * dc + c2 * (brow.x * r0 + brow.y * r1 + brow.z * r2);
+    }
+  }
+}
+void launch_sweep_sb_h(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const void* rec, const float* binv12, float c1, float c2,
+                       const float* din, float* dout, float* x, float* r) {
+  int64_t blocks = (nS + 15) / 16;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_sweep_sb_h, dim3((unsigned)blocks), dim3(256), 0, st, nS, sb_ptr, static_cast<const uint2*>(rec), binv12, c1, c2, din, dout, x, r);
+}
+
 // The same fused sweep without tiles (coarse level of the displacement block: the vertex graph, L2-resident)
 __global__ __launch_bounds__(256) void k_sweep_sc_f32(int64_t N2, const int64_t* __restrict__ nadj_ptr,
                                                       const int32_t* __restrict__ nadj, const float* __restrict__ chat,

@@ -270,8 +270,12 @@ void cheb_db_f32(FsiCtx* ctx, const float* db, const float* dinv, const double* 
       const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->db_ev0[0] && ctx->db_samples_pending < 8;
       if (timed) (void)hipEventRecord(ctx->db_ev0[ctx->db_samples_pending], st);
       const double rn = 1.0 / (2.0 * sig - rho);
-      launch_sweep_tiled_f32(st, 3, ctx->N2, ctx->tile_max_nu, ctx->nadj_ptr.p, db, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
-                             nullptr, dinv, (float)(rn * rho), (float)(2.0 * rn / de), da, db_, fx, fr);
+      if (ctx->sweeps_fp16 && db == ctx->vv_db32.p)
+        launch_sweep_tiled_h(st, 3, ctx->N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->vv_rec.p, ctx->tile_uptr.p, ctx->tile_ulist.p, nullptr,
+                             dinv, (float)(rn * rho), (float)(2.0 * rn / de), da, db_, fx, fr);
+      else
+        launch_sweep_tiled_f32(st, 3, ctx->N2, ctx->tile_max_nu, ctx->nadj_ptr.p, db, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
+                               nullptr, dinv, (float)(rn * rho), (float)(2.0 * rn / de), da, db_, fx, fr);
       if (timed) { (void)hipEventRecord(ctx->db_ev1[ctx->db_samples_pending], st); ctx->db_samples_pending += 1; }
       std::swap(da, db_);
       rho = rn;
@@ -328,7 +332,10 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         auto sweep = [&](float c1, float c2, int sample) {
           const bool timed = ctx->sample_budget > 0 && sample >= 0 && sample < 8 && ctx->ss_ev0[0];
           if (timed) (void)hipEventRecord(ctx->ss_ev0[sample], st);
-          launch_sweep_sb_b3(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_col.p, ctx->sb_vals.p, ctx->sb_binv12.p, c1, c2, dcur, dnext, fx, fr);
+          if (ctx->sweeps_fp16 && ctx->sb_rec.p)
+            launch_sweep_sb_h(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_rec.p, ctx->sb_binv12.p, c1, c2, dcur, dnext, fx, fr);
+          else
+            launch_sweep_sb_b3(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_col.p, ctx->sb_vals.p, ctx->sb_binv12.p, c1, c2, dcur, dnext, fx, fr);
           if (timed) (void)hipEventRecord(ctx->ss_ev1[sample], st);
           std::swap(dcur, dnext);
         };
@@ -503,8 +510,12 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         }
         const bool timed = ctx->sample_budget > 0 && k_sample >= 0 && k_sample < 4 && ctx->sc_ev0[0];
         if (timed) (void)hipEventRecord(ctx->sc_ev0[k_sample], st);
-        launch_sweep_tiled_f32(st, 1, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_chat.p, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
+        if (ctx->sweeps_fp16)
+          launch_sweep_tiled_h(st, 1, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_rec.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
                                ctx->dd_rowflag.p, nullptr, c1, c2, dcur, dnext, fx, fr);
+        else
+          launch_sweep_tiled_f32(st, 1, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_chat.p, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
+                                 ctx->dd_rowflag.p, nullptr, c1, c2, dcur, dnext, fx, fr);
         if (timed) { (void)hipEventRecord(ctx->sc_ev1[k_sample], st); ctx->sc_samples_pending = k_sample + 1; }
         std::swap(dcur, dnext);
       };
@@ -1119,11 +1130,20 @@ int refresh_preconditioner(FsiCtx* ctx) {
       }
       launch_to_f32(st, 3 * npairs, ctx->dd_db.p, ctx->dd_db32.p);
       launch_to_f32(st, 3 * npairs, ctx->vv_db.p, ctx->vv_db32.p);
+      if (ctx->sweeps_fp16 && ctx->tiled) {      // packed FP16 records of the two tiled operators (see k_pack_h1 / k_pack_h3)
+        if (!ctx->dd_rec.p) { HIPCHK(ctx->dd_rec.alloc(npairs)); HIPCHK(ctx->vv_rec.alloc(2 * npairs)); }
+        launch_pack_h1(st, npairs, ctx->dd_chat.p, ctx->tile_ploc.p, ctx->dd_rec.p);
+        launch_pack_h3(st, npairs, ctx->vv_db32.p, ctx->tile_ploc.p, ctx->vv_rec.p);
+      }
       launch_dinv_f32(st, ctx->N2, nullptr, ctx->diagpos3.p, ctx->Mdd.vals.p, ctx->dd_dinv32.p);
       launch_dinv_f32(st, ctx->N2, ctx->mask_f.p, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->vvf_dinv32.p);
     }
     launch_gather_vals(st, (int64_t)ctx->ss_vals.n, ctx->ss_src.p, ctx->Mvv.vals.p, ctx->ss_vals.p);
     launch_sb_gather(st, ctx->sb_nblocks, ctx->sb_row.p, ctx->sb_src.p, ctx->sb_stride.p, ctx->Mvv.vals.p, ctx->sb_vals.p);
+    if (ctx->sweeps_fp16 && ctx->solid_fp32 && ctx->sb_nblocks > 0) {
+      if (!ctx->sb_rec.p) HIPCHK(ctx->sb_rec.alloc(6 * ctx->sb_nblocks));
+      launch_pack_sb(st, ctx->sb_nblocks, ctx->sb_vals.p, ctx->sb_col.p, ctx->sb_rec.p);
+    }
     launch_sb_dinv(st, ctx->nS, ctx->snode.p, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->sb_dinv.p);
     launch_sb_binv(st, ctx->nS, ctx->snode.p, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->sb_binv12.p, ctx->sb_binv9.p);
     ctx->sbmg_ready = false;
@@ -1314,7 +1334,7 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->sb_ptr.release(); ctx->sb_src.release(); ctx->sb_vals.release(); ctx->sb_dinv.release();
   ctx->sb_binv12.release(); ctx->sb_binv9.release();
   ctx->dd_db32.release(); ctx->vv_db32.release(); ctx->dd_dinv32.release(); ctx->vvf_dinv32.release();
-  ctx->dd_chat.release(); ctx->ones32.release(); ctx->dd_rowflag.release();
+  ctx->dd_chat.release(); ctx->ones32.release(); ctx->dd_rowflag.release(); ctx->dd_rec.release(); ctx->vv_rec.release(); ctx->sb_rec.release();
   ctx->tile_ploc.release(); ctx->tile_uptr.release(); ctx->tile_ulist.release();
   for (auto* b : {&ctx->ss_rowptr, &ctx->ss_diagpos, &ctx->ss_src}) b->release();
   for (auto* b : {&ctx->node_solid, &ctx->vrank, &ctx->cols3, &ctx->cols_vp, &ctx->cols_pv, &ctx->cols_pp}) b->release();
@@ -2026,6 +2046,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   }
   ctx->debug_gcr = getenv("FSI_DEBUG_GCR") != nullptr;
   ctx->fused_sweeps = !(getenv("FSI_FUSED_SWEEPS") && atoi(getenv("FSI_FUSED_SWEEPS")) == 0);
+  ctx->sweeps_fp16 = ctx->fused_sweeps && !(getenv("FSI_SWEEPS_FP16") && atoi(getenv("FSI_SWEEPS_FP16")) == 0);
   ctx->debug_prec_apply = (getenv("FSI_DEBUG_PRECOND") && atoi(getenv("FSI_DEBUG_PRECOND")) >= 2) ? 12 : 0;
   if (getenv("FSI_NEWTON_FORCING")) ctx->newton_forcing = atof(getenv("FSI_NEWTON_FORCING"));
   if (getenv("FSI_GCR_REORTH")) ctx->gcr_reorth = atof(getenv("FSI_GCR_REORTH"));

@@ -264,6 +264,8 @@ struct FsiCtx {
   bool op32_ok = false; int op32_policy = 1; int64_t op32_products = 0;
   bool gcr_stagnated = false;                // the last cycle ended on 40 iterations without a 10 % gain
   int debug_prec_apply = 0;
+  bool sweeps_fp16 = true;                   // FSI_SWEEPS_FP16=0: FP32 matrix values in the fine-level sweeps (k_sweep_tiled_f32 / k_sweep_sb_b3)
+  fsi::DevBuf<uint32_t> dd_rec, vv_rec, sb_rec;   // packed FP16 records: [pairs], [pairs][2], [blocks][6] 32-bit words
   bool fused_sweeps = true;                  // FSI_FUSED_SWEEPS=0: product and Chebyshev update of the FP32 sweeps as two launches
 
   double tol_hint = 0.0, bnorm_max = 0.0;     // fsi_newton_solve -> solve_gcr: lowest linear tolerance to expect; largest |b| seen

@@ -138,6 +138,14 @@ void launch_extract_chat(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, co
 void launch_sweep_tiled_f32(hipStream_t st, int nv, int64_t N2, int max_nu, const int64_t* nadj_ptr, const float* vals,
                             const uint16_t* ploc, const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag,
                             const float* dinv, float c1, float c2, const float* din, float* dout, float* x, float* r);
+void launch_pack_h1(hipStream_t st, int64_t n, const float* v, const uint16_t* loc, uint32_t* rec);
+void launch_pack_h3(hipStream_t st, int64_t n, const float* v, const uint16_t* loc, void* rec);
+void launch_pack_sb(hipStream_t st, int64_t nb, const float* v, const int32_t* col, void* rec);
+void launch_sweep_tiled_h(hipStream_t st, int nv, int64_t N2, int max_nu, const int64_t* nadj_ptr, const void* rec,
+                          const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag, const float* dinv, float c1,
+                          float c2, const float* din, float* dout, float* x, float* r);
+void launch_sweep_sb_h(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const void* rec, const float* binv12, float c1, float c2,
+                       const float* din, float* dout, float* x, float* r);
 void launch_sweep_sc_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const float* chat,
                          const uint8_t* rowflag, float c1, float c2, const float* din, float* dout, float* x, float* r);
 void launch_spmv_sc_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const float* chat,
