@@ -410,9 +410,7 @@ __global__ __launch_bounds__(256) void k_spmv_db(int64_t N2, const int64_t* __re
       const double* c = db + 3 * e;
       s0 += c[0] * xs[0]; s1 += c[1] * xs[1]; s2 += c[2] * xs[2];
     }
-    for (int off = 8; off > 0; off >>= 1) {
-      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
-    }
+    s0 = group_sum<16>(s0); s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
     if (sub == 0) { y[3 * r] = s0; y[3 * r + 1] = s1; y[3 * r + 2] = s2; }
   }
 }
@@ -430,9 +428,7 @@ __global__ __launch_bounds__(256) void k_spmv_db_f32(int64_t N2, const int64_t* 
       const float* c = db + 3 * e;
       s0 += c[0] * xv.x; s1 += c[1] * xv.y; s2 += c[2] * xv.z;
     }
-    for (int off = 8; off > 0; off >>= 1) {
-      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
-    }
+    s0 = group_sum<16>(s0); s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
     if (sub == 0) reinterpret_cast<float4*>(y)[r] = make_float4(s0, s1, s2, 0.f);
   }
 }
@@ -499,9 +495,7 @@ __global__ __launch_bounds__(256) void k_spmv_sc_f32(int64_t N2, const int64_t* 
       const float c = chat[e];
       s0 += c * xv.x; s1 += c * xv.y; s2 += c * xv.z;
     }
-    for (int off = 8; off > 0; off >>= 1) {
-      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
-    }
+    s0 = group_sum<16>(s0); s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
     if (sub == 0) {
       const float4 xr = reinterpret_cast<const float4*>(x)[r];
       reinterpret_cast<float4*>(y)[r] = make_float4(rowflag[3 * r] ? xr.x : s0, rowflag[3 * r + 1] ? xr.y : s1,
@@ -565,9 +559,7 @@ __global__ __launch_bounds__(256) void k_spmv_tiled_f32(int64_t N2, const int64_
       if (NV == 1) { const float c = vals[e]; s0 += c * xv.x; s1 += c * xv.y; s2 += c * xv.z; }
       else { const float* c = vals + NV * e; s0 += c[0] * xv.x; s1 += c[NV > 1 ? 1 : 0] * xv.y; s2 += c[NV > 2 ? 2 : 0] * xv.z; }
     }
-    for (int off = 8; off > 0; off >>= 1) {
-      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
-    }
+    s0 = group_sum<16>(s0); s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
     if (sub == 0) {
       const int64_t r = r0 + i;
       if (rowflag) {
@@ -667,9 +659,7 @@ __global__ __launch_bounds__(1024) void k_sweep_tiled_f32(int64_t N2, const int6
       if (NV == 1) { const float c = vals[e]; s0 += c * xv.x; s1 += c * xv.y; s2 += c * xv.z; }
       else { const float* c = vals + NV * e; s0 += c[0] * xv.x; s1 += c[NV > 1 ? 1 : 0] * xv.y; s2 += c[NV > 2 ? 2 : 0] * xv.z; }
     }
-    for (int off = 8; off > 0; off >>= 1) {
-      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
-    }
+    s0 = group_sum<16>(s0); s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
     if (sub == 0) ssum[i] = make_float4(s0, s1, s2, 0.f);
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
@@ -809,9 +799,7 @@ __global__ __launch_bounds__(1024) void k_sweep_tiled_h(int64_t N2, const int64_
     const int len = (int)(sptr[i + 1] - sptr[i]);
     if (__builtin_amdgcn_ballot_w64(len > 32) != 0) { fma3(cr[2], s0, s1, s2); fma3(cr[3], s0, s1, s2); }
     for (int64_t e = sptr[i] + sub + 16 * KS; e < sptr[i + 1]; e += 16) fma3(rec[e], s0, s1, s2);      // more than 64 pairs
-    for (int off = 8; off > 0; off >>= 1) {
-      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
-    }
+    s0 = group_sum<16>(s0); s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
     if (sub == 0) ssum[i] = make_float4(s0, s1, s2, 0.f);
 #pragma unroll
     for (int k = 0; k < KS; ++k) cr[k] = nr[k];
@@ -869,15 +857,13 @@ __global__ __launch_bounds__(256) void k_sweep_sb_h(int64_t nS, const int64_t* _
       s2 += (h2f(a1.y & 0xffffu) * xv.x + h2f(a1.y >> 16) * xv.y + h2f(a2.x & 0xffffu) * xv.z) +
             (h2f(q1.y & 0xffffu) * yv.x + h2f(q1.y >> 16) * yv.y + h2f(q2.x & 0xffffu) * yv.z);
     }
-    for (int off = 8; off > 0; off >>= 1) {
-      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
-    }
+    s0 = group_sum<16>(s0); s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
     float rc = 0.f, dc = 0.f;
     if (sub < 3) {
       dc = din[4 * i + sub];
       rc = r[4 * i + sub] - (sub == 0 ? s0 : (sub == 1 ? s1 : s2));
     }
-    const float r0 = __shfl(rc, 0, 16), r1 = __shfl(rc, 1, 16), r2 = __shfl(rc, 2, 16);
+    const float r0 = dpp_f<0x00>(rc), r1 = dpp_f<0x55>(rc), r2 = dpp_f<0xAA>(rc);      // lanes 0-2 of the row, seen from its first quad
     if (sub < 3) {
       const float4 brow = reinterpret_cast<const float4*>(binv12 + 12 * i)[sub];
       x[4 * i + sub] += dc;
@@ -922,9 +908,7 @@ __global__ __launch_bounds__(256) void k_sweep_sc_f32(int64_t N2, const int64_t*
       s1 += (a0 * x0.y + a1 * x1.y) + (a2 * x2.y + a3 * x3.y);
       s2 += (a0 * x0.z + a1 * x1.z) + (a2 * x2.z + a3 * x3.z);
     }
-    for (int off = 2; off > 0; off >>= 1) {
-      s0 += __shfl_xor(s0, off, 4); s1 += __shfl_xor(s1, off, 4); s2 += __shfl_xor(s2, off, 4);
-    }
+    s0 = group_sum<4>(s0); s1 = group_sum<4>(s1); s2 = group_sum<4>(s2);
     if (sub == 0) {
       const float4 dr = d4[row], xr = reinterpret_cast<const float4*>(x)[row];
       float4 rr = reinterpret_cast<const float4*>(r)[row];
@@ -1164,9 +1148,7 @@ __global__ __launch_bounds__(256) void k_spmv_sb(int64_t nS, const int64_t* __re
       s1 += a[3] * x0 + a[4] * x1 + a[5] * x2;
       s2 += a[6] * x0 + a[7] * x1 + a[8] * x2;
     }
-    for (int off = 8; off > 0; off >>= 1) {
-      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
-    }
+    s0 = group_sum<16>(s0); s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
     if (sub == 0) reinterpret_cast<float4*>(y)[i] = make_float4(s0, s1, s2, 0.f);
   }
 }
@@ -1414,7 +1396,7 @@ __global__ __launch_bounds__(256) void k_sweep_csr_f32(int64_t n, const int64_t*
   for (int64_t i = grp; i < n; i += ngrp) {
     float s = 0.f;
     for (int64_t e = rowptr[i] + sub; e < rowptr[i + 1]; e += 16) s += vals[e] * din[cols[e]];
-    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+    s = group_sum<16>(s);
     if (sub == 0) {
       const float di = din[i], ri = r[i] - s;
       x[i] += di;
@@ -1465,8 +1447,7 @@ __global__ __launch_bounds__(256) void k_sweep_csr_mixed(int64_t n, const int64_
         for (int j = 0; j < KS; ++j) s += (double)v[j] * dj[j];
       }
     }
-#pragma unroll
-    for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, LPR);
+s = group_sum<LPR>(s);
     if (sub == 0) ssum[g] = s;
     __syncthreads();
     if (threadIdx.x < RPB && base + threadIdx.x < n) {
@@ -1561,15 +1542,13 @@ __global__ __launch_bounds__(256) void k_sweep_sb_b3(int64_t nS, const int64_t* 
         s2 += a[6] * x0 + a[7] * x1 + a[8] * x2;
       }
     }
-    for (int off = 8; off > 0; off >>= 1) {
-      s0 += __shfl_xor(s0, off, 16); s1 += __shfl_xor(s1, off, 16); s2 += __shfl_xor(s2, off, 16);
-    }
+    s0 = group_sum<16>(s0); s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
     float rc = 0.f, dc = 0.f;
     if (sub < 3) {
       dc = din[4 * i + sub];
       rc = r[4 * i + sub] - (sub == 0 ? s0 : (sub == 1 ? s1 : s2));
     }
-    const float r0 = __shfl(rc, 0, 16), r1 = __shfl(rc, 1, 16), r2 = __shfl(rc, 2, 16);
+    const float r0 = dpp_f<0x00>(rc), r1 = dpp_f<0x55>(rc), r2 = dpp_f<0xAA>(rc);      // lanes 0-2 of the row, seen from its first quad
     if (sub < 3) {
       const float4 brow = reinterpret_cast<const float4*>(binv12 + 12 * i)[sub];
       x[4 * i + sub] += dc;
@@ -1671,7 +1650,7 @@ __global__ __launch_bounds__(256) void k_residual_rows(int64_t nrows, const int3
   for (int64_t i = grp; i < nrows; i += ngrp) {
     double s = 0.0;
     for (int64_t t = ptr[i] + sub; t < ptr[i + 1]; t += 16) s += vals[src[t]] * x[col[t]];
-    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+    s = group_sum<16>(s);
     if (sub == 0) { const int32_t r = rows[i]; y[r] = b[r] - s; }
   }
 }

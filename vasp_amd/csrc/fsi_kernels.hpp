@@ -3,6 +3,52 @@
 #include "fsi_context.hpp"
 
 namespace fsi {
+#if defined(__HIPCC__)
+// Sum over an aligned group of 4 / 8 / 16 lanes by DPP adds (quad permutes, then half-row and row mirrors): four VALU
+// instructions per value instead of four ds_bpermute round trips through the LDS crossbar, which is what __shfl_xor
+// compiles to and what paced the 16-lanes-per-row sweep kernels.  Every lane of the group ends up with the sum.
+template <int CTRL>
+__device__ inline float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ inline double dpp_d(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+template <int LANES>
+__device__ inline float group_sum(float v) {
+  v += dpp_f<0xB1>(v);                          // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);                          // quad_perm [2,3,0,1]
+  if (LANES >= 8) v += dpp_f<0x141>(v);         // row_half_mirror: the other quad of the half row (quads are uniform by now)
+  if (LANES >= 16) v += dpp_f<0x140>(v);        // row_mirror: the other half row
+  return v;
+}
+template <int LANES>
+__device__ inline double group_sum(double v) {
+  v += dpp_d<0xB1>(v);
+  v += dpp_d<0x4E>(v);
+  if (LANES >= 8) v += dpp_d<0x141>(v);
+  if (LANES >= 16) v += dpp_d<0x140>(v);
+  return v;
+}
+
+// Sum over the 64 lanes of a wave: the four row sums by DPP, then four lane reads.  The result is wave-uniform.
+__device__ inline double wave_sum_dpp(double v) {
+  v = group_sum<16>(v);
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  double t = 0.0;
+#pragma unroll
+  for (int l = 0; l < 64; l += 16) {
+    const int rl = __builtin_amdgcn_readlane(lo, l), rh = __builtin_amdgcn_readlane(hi, l);
+    t += __builtin_bit_cast(double, ((long long)rh << 32) | (long long)(unsigned int)rl);
+  }
+  return t;
+}
+#endif
 
 struct ElemArrays {
   const double* geom;          // [C][10]

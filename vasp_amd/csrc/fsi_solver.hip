@@ -25,10 +25,7 @@ __device__ inline void st_agent(double* p, double v) {
 __device__ inline unsigned long long ld_agent_bits(const double* p) {
   return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ inline double wave_sum(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+__device__ inline double wave_sum(double v) { return wave_sum_dpp(v); }      // DPP row sums + four lane reads, wave-uniform
 __device__ inline double wave_max(double v) {
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
   return v;
