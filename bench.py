@@ -240,7 +240,7 @@ def main():
         pmc = ROOT / "profiles" / "r02_pmc_traffic.json"
         groups = {"k_gcr_dots": [f"k_gcr_dots<{'double' if qb == 8 else 'float'}", f"k_gcr_axpy<{'double' if qb == 8 else 'float'}"],
                   "k_gcr_flush": ["k_gcr_flush<"],
-                  "k_spmv_node6": ["k_spmv_node6<", "k_spmv<0,"], "k_spmv_compact": ["k_spmv_compact", "k_spmv<0,"],
+                  "k_spmv_node6": ["k_spmv_node6<", "k_spmv_node6p<", "k_spmv<0,"], "k_spmv_compact": ["k_spmv_compact", "k_spmv<0,"],
                   "k_spmv_tiled_f32<1>": ["k_spmv_tiled_f32<1>"], "k_spmv_tiled_f32<3>": ["k_spmv_tiled_f32<3>"],
                   "k_sweep_tiled_f32<1>": ["k_sweep_tiled_f32<1>"], "k_sweep_tiled_f32<3>": ["k_sweep_tiled_f32<3>"],
                   "k_sweep_tiled_h<1>": ["k_sweep_tiled_h<1>"], "k_sweep_tiled_h<3>": ["k_sweep_tiled_h<3>"], "k_sweep_sb_h": ["k_sweep_sb_h"],

@@ -641,7 +641,8 @@ int spmv(FsiCtx* ctx, const double* x, double* y, bool working = false) {
   Phase ph(ctx, &ctx->t_spmv);
   if (working && ctx->op32_ok && ctx->kry_fp32) {
     ctx->op32_products += 1;
-    launch_spmv_node6_f32(ctx->stream, ctx->N2, ctx->V, ctx->rowptr.p, ctx->cols.p, ctx->A32.p, x, y);
+    launch_spmv_node6p(ctx->stream, ctx->N2, ctx->V, ctx->a32_ptr.p, ctx->a32_cols.p, ctx->A32.p, ctx->rowptr.p, ctx->cols.p,
+                       ctx->a32_ptail - ctx->a32_tail_src, x, y);
     return FSI_OK;
   }
   // FSI_SPMV_MONO=1: column-array-free variant (8.7 instead of 12 bytes per entry); measured SLOWER on MI355X (6.6 vs
@@ -831,36 +832,72 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
     std::vector<double> htot(m, 0.0);
     double wn = 0.0, wr = 0.0, w0 = 0.0;
     {
-      Phase ph(ctx, &ctx->t_ortho);
       // classical Gram-Schmidt; a second pass when the first one cancelled w by more than 1 / reorth.  With recycled
       // directions w = A M^-1 r lies mostly IN the kept space, so the usual 2x criterion fires on most iterations; the
       // orthogonality lost in one pass only matters relative to the tolerance asked for.
+      // The update kernel reads the coefficients from device memory, so in a single context it is queued right behind
+      // the product kernel and the host reads both results in one wait per pass (partitioned: the coefficients are
+      // all-reduced by the host in between).  The phase timer brackets the kernels only, not the host's wait.
+      double* hh_hot = hh + cap + 4;                 // second staging area of the pinned buffer (nh + 2 <= 34 values)
+      int nh = 0;
       if (f32) {
-        // exact (FP64) Gram-Schmidt against the window of this cycle's directions first
+        // exact (FP64) Gram-Schmidt against the window of this cycle's directions first;
         // columns [0, nh) of the window are in use (it fills from 0 and then turns into a ring)
-        int nh = 0;
         for (int k = 0; k < 32; ++k)
           if (ctx->hot_slots[k] >= 0) nh = k + 1;
         if (nh > 0) {
-          launch_gcr_dots(st, false, ctx->KQh.p, ctx->ldq, n, nh, w, nullptr, ctx->scratch.p, ctx->hcoef_hot.p);
-          FSICHK(gcr_read(ctx, ctx->hcoef_hot.p, nh + 2, hh));
-          if (ctx->part) {
-            FSICHK(allreduce(ctx, hh, nh + 2));
-            HIPCHK(hipMemcpyAsync(ctx->hcoef_hot.p, hh, (size_t)nh * sizeof(double), hipMemcpyHostToDevice, st));
+          {
+            Phase ph(ctx, &ctx->t_ortho);
+            launch_gcr_dots(st, false, ctx->KQh.p, ctx->ldq, n, nh, w, nullptr, ctx->scratch.p, ctx->hcoef_hot.p);
+            if (!ctx->part)
+              launch_gcr_axpy(st, false, ctx->KQh.p, ctx->ldq, n, nh, ctx->hcoef_hot.p, w, nullptr, ctx->scratch.p, ctx->gcr_out.p);
           }
-          w0 = std::sqrt(std::max(hh[nh], 0.0));
-          for (int k = 0; k < nh; ++k)
-            if (ctx->hot_slots[k] >= 0) htot[ctx->hot_slots[k]] += hh[k];
-          launch_gcr_axpy(st, false, ctx->KQh.p, ctx->ldq, n, nh, ctx->hcoef_hot.p, w, nullptr, ctx->scratch.p, ctx->gcr_out.p);
+          if (ctx->part) {
+            FSICHK(gcr_read(ctx, ctx->hcoef_hot.p, nh + 2, hh_hot));
+            FSICHK(allreduce(ctx, hh_hot, nh + 2));
+            HIPCHK(hipMemcpyAsync(ctx->hcoef_hot.p, hh_hot, (size_t)nh * sizeof(double), hipMemcpyHostToDevice, st));
+            Phase ph(ctx, &ctx->t_ortho);
+            launch_gcr_axpy(st, false, ctx->KQh.p, ctx->ldq, n, nh, ctx->hcoef_hot.p, w, nullptr, ctx->scratch.p, ctx->gcr_out.p);
+          } else {
+            // read with the first pass below (stream order: the copy sees the values before hcoef_hot is reused)
+            HIPCHK(hipMemcpyAsync(hh_hot, ctx->hcoef_hot.p, (size_t)(nh + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
+          }
           ctx->ortho_q_cols += 2 * (int64_t)nh * 2; ctx->ortho_q_launches += 2;      // FP64 columns counted as two FP32 ones
         }
       }
+      bool hot_pending = nh > 0;
       for (int pass = 0; pass < 2; ++pass) {
-        launch_gcr_dots(st, f32, ctx->KQ.p, ctx->ldq, n, m, w, nullptr, ctx->scratch.p, ctx->hcoef.p);
-        FSICHK(gcr_read(ctx, ctx->hcoef.p, m + 2, hh));
+        double h2[2] = {0.0, 0.0};
         if (ctx->part) {
+          {
+            Phase ph(ctx, &ctx->t_ortho);
+            launch_gcr_dots(st, f32, ctx->KQ.p, ctx->ldq, n, m, w, nullptr, ctx->scratch.p, ctx->hcoef.p);
+          }
+          FSICHK(gcr_read(ctx, ctx->hcoef.p, m + 2, hh));
           FSICHK(allreduce(ctx, hh, m + 2));
           HIPCHK(hipMemcpyAsync(ctx->hcoef.p, hh, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
+          {
+            Phase ph(ctx, &ctx->t_ortho);
+            launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, w, r, ctx->scratch.p, ctx->gcr_out.p);
+          }
+          FSICHK(gcr_read(ctx, ctx->gcr_out.p, 2, h2));
+          FSICHK(allreduce(ctx, h2, 2));
+        } else {
+          {
+            Phase ph(ctx, &ctx->t_ortho);
+            launch_gcr_dots(st, f32, ctx->KQ.p, ctx->ldq, n, m, w, nullptr, ctx->scratch.p, ctx->hcoef.p);
+            launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, w, r, ctx->scratch.p, ctx->gcr_out.p);
+          }
+          HIPCHK(hipMemcpyAsync(hh, ctx->hcoef.p, (size_t)(m + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
+          HIPCHK(hipMemcpyAsync(hh + m + 2, ctx->gcr_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+          HIPCHK(hipStreamSynchronize(st));
+          h2[0] = hh[m + 2]; h2[1] = hh[m + 3];
+        }
+        if (hot_pending) {                       // the window's coefficients (read by the wait above, or all-reduced before)
+          w0 = std::sqrt(std::max(hh_hot[nh], 0.0));
+          for (int k = 0; k < nh; ++k)
+            if (ctx->hot_slots[k] >= 0) htot[ctx->hot_slots[k]] += hh_hot[k];
+          hot_pending = false;
         }
         if (pass == 0 && w0 == 0.0) w0 = std::sqrt(std::max(hh[m], 0.0));
         for (int j = 0; j < m; ++j) htot[j] += hh[j];
@@ -874,12 +911,9 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
             if (a > 1e-12 * wref) ctx->dbg_sig12 += 1;
           }
         }
-        launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, w, r, ctx->scratch.p, ctx->gcr_out.p);
-        FSICHK(gcr_read(ctx, ctx->gcr_out.p, 2, hh));
-        FSICHK(allreduce(ctx, hh, 2));
         ctx->ortho_q_cols += 2 * (int64_t)m; ctx->ortho_q_launches += 2;
-        wn = std::sqrt(std::max(hh[0], 0.0));
-        wr = hh[1];
+        wn = std::sqrt(std::max(h2[0], 0.0));
+        wr = h2[1];
         if (wn > reorth * w0) break;
         w0 = wn;
       }
@@ -1305,7 +1339,7 @@ int fsi_destroy(FsiCtx* ctx) {
                            &ctx->tmp7, &ctx->scratch, &ctx->bc_vals, &ctx->pf_coef, &ctx->rb_val, &ctx->KZ, &ctx->hcoef,
                            &ctx->gcr_out, &ctx->gcr_y, &ctx->gcr_cn, &ctx->KQh, &ctx->hcoef_hot, &ctx->cA, &ctx->cP};
   for (auto* b : dbl) b->release();
-  ctx->KQ.release();
+  ctx->KQ.release(); ctx->A32.release(); ctx->a32_ptr.release(); ctx->a32_cols.release();
   ctx->gcr_slots.release();
   ctx->gv_idx.release();
   if (ctx->gcr_host) { (void)hipHostFree(ctx->gcr_host); ctx->gcr_host = nullptr; }
@@ -2041,7 +2075,20 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   ctx->kry_fp32 = ctx->kry_fp32_policy == 1;
   ctx->op32_policy = getenv("FSI_OPERATOR_FP32") ? atoi(getenv("FSI_OPERATOR_FP32")) : 1;
   if (ctx->op32_policy && ctx->kry_fp32_policy != 0) {
-    HIPCHK(ctx->A32.alloc(ctx->nnz));
+    // layout of the FP32 copy (see k_spmv_node6p): node blocks padded to multiples of four entries, pressure rows behind
+    std::vector<int64_t> rp(6 * (size_t)ctx->N2 + 2), p32((size_t)ctx->N2 + 1, 0);
+    HIPCHK(hipMemcpy(rp.data(), ctx->rowptr.p, rp.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < ctx->N2; ++r) {
+      const int64_t L = rp[6 * r + 1] - rp[6 * r];
+      p32[r + 1] = p32[r] + 6 * ((L + 3) & ~(int64_t)3);
+    }
+    ctx->a32_ptail = p32[ctx->N2];
+    ctx->a32_tail_src = rp[6 * (size_t)ctx->N2];
+    ctx->a32_tail_nnz = ctx->nnz - ctx->a32_tail_src;
+    FSICHK(upload(ctx, ctx->a32_ptr, p32));
+    HIPCHK(ctx->a32_cols.alloc((size_t)(ctx->a32_ptail / 6)));
+    launch_pad_cols32(ctx->stream, ctx->N2, ctx->rowptr.p, ctx->cols.p, ctx->a32_ptr.p, ctx->a32_cols.p);
+    HIPCHK(ctx->A32.alloc((size_t)(ctx->a32_ptail + ctx->a32_tail_nnz)));
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
   }
   ctx->debug_gcr = getenv("FSI_DEBUG_GCR") != nullptr;
@@ -2066,7 +2113,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   HIPCHK(ctx->gcr_y.alloc(cap));
   HIPCHK(ctx->gcr_cn.alloc((size_t)32 * cap));
   HIPCHK(ctx->gcr_slots.alloc(32));
-  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->gcr_host), (size_t)(cap + 16) * sizeof(double), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->gcr_host), (size_t)(cap + 64) * sizeof(double), hipHostMallocDefault));
   ctx->kry_born.assign(cap, -1);
   gcr_reset(ctx);
   HIPCHK(ctx->scratch.alloc(std::max<size_t>(8192, (size_t)(cap + 2) * 64 + 16)));
@@ -2292,7 +2339,8 @@ int fsi_assemble_jacobian(FsiCtx* ctx) {
   }
   ctx->op32_ok = false;
   if (ctx->op32_policy && ctx->kry_fp32_policy != 0 && ctx->precond == 0 && ctx->A32.p) {
-    launch_round_to_f32(ctx->stream, ctx->nnz, ctx->A.p, ctx->A32.p);       // rows are equilibrated: |entries| <= 1
+    launch_pad_vals32(ctx->stream, ctx->N2, ctx->V, ctx->rowptr.p, ctx->A.p, ctx->a32_ptr.p, ctx->a32_ptail, ctx->a32_tail_nnz,
+                      ctx->a32_tail_src, ctx->A32.p);       // rows are equilibrated: |entries| <= 1
     ctx->op32_ok = true;
   }
   gcr_reset(ctx);          // the recycled directions belong to the previous matrix

@@ -262,6 +262,9 @@ struct FsiCtx {
   bool gcr_arnoldi = false;                  // FSI_GCR_ARNOLDI=1: new directions from the latest q instead of the residual (measured: worse)
   fsi::DevBuf<float> A32;                         // FP32 copy of A for the products inside the Krylov iterations (FSI_OPERATOR_FP32, default on)
   bool op32_ok = false; int op32_policy = 1; int64_t op32_products = 0;
+  fsi::DevBuf<int64_t> a32_ptr;              // [N2 + 1] first entry of a node's padded block in A32 (k_spmv_node6p)
+  fsi::DevBuf<int32_t> a32_cols;             // padded index rows
+  int64_t a32_ptail = 0, a32_tail_src = 0, a32_tail_nnz = 0;     // pressure rows: behind the padded node blocks, unpadded
   bool gcr_stagnated = false;                // the last cycle ended on 40 iterations without a 10 % gain
   int debug_prec_apply = 0;
   bool sweeps_fp16 = true;                   // FSI_SWEEPS_FP16=0: FP32 matrix values in the fine-level sweeps (k_sweep_tiled_f32 / k_sweep_sb_b3)

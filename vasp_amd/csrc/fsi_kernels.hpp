@@ -111,6 +111,11 @@ void launch_add_at(hipStream_t st, double* vals, const int64_t* pos, const doubl
 enum SpmvTag : int { SPMV_MONOLITHIC = 0, SPMV_SOLID_BLOCK = 1, SPMV_FIELD_BLOCK = 2 };
 void launch_spmv_node6_f32(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const float* vals,
                            const double* x, double* y);
+void launch_pad_cols32(hipStream_t st, int64_t N2, const int64_t* rowptr, const int32_t* cols, const int64_t* p32, int32_t* cols32);
+void launch_pad_vals32(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const double* A, const int64_t* p32,
+                       int64_t ptail, int64_t nnz_tail, int64_t tail_src, float* A32);
+void launch_spmv_node6p(hipStream_t st, int64_t N2, int64_t V, const int64_t* p32, const int32_t* cols32, const float* vals,
+                        const int64_t* rowptr, const int32_t* cols, int64_t tail_shift, const double* x, double* y);
 void launch_round_to_f32(hipStream_t st, int64_t n, const double* a, float* b);
 void launch_spmv(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const double* vals,
                  const double* x, double* y, int tag = SPMV_FIELD_BLOCK);

@@ -385,6 +385,100 @@ void launch_spmv_node6_f32(hipStream_t st, int64_t N2, int64_t V, const int64_t*
                            const double* x, double* y) {
   spmv_node6_any<float>(st, N2, V, rowptr, cols, vals, x, y);
 }
+// ---- FP32 copy of the Jacobian in its own layout --------------------------------------------------------------------
+// The copy only serves k_spmv_node6p, so it is laid out for it: the six value rows of a node (and one row of column
+// indices) padded to a multiple of four entries and 16-byte aligned, p32[r] = first entry of node r's block in units of
+// ENTRIES (block = 6 Lp values; the index row has Lp entries at p32[r] / 6).  One float4 / int4 load per lane then covers
+// 256 entries: the ~170 entries of a P2 edge node take ONE round of 6 + 1 loads and 4 gathers per lane instead of three
+// rounds of 6 + 1 + 1 - the FP32 product was paced by its memory instructions, not by its 7.5 GB.  Padding entries carry
+// value 0 and column 0.  The pressure rows follow unpadded (k_spmv on them as before).
+__global__ __launch_bounds__(256) void k_pad_cols32(int64_t N2, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                    const int64_t* __restrict__ p32, int32_t* __restrict__ cols32) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < N2; r += nwaves) {
+    const int64_t s0 = rowptr[6 * r], L = rowptr[6 * r + 1] - s0, Lp = (L + 3) & ~(int64_t)3, o = p32[r] / 6;
+    for (int64_t t = lane; t < Lp; t += 64) cols32[o + t] = t < L ? cols[s0 + t] : 0;
+  }
+}
+__global__ __launch_bounds__(256) void k_pad_vals32(int64_t N2, const int64_t* __restrict__ rowptr, const double* __restrict__ A,
+                                                    const int64_t* __restrict__ p32, float* __restrict__ A32) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < N2; r += nwaves) {
+    const int64_t s0 = rowptr[6 * r], L = rowptr[6 * r + 1] - s0, Lp = (L + 3) & ~(int64_t)3, o = p32[r];
+    for (int k = 0; k < 6; ++k)
+      for (int64_t t = lane; t < Lp; t += 64) A32[o + k * Lp + t] = t < L ? (float)A[s0 + k * L + t] : 0.f;
+  }
+}
+template <bool XCD>
+__global__ __launch_bounds__(256) void k_spmv_node6p(int64_t N2, const int64_t* __restrict__ p32, const int32_t* __restrict__ cols32,
+                                                     const float* __restrict__ vals, const double* __restrict__ x,
+                                                     double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  int64_t first, last, stride;
+  if (XCD) {
+    const int64_t chunk = (N2 + 7) >> 3, k = blockIdx.x & 7;
+    first = k * chunk + (blockIdx.x >> 3) * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    last = (k + 1) * chunk < N2 ? (k + 1) * chunk : N2;
+    stride = (int64_t)(gridDim.x >> 3) * (blockDim.x >> 6);
+  } else {
+    first = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    last = N2;
+    stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  }
+  for (int64_t r = first; r < last; r += stride) {
+    const int64_t o = p32[r];
+    const int Lp = (int)((p32[r + 1] - o) / 6);
+    const float* v = vals + o;
+    const int32_t* c = cols32 + o / 6;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
+    for (int t = 4 * lane; t < Lp; t += 256) {
+      const int4 cc = *reinterpret_cast<const int4*>(c + t);
+      const float4 v0 = *reinterpret_cast<const float4*>(v + t), v1 = *reinterpret_cast<const float4*>(v + Lp + t),
+                   v2 = *reinterpret_cast<const float4*>(v + 2 * Lp + t), v3 = *reinterpret_cast<const float4*>(v + 3 * Lp + t),
+                   v4 = *reinterpret_cast<const float4*>(v + 4 * Lp + t), v5 = *reinterpret_cast<const float4*>(v + 5 * Lp + t);
+      const double x0 = x[cc.x], x1 = x[cc.y], x2 = x[cc.z], x3 = x[cc.w];
+      a0 += ((double)v0.x * x0 + (double)v0.y * x1) + ((double)v0.z * x2 + (double)v0.w * x3);
+      a1 += ((double)v1.x * x0 + (double)v1.y * x1) + ((double)v1.z * x2 + (double)v1.w * x3);
+      a2 += ((double)v2.x * x0 + (double)v2.y * x1) + ((double)v2.z * x2 + (double)v2.w * x3);
+      a3 += ((double)v3.x * x0 + (double)v3.y * x1) + ((double)v3.z * x2 + (double)v3.w * x3);
+      a4 += ((double)v4.x * x0 + (double)v4.y * x1) + ((double)v4.z * x2 + (double)v4.w * x3);
+      a5 += ((double)v5.x * x0 + (double)v5.y * x1) + ((double)v5.z * x2 + (double)v5.w * x3);
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3); a4 = wave_sum(a4); a5 = wave_sum(a5);
+    if (lane == 0) { double* o6 = y + 6 * r; o6[0] = a0; o6[1] = a1; o6[2] = a2; o6[3] = a3; o6[4] = a4; o6[5] = a5; }
+  }
+}
+void launch_pad_cols32(hipStream_t st, int64_t N2, const int64_t* rowptr, const int32_t* cols, const int64_t* p32, int32_t* cols32) {
+  int64_t blocks = std::min<int64_t>((N2 + 3) / 4, 8192);
+  hipLaunchKernelGGL(k_pad_cols32, dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, cols, p32, cols32);
+}
+// node rows padded (k_pad_vals32), pressure rows as they are behind them at entry offset ptail
+void launch_pad_vals32(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const double* A, const int64_t* p32,
+                       int64_t ptail, int64_t nnz_tail, int64_t tail_src, float* A32) {
+  int64_t blocks = std::min<int64_t>((N2 + 3) / 4, 8192);
+  hipLaunchKernelGGL(k_pad_vals32, dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, A, p32, A32);
+  if (V > 0 && nnz_tail > 0) launch_round_to_f32(st, nnz_tail, A + tail_src, A32 + ptail);
+}
+// y = A32 x: padded node rows, then the pressure rows (their values at vals + ptail, indexed by the rows' own pointers
+// shifted by tail_shift = ptail - rowptr[6 N2])
+void launch_spmv_node6p(hipStream_t st, int64_t N2, int64_t V, const int64_t* p32, const int32_t* cols32, const float* vals,
+                        const int64_t* rowptr, const int32_t* cols, int64_t tail_shift, const double* x, double* y) {
+  static const bool xcd = !(getenv("FSI_SPMV_XCD") && atoi(getenv("FSI_SPMV_XCD")) == 0);
+  int64_t blocks = (N2 + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  blocks = (blocks + 7) & ~(int64_t)7;
+  if (xcd) hipLaunchKernelGGL(k_spmv_node6p<true>, dim3((unsigned)blocks), dim3(256), 0, st, N2, p32, cols32, vals, x, y);
+  else hipLaunchKernelGGL(k_spmv_node6p<false>, dim3((unsigned)blocks), dim3(256), 0, st, N2, p32, cols32, vals, x, y);
+  if (V > 0) {
+    int64_t pb = (V + 3) / 4;
+    if (pb > 8192) pb = 8192;
+    // the generic kernel indexes values and columns with the same pointer: hand it the value array shifted so that
+    // vals32[rowptr[row]] is the row's first value
+    hipLaunchKernelGGL((k_spmv<SPMV_MONOLITHIC, float>), dim3((unsigned)pb), dim3(256), 0, st, V, rowptr + 6 * N2, cols, vals + tail_shift, x, y + 6 * N2);
+  }
+}
 __global__ __launch_bounds__(256) void k_round_to_f32(int64_t n, const double* __restrict__ a, float* __restrict__ b) {
   GRID_STRIDE(i, n) b[i] = (float)a[i];
 }
