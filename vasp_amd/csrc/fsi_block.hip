@@ -296,19 +296,43 @@ void launch_merge(hipStream_t st, int64_t N2, int64_t V, const double* zd, const
 
 // dv[R] = vs[R] - (A_vp dp)[R] / D[R]   (SIMPLE velocity correction); also y = D^-1 A_vp x for the Schur operator.
 // One thread per row (rows have 4-30 entries).
-__global__ void k_vel_correct(int64_t n3, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
-                              const double* __restrict__ vals, const double* __restrict__ dp,
-                              const int64_t* __restrict__ diagpos3, const double* __restrict__ Avv,
-                              const double* __restrict__ vs, double* __restrict__ dv) {
-  GS(R, n3) {
+// dv = vs - D^-1 A_vp dp.  A row of A_vp has the ~7 vertices its node sees: 8 lanes per row (a wave reads 8 consecutive rows,
+// ~56 consecutive entries), sums by DPP, and the update of a workgroup's 32 consecutive rows by its first 32 lanes through
+// LDS.  (One thread per row, the first form, walked 4.4 M rows with stride-7 accesses: 375 us, 1 TB/s.)
+__global__ __launch_bounds__(256) void k_vel_correct(int64_t n3, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                     const double* __restrict__ vals, const double* __restrict__ dp,
+                                                     const int64_t* __restrict__ diagpos3, const double* __restrict__ Avv,
+                                                     const double* __restrict__ dinv, const double* __restrict__ vs,
+                                                     double* __restrict__ dv) {
+  __shared__ double ssum[32];
+  const int sub = threadIdx.x & 7, g = threadIdx.x >> 3;
+  for (int64_t base = (int64_t)blockIdx.x * 32; base < n3; base += (int64_t)gridDim.x * 32) {
+    const int64_t R = base + g;
     double s = 0.0;
-    for (int64_t t = rowptr[R]; t < rowptr[R + 1]; ++t) s += vals[t] * dp[cols[t]];
-    dv[R] = (vs ? vs[R] : 0.0) - s / Avv[diagpos3[R]];
+    if (R < n3)
+      for (int64_t t = rowptr[R] + sub; t < rowptr[R + 1]; t += 8) s += vals[t] * dp[cols[t]];
+    s = group_sum<8>(s);
+    if (sub == 0) ssum[g] = s;
+    __syncthreads();
+    if (threadIdx.x < 32 && base + threadIdx.x < n3) {
+      const int64_t row = base + threadIdx.x;
+      // dinv: 1 / diagonal, made once per refresh (the diagonal itself is a gather from the 1 GB value array of the block)
+      dv[row] = (vs ? vs[row] : 0.0) - (dinv ? ssum[threadIdx.x] * dinv[row] : ssum[threadIdx.x] / Avv[diagpos3[row]]);
+    }
+    __syncthreads();
   }
 }
 void launch_vel_correct(hipStream_t st, int64_t n3, const int64_t* rowptr, const int32_t* cols, const double* vals,
-                        const double* dp, const int64_t* diagpos3, const double* Avv, const double* vs, double* dv) {
-  hipLaunchKernelGGL(k_vel_correct, dim3(gridn(n3)), dim3(256), 0, st, n3, rowptr, cols, vals, dp, diagpos3, Avv, vs, dv);
+                        const double* dp, const int64_t* diagpos3, const double* Avv, const double* vs, double* dv, const double* dinv) {
+  int64_t blocks = (n3 + 31) / 32;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k_vel_correct, dim3((unsigned)blocks), dim3(256), 0, st, n3, rowptr, cols, vals, dp, diagpos3, Avv, dinv, vs, dv);
+}
+__global__ void k_diag_inverse(int64_t n, const int64_t* __restrict__ diagpos, const double* __restrict__ A, double* __restrict__ dinv) {
+  GS(i, n) dinv[i] = 1.0 / A[diagpos[i]];
+}
+void launch_diag_inverse(hipStream_t st, int64_t n, const int64_t* diagpos, const double* A, double* dinv) {
+  hipLaunchKernelGGL(k_diag_inverse, dim3(gridn(n)), dim3(256), 0, st, n, diagpos, A, dinv);
 }
 // y = alpha * (App x)[q] + beta * (Apv~ w)[q] + gamma * c[q]: pressure-row products (Schur operator, pressure rhs).
 // One wave per pressure row.
@@ -397,22 +421,45 @@ __global__ void k_extract_db(int64_t N2, const int64_t* __restrict__ nadj_ptr, c
   }
 }
 // y[3r+i] = sum_k db[e][i] x[3 s_k + i]; 16 lanes per node (4 nodes per wave)
+// rowmask (may be null): rows whose flag is 0 hold only zeros (A_dv: every fluid row) and are not streamed
 __global__ __launch_bounds__(256) void k_spmv_db(int64_t N2, const int64_t* __restrict__ nadj_ptr,
                                                  const int32_t* __restrict__ nadj, const double* __restrict__ db,
-                                                 const double* __restrict__ x, double* __restrict__ y) {
+                                                 const uint8_t* __restrict__ rowmask, const double* __restrict__ x,
+                                                 double* __restrict__ y) {
   const int sub = threadIdx.x & 15;
   const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
   const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
   for (int64_t r = grp; r < N2; r += ngrp) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int64_t e = nadj_ptr[r] + sub; e < nadj_ptr[r + 1]; e += 16) {
-      const double* xs = x + 3 * (int64_t)nadj[e];
-      const double* c = db + 3 * e;
-      s0 += c[0] * xs[0]; s1 += c[1] * xs[1]; s2 += c[2] * xs[2];
+    if (!rowmask || rowmask[r]) {
+      for (int64_t e = nadj_ptr[r] + sub; e < nadj_ptr[r + 1]; e += 16) {
+        const double* xs = x + 3 * (int64_t)nadj[e];
+        const double* c = db + 3 * e;
+        s0 += c[0] * xs[0]; s1 += c[1] * xs[1]; s2 += c[2] * xs[2];
+      }
+      s0 = group_sum<16>(s0); s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
     }
-    s0 = group_sum<16>(s0); s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
     if (sub == 0) { y[3 * r] = s0; y[3 * r + 1] = s1; y[3 * r + 2] = s2; }
   }
+}
+// rowmask[r] = 1 iff node r has a non-zero entry in db
+__global__ __launch_bounds__(256) void k_db_rowmask(int64_t N2, const int64_t* __restrict__ nadj_ptr, const double* __restrict__ db,
+                                                    uint8_t* __restrict__ rowmask) {
+  const int sub = threadIdx.x & 15;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t r = grp; r < N2; r += ngrp) {
+    float any = 0.f;
+    for (int64_t e = nadj_ptr[r] + sub; e < nadj_ptr[r + 1]; e += 16)
+      if (db[3 * e] != 0.0 || db[3 * e + 1] != 0.0 || db[3 * e + 2] != 0.0) any = 1.f;
+    any = group_sum<16>(any);
+    if (sub == 0) rowmask[r] = any > 0.f ? 1 : 0;
+  }
+}
+void launch_db_rowmask(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const double* db, uint8_t* rowmask) {
+  int64_t blocks = (N2 + 15) / 16;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_db_rowmask, dim3((unsigned)blocks), dim3(256), 0, st, N2, nadj_ptr, db, rowmask);
 }
 // FP32 variants for the preconditioner sweeps (values converted once per Jacobian refresh)
 __global__ __launch_bounds__(256) void k_spmv_db_f32(int64_t N2, const int64_t* __restrict__ nadj_ptr,
@@ -1091,10 +1138,10 @@ void launch_extract_db(hipStream_t st, int64_t N2, int64_t npairs, const int64_t
   hipLaunchKernelGGL(k_extract_db, dim3(gridn(npairs)), dim3(256), 0, st, N2, nadj_ptr, rowptr3, vals, db, flags, check);
 }
 void launch_spmv_db(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
-                    const double* x, double* y) {
+                    const double* x, double* y, const uint8_t* rowmask) {
   int64_t blocks = (N2 + 15) / 16;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(k_spmv_db, dim3((unsigned)blocks), dim3(256), 0, st, N2, nadj_ptr, nadj, db, x, y);
+  hipLaunchKernelGGL(k_spmv_db, dim3((unsigned)blocks), dim3(256), 0, st, N2, nadj_ptr, nadj, db, rowmask, x, y);
 }
 
 // compact solid block: values gathered from Avv~ (vals[e] = src[pos[e]]), vectors gathered / scattered by node list

@@ -473,9 +473,9 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
                           ctx->inner_rtol, ctx->inner_maxit_p, &ctx->inner_its[1]));
   }
   // velocity correction and displacement
-  launch_vel_correct(st, n3, ctx->rowptr_vp.p, ctx->cols_vp.p, ctx->Avp.p, dp, ctx->diagpos3.p, ctx->Mvv.vals.p, vs, dv);
+  launch_vel_correct(st, n3, ctx->rowptr_vp.p, ctx->cols_vp.p, ctx->Avp.p, dp, ctx->diagpos3.p, ctx->Mvv.vals.p, vs, dv, ctx->vv_dinv.p);
   if (ctx->adv_is_db) {
-    launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->adv_db.p, dv, w3);
+    launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->adv_db.p, dv, w3, ctx->adv_rowmask.p);
     launch_axpby(st, td, 1.0, rd, -1.0, w3, n3);
   } else {
     launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Adv.p, dv, rd, td);
@@ -1141,6 +1141,10 @@ int refresh_preconditioner(FsiCtx* ctx) {
       launch_extract_db(st, ctx->N2, npairs, ctx->nadj_ptr.p, ctx->rowptr3.p, ctx->Adv.p, ctx->adv_db.p, ctx->iflags.p, 1);
       HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
       ctx->adv_is_db = !(flags[1] & 8);
+      if (!ctx->vv_dinv.p) HIPCHK(ctx->vv_dinv.alloc(3 * ctx->N2));
+      launch_diag_inverse(st, 3 * ctx->N2, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->vv_dinv.p);
+      if (!ctx->adv_rowmask.p) HIPCHK(ctx->adv_rowmask.alloc(ctx->N2));
+      launch_db_rowmask(st, ctx->N2, ctx->nadj_ptr.p, ctx->adv_db.p, ctx->adv_rowmask.p);     // A_dv has no entries in fluid rows
       HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
       launch_extract_chat(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_db.p, ctx->dd_chat.p, ctx->dd_rowflag.p, ctx->iflags.p);
       HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
@@ -1368,7 +1372,7 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->sb_ptr.release(); ctx->sb_src.release(); ctx->sb_vals.release(); ctx->sb_dinv.release();
   ctx->sb_binv12.release(); ctx->sb_binv9.release();
   ctx->dd_db32.release(); ctx->vv_db32.release(); ctx->dd_dinv32.release(); ctx->vvf_dinv32.release();
-  ctx->dd_chat.release(); ctx->ones32.release(); ctx->dd_rowflag.release(); ctx->dd_rec.release(); ctx->vv_rec.release(); ctx->sb_rec.release();
+  ctx->adv_rowmask.release(); ctx->vv_dinv.release(); ctx->dd_chat.release(); ctx->ones32.release(); ctx->dd_rowflag.release(); ctx->dd_rec.release(); ctx->vv_rec.release(); ctx->sb_rec.release();
   ctx->tile_ploc.release(); ctx->tile_uptr.release(); ctx->tile_ulist.release();
   for (auto* b : {&ctx->ss_rowptr, &ctx->ss_diagpos, &ctx->ss_src}) b->release();
   for (auto* b : {&ctx->node_solid, &ctx->vrank, &ctx->cols3, &ctx->cols_vp, &ctx->cols_pv, &ctx->cols_pp}) b->release();

@@ -267,6 +267,8 @@ struct FsiCtx {
   int64_t a32_ptail = 0, a32_tail_src = 0, a32_tail_nnz = 0;     // pressure rows: behind the padded node blocks, unpadded
   bool gcr_stagnated = false;                // the last cycle ended on 40 iterations without a 10 % gain
   int debug_prec_apply = 0;
+  fsi::DevBuf<double> vv_dinv;               // [3 N2] 1 / diag(Avv~), for the velocity correction
+  fsi::DevBuf<uint8_t> adv_rowmask;          // [N2] 1: the node's A_dv rows have entries (solid nodes), 0: all zero, not streamed
   bool sweeps_fp16 = true;                   // FSI_SWEEPS_FP16=0: FP32 matrix values in the fine-level sweeps (k_sweep_tiled_f32 / k_sweep_sb_b3)
   fsi::DevBuf<uint32_t> dd_rec, vv_rec, sb_rec;   // packed FP16 records: [pairs], [pairs][2], [blocks][6] 32-bit words
   bool fused_sweeps = true;                  // FSI_FUSED_SWEEPS=0: product and Chebyshev update of the FP32 sweeps as two launches

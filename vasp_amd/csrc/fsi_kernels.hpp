@@ -167,7 +167,9 @@ void launch_schur_full(hipStream_t st, int64_t V, const int64_t* s_rowptr, const
 void launch_split(hipStream_t st, int64_t N2, int64_t V, const double* r, double* rd, double* rv, double* rp);
 void launch_merge(hipStream_t st, int64_t N2, int64_t V, const double* zd, const double* zv, const double* zp, double* z);
 void launch_vel_correct(hipStream_t st, int64_t n3, const int64_t* rowptr, const int32_t* cols, const double* vals,
-                        const double* dp, const int64_t* diagpos3, const double* Avv, const double* vs, double* dv);
+                        const double* dp, const int64_t* diagpos3, const double* Avv, const double* vs, double* dv,
+                        const double* dinv = nullptr);
+void launch_diag_inverse(hipStream_t st, int64_t n, const int64_t* diagpos, const double* A, double* dinv);
 void launch_pres_rows(hipStream_t st, int64_t V, const int64_t* rowptr_pp, const int32_t* cols_pp, const double* App,
                       const double* x, double alpha, const int64_t* rowptr_pv, const int32_t* cols_pv, const double* Apv,
                       const double* w, double beta, const double* c, double gamma, double* y);
@@ -178,7 +180,8 @@ void launch_cheb_step(hipStream_t st, int64_t n, const double* mask, const doubl
 void launch_extract_db(hipStream_t st, int64_t N2, int64_t npairs, const int64_t* nadj_ptr, const int64_t* rowptr3,
                        const double* vals, double* db, int32_t* flags, int check);
 void launch_spmv_db(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
-                    const double* x, double* y);
+                    const double* x, double* y, const uint8_t* rowmask = nullptr);
+void launch_db_rowmask(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const double* db, uint8_t* rowmask);
 void launch_spmv_tiled_f32(hipStream_t st, int nv, int64_t N2, int max_nu, const int64_t* nadj_ptr, const float* vals,
                            const uint16_t* ploc, const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag,
                            const float* x, float* y);
