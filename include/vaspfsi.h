@@ -179,7 +179,8 @@ int fsi_spmv(FsiCtx* ctx, const double* x, double* y);
  * the caller's business); out[i] = d_x d_y d_z v_x v_y v_z p of dvp_["n"] at point i (P2 / P1 interpolation). */
 int fsi_probe(FsiCtx* ctx, int64_t n, const int32_t* cells, const double* bary, double* out);
 /* Replaces: the DG0 projections of calculate_and_print_flow_properties (:253-317) and compute_minimum_jacobian (:320-348):
- * out[0..3] = mean, min, max over the cells of the cell-mean |v|, and min over the cells of the cell-mean det(I + grad d). */
+ * out[0..3] = mean, min, max over the cells of the cell-mean |v|, and min over the cells of the cell-mean det(I + grad d).
+ * After fsi_set_partition: over the cells this context owns (the caller combines the ranks with the owned-cell counts). */
 int fsi_flow_stats(FsiCtx* ctx, double* out);
 
 /* ---- post-processing kernels on the resident state ------------------------------------- */

@@ -46,8 +46,13 @@ def _worker(rank, world, port, q):
     hist = _time_steps(db, ns, bc_values, pressure, hook)
     x = db.get_state("n")
     b_norm = db.assemble_residual()                     # residual norm of the final state (an all-reduced sum over owners)
+    # post_solve diagnostics of the partitioned backend (collectives: every rank calls them)
+    mesh = ns["mesh"]
+    pts = mesh.cell_midpoints()[::97] + 1e-6
+    cells, bary = mesh.locate(pts)
+    diag = (db.flow_stats(), db.probe(cells, bary), db.get_values("n", np.arange(0, db.ndof_global, 53)))
     if rank == 0:
-        q.put((x, hist, b_norm))
+        q.put((x, hist, b_norm, diag))
     dist.barrier()
     db.close()
     dist.destroy_process_group()
@@ -66,7 +71,7 @@ def test_partitioned_steps_match_single_context(world, tmp_path):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    x_part, hist_part, b_part = q.get(timeout=900)
+    x_part, hist_part, b_part, diag_part = q.get(timeout=900)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -76,6 +81,10 @@ def test_partitioned_steps_match_single_context(world, tmp_path):
     hist_one = _time_steps(hb, ns, bc_values, pressure, hook)
     x_one = hb.get_state("n")
     b_one = hb.assemble_residual()
+    m1 = ns["mesh"]
+    pts = m1.cell_midpoints()[::97] + 1e-6
+    cells, bary = m1.locate(pts)
+    diag_one = (hb.flow_stats(), hb.probe(cells, bary), hb.get_values("n", np.arange(0, hb.ndof, 53)))
     hb.close()
 
     mesh = ns["mesh"]
@@ -86,6 +95,14 @@ def test_partitioned_steps_match_single_context(world, tmp_path):
     big = r_one > 1e-6 * r_one.max()
     assert np.allclose(r_part[big], r_one[big], rtol=1e-5)             # the same residual norms (sums over the owners)
     assert b_part == pytest.approx(b_one, rel=1e-4, abs=1e-10 * r_one.max())
+    # diagnostics: the owners' contributions add up to what one context reports on (to solver accuracy) the same state
+    scale = [np.abs(x_one[sl]).max() for sl in (slice(0, 3 * mesh.num_nodes), slice(3 * mesh.num_nodes, 6 * mesh.num_nodes),
+                                                 slice(6 * mesh.num_nodes, None))]
+    assert np.allclose(diag_part[0], diag_one[0], rtol=1e-6)                                   # mean / min / max |v|, min J
+    for cols, sc in ((slice(0, 3), scale[0]), (slice(3, 6), scale[1]), (slice(6, 7), scale[2])):
+        assert np.abs(diag_part[1][:, cols] - diag_one[1][:, cols]).max() <= 1e-7 * sc
+    assert np.abs(diag_part[2] - diag_one[2]).max() <= 1e-7 * max(scale)
+    assert np.abs(diag_one[2] - x_one[::53]).max() == 0.0
     print("krylov iterations per Newton iteration:", world, "ranks", [it[3] for h in hist_part for it in h], "single",
           [it[3] for h in hist_one for it in h])
 

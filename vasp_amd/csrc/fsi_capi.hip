@@ -2563,12 +2563,15 @@ int fsi_flow_stats(FsiCtx* ctx, double* out) {
   HIPCHK(hipSetDevice(ctx->device));
   if (!ctx->cellvals.p) HIPCHK(ctx->cellvals.alloc(2 * ctx->C + 8));
   double* res = ctx->cellvals.p + 2 * ctx->C;
-  launch_cell_stats(ctx->stream, ctx->C, elem_arrays(ctx), ctx->U.p, ctx->cellvals.p, res);
+  // partitioned: the cells this rank owns (they come first); the host combines the ranks with the owned-cell counts
+  const int64_t nc = ctx->part ? ctx->C_owned : ctx->C;
+  if (nc <= 0) { out[0] = 0.0; out[1] = 1e300; out[2] = -1e300; out[3] = 1e300; return FSI_OK; }
+  launch_cell_stats(ctx->stream, nc, elem_arrays(ctx), ctx->U.p, ctx->cellvals.p, res);
   HIPCHK(hipGetLastError());
   double h[4];
   HIPCHK(hipMemcpyAsync(h, res, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  out[0] = h[0] / (double)ctx->C; out[1] = h[1]; out[2] = h[2]; out[3] = h[3];
+  out[0] = h[0] / (double)nc; out[1] = h[1]; out[2] = h[2]; out[3] = h[3];
   return FSI_OK;
 }
 

@@ -222,6 +222,7 @@ class DistBackend:
         self.recvbuf = torch.zeros(max(1, len(p.ghost_dofs)), dtype=torch.float64, device=dev)
         self._red = torch.zeros(1024, dtype=torch.float64, device=dev)
         self._error: Optional[BaseException] = None
+        self._g2l_owned: Optional[np.ndarray] = None
         self._cb_red = self._CB_RED(self._allreduce)
         self._cb_halo = self._CB_HALO(self._halo)
 
@@ -308,6 +309,51 @@ class DistBackend:
 
     def timers(self, reset=False):
         return self.hb.timers(reset)
+
+    # ---- post_solve diagnostics on the device (simulation_common picks them up by name, as for HipBackend) ---------------
+    # Without them every rank would fall back to the numpy versions on the gathered global state: seconds per step.
+    def _reduce(self, values, op: str):
+        """All-reduce a few host scalars (op: "sum" | "min" | "max") over the job; returns a numpy array."""
+        torch = self.torch
+        t = torch.tensor(np.asarray(values, dtype=np.float64), dtype=torch.float64,
+                         device=self.dev if self.on_gpu_wire else "cpu")
+        self.dist.all_reduce(t, op={"sum": self.dist.ReduceOp.SUM, "min": self.dist.ReduceOp.MIN, "max": self.dist.ReduceOp.MAX}[op])
+        return t.cpu().numpy()
+
+    def flow_stats(self):
+        """HipBackend.flow_stats over the whole job: every rank contributes the cells it owns (fsi_flow_stats counts those)."""
+        n = self.part.num_owned_cells
+        mean, mn, mx, mj = self.hb.flow_stats() if n > 0 else (0.0, np.inf, -np.inf, np.inf)
+        tot = self._reduce([mean * n, float(n)], "sum")
+        lo = self._reduce([mn, mj], "min")
+        hi = self._reduce([mx], "max")
+        return float(tot[0] / max(tot[1], 1.0)), float(lo[0]), float(hi[0]), float(lo[1])
+
+    def probe(self, cells, bary):
+        """HipBackend.probe for global cell ids: the owner of a cell evaluates its points, the rest add zeros."""
+        cells = np.asarray(cells, dtype=np.int64)
+        bary = np.asarray(bary, dtype=np.float64).reshape(-1, 4)
+        loc = self.part.cell_g2l[cells]
+        mine = (loc >= 0) & (loc < self.part.num_owned_cells)
+        out = np.zeros((len(cells), 7))
+        if mine.any():
+            out[mine] = self.hb.probe(loc[mine], bary[mine])
+        return self._reduce(out.ravel(), "sum").reshape(-1, 7)
+
+    def get_values(self, which, dofs):
+        """state[dofs] for global user-layout dofs, from their owners."""
+        if self._g2l_owned is None:
+            g = -np.ones(self.ndof_global, dtype=np.int64)
+            own = np.nonzero(self.part.owned_dof_mask)[0]
+            g[self.part.l2g_dofs[own]] = own
+            self._g2l_owned = g
+        dofs = np.asarray(dofs, dtype=np.int64)
+        loc = self._g2l_owned[dofs]
+        mine = loc >= 0
+        out = np.zeros(len(dofs))
+        if mine.any():
+            out[mine] = self.hb.get_values(which, loc[mine])
+        return self._reduce(out, "sum")
 
     def set_state(self, which, x_global):
         self.hb.set_state(which, self.part.restrict(x_global))
