@@ -19,3 +19,7 @@ for f in $(find /tmp/prof_final -name "*kernel_stats*.csv"); do cp $f $O/kernel_
 python tools/show_kernels.py $O/bench_profiled.json | head -1 | cut -c1-200
 VASPFSI_DIST_BACKEND=gloo VASPFSI_ONE_GPU=1 VASPFSI_LIN_MAX_IT=600 timeout -k 10 400 python bench.py --gpus 2 --steps 3 --warmup 1 --tets 100000 --no-cpu-baseline > $O/launch2.json 2> $O/launch2.err; echo "launch2 rc=$?"
 python tools/show_bench.py $O/launch2.json | cut -c1-400
+VASPFSI_FORCE_PARTITION=1 timeout -k 10 300 python bench.py --steps 3 --warmup 1 --tets 100000 --no-cpu-baseline > $O/nccl_one_rank.json 2> $O/nccl_one_rank.err; echo "nccl one rank rc=$?"
+python tools/show_bench.py $O/nccl_one_rank.json | cut -c1-300
+timeout -k 10 300 python bench.py --steps 3 --warmup 1 --tets 100000 --no-cpu-baseline > $O/single_100k.json 2> $O/single_100k.err; echo "single 100k rc=$?"
+python tools/show_bench.py $O/single_100k.json | cut -c1-300
