@@ -156,6 +156,43 @@ def test_offset_stenosis_known_answer_on_gpu(stenosis_case):
     hb.close()
 
 
+def test_production_storage_precisions_do_not_change_the_result(stenosis_case, monkeypatch):
+    """The production defaults (FP32 Krylov basis and FP32 copy of the Jacobian inside the iterations, FP16 / FP32 matrix
+    copies in the preconditioner sweeps, inexact-Newton forcing 1e-2) against the same five steps with every one of them
+    switched off (all FP64, every system to 1e-10): the reference's Newton policy (tolerances 1e-6) must stop on the same
+    fields - the storage precisions only exist inside linear solves whose answers are judged on the FP64 matrix."""
+    from vasp_amd.capi import HipBackend
+    ns, desc, bc_values, pressure, hook = stenosis_case
+    mesh = ns["mesh"]
+
+    def run(**kw):
+        hb = HipBackend(desc, **kw)
+        its, kry = [], 0
+        for k in range(5):
+            g, P = boundary_data(stenosis_case, 0.01 * (k + 1))
+            hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+            h = hb.newton_solve(counter=k, first_step_num=0, atol=ns["atol"], rtol=ns["rtol"], max_it=ns["max_it"], lmbda=1.0,
+                                recompute=ns["recompute"], recompute_tstep=ns["recompute_tstep"])
+            its.append(len(h)); kry += sum(it[3] for it in h)
+            hb.shift()
+        U = hb.get_state("n")
+        tm = hb.timers()
+        hb.close()
+        return U, its, kry, tm
+
+    U_prod, its_prod, kry_prod, tm = run()                                  # defaults
+    assert tm["q_elem_bytes"] == 4 and tm["spmv_fp32_calls"] > 0            # ... which did select the FP32 basis and operator
+    for var in ("FSI_KRYLOV_FP32", "FSI_OPERATOR_FP32", "FSI_SCHUR_FP32", "FSI_SWEEPS_FP16"):
+        monkeypatch.setenv(var, "0")
+    U_ref, its_ref, kry_ref, tm_ref = run(lin_rtol=1e-10, newton_forcing=0.0)
+    assert tm_ref["q_elem_bytes"] == 8 and tm_ref["spmv_fp32_calls"] == 0
+    N2 = mesh.num_nodes
+    for name, sl in (("d", slice(0, 3 * N2)), ("v", slice(3 * N2, 6 * N2)), ("p", slice(6 * N2, None))):
+        err = np.linalg.norm(U_prod[sl] - U_ref[sl]) / np.linalg.norm(U_ref[sl])
+        assert err < 2e-5, (name, err)                 # the policy's own stopping tolerance (1e-6 on the update) times its history
+    print("Newton iterations per step", its_prod, "vs exact solves", its_ref, "| Krylov iterations", kry_prod, "vs", kry_ref)
+
+
 def test_robin_terms_match_oracle(tmp_path):
     """aneurysm-style Robin boundary term on the outer wall [REF src/vasp/simulations/aneurysm.py:73-76]."""
     from oracle.fsi_oracle import FsiOracle
