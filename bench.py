@@ -274,7 +274,13 @@ def main():
                                    f"per step: pre_solve, Newton solve, shift, post_solve (no file output)",
                        "tets": C, "dofs": ndof, "matrix_nnz": nnz, "parallelism": (f"element partition over {world} ranks (node slabs, ghost-layer cells {C_all / C - 1:.1%}), "
                                        f"halo + all-reduce over {dist.get_backend()}") if partitioned else "1 GPU",
-                       "rank0_matrix_nnz": nnz, "krylov_storage": f"Q FP{8 * qb}, directions FP64, capacity {tm['krylov_cap']}"},
+                       "rank0_matrix_nnz": nnz, "krylov_storage": f"Q FP{8 * qb}, directions FP64, capacity {tm['krylov_cap']}",
+                       "storage_precisions": ("state, residual, Jacobian and every accumulation FP64; Krylov basis "
+                                              f"FP{8 * qb}" + (" with an FP64 window of 32 columns" if qb == 4 else "")
+                                              + f"; {op32} of {int(tm['spmv_calls'])} outer products on an FP32 copy of the Jacobian values, "
+                                              "every linear answer judged on the FP64 residual of the FP64 matrix; preconditioner "
+                                              "sweeps: " + ("FP16" if fp16 else "FP32") + " matrix values, FP32 vectors (Schur: FP32 values, "
+                                              "FP64 vectors)")},
             "dof_updates_per_s": total_newton * ndof / elapsed,
             "newton_iterations": n_newton, "krylov_iterations": n_krylov,
             "phase_ms": {k: tm[k] for k in ("residual_ms", "jacobian_ms", "factor_ms", "spmv_ms", "precond_ms", "ortho_ms", "flush_ms", "krylov_ms")},

@@ -254,6 +254,44 @@ def test_properties_on_generated_mesh(tmp_path):
     hb.close()
 
 
+def test_properties_at_bench_size(tmp_path):
+    """BASELINE config 2 size (the 1.12 M-tet mesh bench.py times; no oracle run at this size): size-independent properties
+    through the C-ABI - F(0; 0) = 0, linearity and reproducibility of the outer product, the FP32 working copy of the Jacobian
+    against the FP64 one, and one time step of the production policy (FP32 basis / operator, FP16 sweep records) whose Newton
+    residuals fall and whose solid obeys d = dt (theta v + (1 - theta) v1) nodally."""
+    from vasp_amd.capi import HipBackend
+    from vasp_amd.meshgen import write_mesh
+    write_mesh(tmp_path / "s.h5", 1000000)
+    case = prepare_case("offset_stenosis", tmp_path / "s.h5", tmp_path / "run", dt="0.001", T="0.002")
+    ns, desc = case[0], case[1]
+    mesh = ns["mesh"]
+    assert mesh.num_cells > 1_000_000
+    hb = HipBackend(desc)
+    hb.set_dirichlet_values(np.zeros(len(desc["bc_dofs"]))); hb.set_interface_pressure(0.0)
+    assert hb.assemble_residual() == 0.0
+    g, P = boundary_data(case, 1e-3)
+    hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+    hb.assemble_jacobian()
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(hb.ndof), rng.standard_normal(hb.ndof)
+    ax, ay, axy = hb.spmv(x), hb.spmv(y), hb.spmv(2 * x - 3 * y)
+    assert np.abs(axy - (2 * ax - 3 * ay)).max() <= 1e-12 * np.abs(axy).max()
+    assert np.array_equal(hb.spmv(x), ax)
+    hist = hb.newton_solve(counter=0, first_step_num=0, atol=1e-6, rtol=1e-6, max_it=20, lmbda=1.0, recompute=20,
+                           recompute_tstep=20)
+    tm = hb.timers()
+    assert tm["q_elem_bytes"] == 4 and tm["spmv_fp32_calls"] > 0           # the production storage precisions were in use
+    res = [h[0] for h in hist]
+    assert len(hist) <= 6 and (hist[-1][0] < 1e-6 or hist[-1][1] < 1e-6)    # the reference's stopping rule was met
+    assert res[-1] < 1e-2 * res[0]
+    U = hb.get_state("n")
+    d, v, _ = mesh.split(U)
+    solid_only = np.setdiff1d(np.unique(mesh.tet_nodes[mesh.cell_markers == 2]), np.unique(mesh.tet_nodes[mesh.cell_markers != 2]))
+    free = np.setdiff1d(solid_only, np.unique(desc["bc_dofs"][desc["bc_dofs"] < 3 * mesh.num_nodes] // 3))
+    assert np.abs(d[free] - 1e-3 * ns["theta"] * v[free]).max() <= 1e-3 * np.abs(d[free]).max()   # Newton stops at 1e-6
+    hb.close()
+
+
 def test_error_behaviour(cyl, cylinder_case):
     from vasp_amd.capi import FsiError
     with pytest.raises(FsiError) as e:
