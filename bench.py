@@ -135,10 +135,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     n_newton, n_krylov = 0, 0
+    krylov_per_solve = []                    # per time step: Krylov iterations of each Newton iteration
     for _ in range(args.steps):
         hist = one_step()
         n_newton += len(hist)
         n_krylov += sum(h[3] for h in hist)
+        krylov_per_solve.append([int(h[3]) for h in hist])
     barrier()
     elapsed = time.perf_counter() - t0
     tm = hb.timers()
@@ -282,7 +284,7 @@ def main():
                                               "sweeps: " + ("FP16" if fp16 else "FP32") + " matrix values, FP32 vectors (Schur: FP32 values, "
                                               "FP64 vectors)")},
             "dof_updates_per_s": total_newton * ndof / elapsed,
-            "newton_iterations": n_newton, "krylov_iterations": n_krylov,
+            "newton_iterations": n_newton, "krylov_iterations": n_krylov, "krylov_per_solve": krylov_per_solve,
             "phase_ms": {k: tm[k] for k in ("residual_ms", "jacobian_ms", "factor_ms", "spmv_ms", "precond_ms", "ortho_ms", "flush_ms", "krylov_ms")},
             "phase_calls": {k: tm[k] for k in ("residual_calls", "jacobian_calls", "factor_calls", "spmv_calls", "precond_calls",
                                                "krylov_solves", "krylov_iters", "inner_vv_iters", "inner_schur_iters", "inner_dd_iters",
