@@ -4,7 +4,8 @@ The reference cannot run here, so what can be established about
 the pinned numbers of REF tests/test_create_hdf5_and_separate_viz.py:40-51,196-206 / tests/test_predeform.py:32-33 is
 established on the cylinder case (1 647 tets, 3 steps), where every step is cheap enough to perturb:
 
-1. the linear solves are not the source: one SuperLU solve of the first Newton system is accurate to 1e-10 of v_x;
+1. OUR linear solves are not the source: one SuperLU solve of the first Newton system is accurate to 1e-10 of v_x (the
+   matrix is well-conditioned componentwise but has cond_1 = 4e15: what the reference's MUMPS returned for it is another matter);
 2. the structure of the discrete equations is right where the pins can see it: the pinned pairs (v_x, d_x) at the interface
    vertex violate d = dt (theta v^n + (1 - theta) v^{n-1}) by 2.695e-5 d - the footprint of the fluid's Laplace lifting
    term (alfa = 1) on a d-row whose penalty is delta rho_s / k - and the oracle reproduces that number to five digits at all
@@ -94,6 +95,27 @@ def test_linear_solve_is_accurate(study):
     r = b - A @ x
     dx = lu.solve(r)                                    # one step of iterative refinement
     assert abs(dx[3 * o.N2]) <= 1e-10 * abs(x[3 * o.N2])
+
+
+def test_the_newton_matrix_is_normwise_singular_to_double_precision(study):
+    """cond_1 of the first Newton matrix is ~4e15 (rows of the delta = 1e7 penalty next to rows of size 1e-9), while entrywise
+    perturbations of a few ulp move the pinned velocity by 1e-10: SuperLU's answer (item 1) is accurate, but a factorisation
+    with other scaling / pivoting choices (the reference's MUMPS) is only bounded by cond * eps on such a matrix."""
+    o, A, lu = study["o"], study["A"].tocsc(), study["lu"]
+    inv = spla.LinearOperator(A.shape, matvec=lu.solve, rmatvec=lambda x: lu.solve(x, trans="T"))
+    cond = spla.onenormest(A) * spla.onenormest(inv)
+    assert cond > 1e15
+    rowmax = np.asarray(abs(A).max(axis=1).todense()).ravel()
+    assert rowmax.min() < 1e-8 and rowmax.max() > 1e3
+    g, P = study["data"](0)
+    Z = np.zeros(o.ndof)
+    b = o.rhs(Z, Z, P, g)
+    x0 = lu.solve(b)
+    rng = np.random.default_rng(0)
+    Ap = A.copy()
+    Ap.data = Ap.data * (1.0 + 4.4e-16 * rng.standard_normal(Ap.nnz))
+    xp = spla.splu(Ap).solve(b)
+    assert abs(xp[3 * o.N2] / x0[3 * o.N2] - 1) < 1e-9
 
 
 def test_pins_carry_the_laplace_footprint_and_the_oracle_reproduces_it(study):
