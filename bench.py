@@ -246,7 +246,7 @@ def main():
                   "k_spmv_tiled_f32<1>": ["k_spmv_tiled_f32<1>"], "k_spmv_tiled_f32<3>": ["k_spmv_tiled_f32<3>"],
                   "k_sweep_tiled_f32<1>": ["k_sweep_tiled_f32<1>"], "k_sweep_tiled_f32<3>": ["k_sweep_tiled_f32<3>"],
                   "k_sweep_tiled_h<1>": ["k_sweep_tiled_h<1>"], "k_sweep_tiled_h<3>": ["k_sweep_tiled_h<3>"], "k_sweep_sb_h": ["k_sweep_sb_h"],
-                  "k_sweep_sb_b3<0>": ["k_sweep_sb_b3<0>"], "Schur": ["k_sweep_csr_mixed", "k_sweep_csr_f32", "k_spmv<2,"],
+                  "k_sweep_sb_b3<0>": ["k_sweep_sb_b3<0>"], "Schur": ["k_sweep_schur_tiled", "k_sweep_csr_mixed", "k_sweep_csr_f32", "k_spmv<2,"],
                   "k_residual": ["k_residual"], "k_jacobian": ["k_jacobian<2>"]}
         if pmc.exists():
             with contextlib.suppress(Exception):

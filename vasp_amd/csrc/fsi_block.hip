@@ -1521,6 +1521,63 @@ void launch_sweep_csr_mixed(hipStream_t st, int64_t n, const int64_t* rowptr, co
   else
     hipLaunchKernelGGL((k_sweep_csr_mixed<8, 8>), dim3((unsigned)blocks), dim3(256), 0, st, n, rowptr, cols, vals, diagpos, dvals, c1, c2, din, dout, x, r);
 }
+// The Schur sweep on packed records (FP16 value + 16-bit tile-local column, 4 bytes per entry instead of 8) with the d entries
+// of a 256-row tile's columns staged once in LDS (FP64; the tile of a two-ring pattern sees ~2-3 k distinct columns).
+// Vectors stay FP64 as in k_sweep_csr_mixed; a rounded matrix is still one linear operator.
+static constexpr int SCHUR_TILE = 256;
+__global__ __launch_bounds__(256) void k_sweep_schur_tiled(int64_t n, const int64_t* __restrict__ rowptr,
+                                                           const uint32_t* __restrict__ rec, const int64_t* __restrict__ tile_uptr,
+                                                           const int32_t* __restrict__ ulist, const double* __restrict__ dinv,
+                                                           double c1, double c2, const double* __restrict__ din,
+                                                           double* __restrict__ dout, double* __restrict__ x, double* __restrict__ r) {
+  extern __shared__ __attribute__((aligned(16))) double sxd[];
+  __shared__ int64_t sptr[SCHUR_TILE + 1];
+  __shared__ double ssum[SCHUR_TILE];
+  const int64_t tile = blockIdx.x, r0 = tile * SCHUR_TILE;
+  const int nrows = (int)((r0 + SCHUR_TILE < n ? r0 + SCHUR_TILE : n) - r0);
+  const int64_t u0 = tile_uptr[tile], nu = tile_uptr[tile + 1] - u0;
+  for (int64_t i = threadIdx.x; i < nu; i += 1024) {              // four dependent index -> entry pairs in flight
+    const int64_t i1 = i + 256, i2 = i + 512, i3 = i + 768;
+    const int32_t k0 = ulist[u0 + i], k1 = i1 < nu ? ulist[u0 + i1] : 0, k2 = i2 < nu ? ulist[u0 + i2] : 0, k3 = i3 < nu ? ulist[u0 + i3] : 0;
+    const double v0 = din[k0], v1 = din[k1], v2 = din[k2], v3 = din[k3];
+    sxd[i] = v0;
+    if (i1 < nu) sxd[i1] = v1;
+    if (i2 < nu) sxd[i2] = v2;
+    if (i3 < nu) sxd[i3] = v3;
+  }
+  for (int i = threadIdx.x; i <= nrows; i += 256) sptr[i] = rowptr[r0 + i];
+  __syncthreads();
+  const int sub = threadIdx.x & 7, g = threadIdx.x >> 3;          // 8 lanes per row, 32 rows per pass
+  for (int row = g; row < nrows; row += 32) {
+    const int64_t b = sptr[row + 1];
+    double s = 0.0;
+    for (int64_t e = sptr[row] + sub; e < b; e += 64) {
+      uint32_t q[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[j] = e + 8 * j < b ? rec[e + 8 * j] : 0u;      // zero record: value +0, local index 0
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (double)h2f(q[j] & 0xffffu) * sxd[q[j] >> 16];
+    }
+    s = group_sum<8>(s);
+    if (sub == 0) ssum[row] = s;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nrows) {
+    const int64_t row = r0 + threadIdx.x;
+    const double di = din[row], ri = r[row] - ssum[threadIdx.x];
+    x[row] += di;
+    r[row] = ri;
+    dout[row] = c1 * di + c2 * ri * dinv[row];
+  }
+}
+int schur_tile_rows() { return SCHUR_TILE; }
+void launch_sweep_schur_tiled(hipStream_t st, int64_t n, int max_nu, const int64_t* rowptr, const uint32_t* rec,
+                              const int64_t* tile_uptr, const int32_t* ulist, const double* dinv, double c1, double c2,
+                              const double* din, double* dout, double* x, double* r) {
+  const unsigned tiles = (unsigned)((n + SCHUR_TILE - 1) / SCHUR_TILE);
+  hipLaunchKernelGGL(k_sweep_schur_tiled, dim3(tiles), dim3(256), (size_t)max_nu * sizeof(double), st, n, rowptr, rec, tile_uptr, ulist,
+                     dinv, c1, c2, din, dout, x, r);
+}
 __global__ void k_csr_dinv_f32(int64_t n, const int64_t* __restrict__ diagpos, const double* __restrict__ A, float* __restrict__ dinv) {
   GS(i, n) dinv[i] = (float)(1.0 / A[diagpos[i]]);
 }

@@ -445,10 +445,15 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
     } else {
       double *pr = IW, *pa = IW + V, *pb = IW + 2 * V;
       launch_cheb_init(st, V, nullptr, tp, ctx->s_diagpos.p, ctx->s_vals.p, 1.0 / th, dp, pr, pa);
+      const bool tiled16 = ctx->schur_tiled && ctx->sweeps_fp16 && ctx->s_rec.p;
       for (int k = 0; k < ctx->cheb_its_p; ++k) {
         const double rn = 1.0 / (2.0 * sig - rho);
         const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->sch_ev0[0];
         if (timed) (void)hipEventRecord(ctx->sch_ev0[k], st);
+        if (tiled16)
+          launch_sweep_schur_tiled(st, V, ctx->s_tile_max_nu, ctx->s_rowptr.p, ctx->s_rec.p, ctx->s_tile_uptr.p, ctx->s_tile_ulist.p,
+                                   ctx->s_dinv.p, rn * rho, 2.0 * rn / de, pa, pb, dp, pr);
+        else
         launch_sweep_csr_mixed(st, V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->s_vals32.p, ctx->s_diagpos.p, ctx->s_vals.p, rn * rho,
                                2.0 * rn / de, pa, pb, dp, pr);
         if (timed) { (void)hipEventRecord(ctx->sch_ev1[k], st); ctx->sch_samples_pending = k + 1; }
@@ -1234,6 +1239,11 @@ int refresh_preconditioner(FsiCtx* ctx) {
       }
       launch_to_f32(st, (int64_t)ctx->s_vals.n, ctx->s_vals.p, ctx->s_vals32.p);
       launch_csr_dinv_f32(st, ctx->V, ctx->s_diagpos.p, ctx->s_vals.p, ctx->s_dinv32.p);
+      if (ctx->schur_tiled && ctx->sweeps_fp16 && ctx->schur_fp32 == 1) {
+        if (!ctx->s_rec.p) { HIPCHK(ctx->s_rec.alloc(ctx->s_vals.n)); HIPCHK(ctx->s_dinv.alloc(ctx->V)); }
+        launch_pack_h1(st, (int64_t)ctx->s_vals.n, ctx->s_vals32.p, ctx->s_ploc.p, ctx->s_rec.p);
+        launch_diag_inverse(st, ctx->V, ctx->s_diagpos.p, ctx->s_vals.p, ctx->s_dinv.p);
+      }
       if (getenv("FSI_DEBUG_PRECOND")) {
         std::vector<float> h(ctx->V), hv(ctx->s_vals.n);
         HIPCHK(hipMemcpy(h.data(), ctx->s_dinv32.p, h.size() * sizeof(float), hipMemcpyDeviceToHost));
@@ -1356,7 +1366,8 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->sbmg_par.release(); ctx->sbmg_ccol.release(); ctx->sbmg_child.release(); ctx->sbmg_cfine.release(); ctx->sbmg_pw.release();
   ctx->sbmg_chw.release(); ctx->sbmg_cvals.release(); ctx->sbmg_cbinv12.release(); ctx->sbmg_work.release(); ctx->sbmg_cptr.release();
   ctx->sbmg_chptr.release(); ctx->sbmg_flag.release(); ctx->sbmg_cflag.release();
-  ctx->s_vals32.release(); ctx->s_dinv32.release(); ctx->s_work32.release();
+  ctx->s_vals32.release(); ctx->s_dinv32.release(); ctx->s_work32.release(); ctx->s_rec.release(); ctx->s_dinv.release();
+  ctx->s_ploc.release(); ctx->s_tile_uptr.release(); ctx->s_tile_ulist.release();
   ctx->fs_rows.release(); ctx->fs_col.release(); ctx->fs_ptr.release(); ctx->fs_src.release();
   ctx->mg_par.release(); ctx->mg_ccol.release(); ctx->mg_child.release(); ctx->mg_cfine.release(); ctx->mg_pw.release();
   ctx->mg_chw.release(); ctx->mg_cptr.release(); ctx->mg_chptr.release(); ctx->mg_Ac.release(); ctx->mg_cc.release();
@@ -2062,6 +2073,35 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
       FSICHK(upload(ctx, ctx->s_diagpos, s_diagpos));
       FSICHK(upload(ctx, ctx->s_cols, s_cols));
       HIPCHK(ctx->s_vals.alloc(s_cols.size()));
+      {   // tiles of the Schur pattern for k_sweep_schur_tiled: per 256 rows the distinct columns and 16-bit local indices
+        const int TR = schur_tile_rows();
+        const int64_t ntiles = (V + TR - 1) / TR;
+        std::vector<int64_t> uptr(ntiles + 1, 0);
+        std::vector<int32_t> ulist, tmpu;
+        std::vector<uint16_t> ploc(s_cols.size());
+        bool ok = true;
+        int max_nu = 0;
+        for (int64_t t = 0; t < ntiles && ok; ++t) {
+          const int64_t q0 = t * TR, q1 = std::min<int64_t>(V, q0 + TR);
+          const int64_t e0 = s_rowptr[q0], e1 = s_rowptr[q1];
+          tmpu.assign(s_cols.begin() + e0, s_cols.begin() + e1);
+          std::sort(tmpu.begin(), tmpu.end());
+          tmpu.erase(std::unique(tmpu.begin(), tmpu.end()), tmpu.end());
+          if (tmpu.size() > 7000) { ok = false; break; }          // 56 KB of LDS as doubles
+          max_nu = std::max<int>(max_nu, (int)tmpu.size());
+          for (int64_t e = e0; e < e1; ++e)
+            ploc[e] = (uint16_t)(std::lower_bound(tmpu.begin(), tmpu.end(), s_cols[e]) - tmpu.begin());
+          ulist.insert(ulist.end(), tmpu.begin(), tmpu.end());
+          uptr[t + 1] = (int64_t)ulist.size();
+        }
+        ctx->schur_tiled = ok && V > 0;
+        ctx->s_tile_max_nu = max_nu;
+        if (ctx->schur_tiled) {
+          FSICHK(upload(ctx, ctx->s_tile_uptr, uptr));
+          FSICHK(upload(ctx, ctx->s_tile_ulist, ulist));
+          FSICHK(upload(ctx, ctx->s_ploc, ploc));
+        }
+      }
     }
     HIPCHK(ctx->blk.alloc((size_t)20 * 3 * N2 + 16));
   }
@@ -2670,7 +2710,7 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
                    ctx->ortho_q_cols, ctx->ortho_q_launches, ctx->ortho_z_cols, ctx->ortho_z_launches,
                    (int64_t)(ctx->kry_fp32 ? 4 : 8), ctx->ldq, ctx->ldz, ctx->kry_hw, ctx->kry_cap,
                    (int64_t)ctx->s_cols.n, ctx->V, ctx->t_flush.ms, ctx->t_flush.calls, ctx->t_sch.ms, ctx->t_sch.calls,
-                   (int64_t)((ctx->schur_fp32 && ctx->s_vals32.p) ? 4 : 8),
+                   (int64_t)((ctx->schur_fp32 && ctx->s_vals32.p) ? ((ctx->schur_tiled && ctx->sweeps_fp16 && ctx->s_rec.p) ? 0 : 4) : 8),
                    (int64_t)(ctx->compact_ok && ctx->spmv_compact ? 1 : 0), (int64_t)ctx->h_nadj.size(), (int64_t)ctx->h_padj.size(),
                    ctx->op32_products};
   if (reset) {

@@ -169,6 +169,9 @@ struct FsiCtx {
   int schur_fp32 = 1;                                 // with the Chebyshev update (k_sweep_csr_mixed); 0: FP64 product + update; 2: vectors
                                                       // in FP32 too (on the 50 k-tet generated mesh the outer GCR then makes no progress:
                                                       // rounding noise of the pressure exceeds the velocity residual; measurement only)
+  bool schur_tiled = false; int s_tile_max_nu = 0;   // FP16 records + tile-local columns for the Schur sweep (k_sweep_schur_tiled)
+  fsi::DevBuf<uint32_t> s_rec; fsi::DevBuf<uint16_t> s_ploc; fsi::DevBuf<int64_t> s_tile_uptr; fsi::DevBuf<int32_t> s_tile_ulist;
+  fsi::DevBuf<double> s_dinv;
   fsi::DevBuf<double> dd_db, vv_db;          // component-diagonal node-block copies of A_dd and Avv~ ([pairs][3])
   fsi::DevBuf<double> adv_db;
   bool dd_is_db = false, adv_is_db = false;

@@ -247,6 +247,10 @@ void launch_cheb_init_plain_f32(hipStream_t st, int64_t n, const double* rhs, co
 void launch_sweep_csr_mixed(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const float* vals,
                             const int64_t* diagpos, const double* dvals, double c1, double c2, const double* din, double* dout,
                             double* x, double* r);
+int schur_tile_rows();
+void launch_sweep_schur_tiled(hipStream_t st, int64_t n, int max_nu, const int64_t* rowptr, const uint32_t* rec,
+                              const int64_t* tile_uptr, const int32_t* ulist, const double* dinv, double c1, double c2,
+                              const double* din, double* dout, double* x, double* r);
 void launch_f32_to_f64(hipStream_t st, int64_t n, const float* a, double* b);
 void launch_sbmg_flags(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals, uint8_t* flag);
 void launch_sbmg_rap(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
