@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void k_spmv_sc_f32(int64_t N2, const int64_t* 
 // entries from LDS through 2-byte local indices.  HBM per pair: value(s) + 2 B instead of value(s) + 4 B + a 16-B
 // gather that the L1/L2 have to serve.
 static constexpr int TILE_NODES = 256;
-static constexpr int TILE_LIMIT = 4096;          // distinct neighbour nodes per tile (64 KB of LDS as float4)
+static constexpr int TILE_LIMIT = 3584;          // distinct neighbour nodes per tile (56 KB of LDS as float4; + 6 KB static < 64 KB per workgroup)
 template <int NV>     // NV = 1: one ratio per pair (displacement block), NV = 3: component-diagonal values (fluid velocity block)
 __global__ __launch_bounds__(256) void k_spmv_tiled_f32(int64_t N2, const int64_t* __restrict__ nadj_ptr,
                                                         const float* __restrict__ vals, const uint16_t* __restrict__ ploc,
