@@ -334,6 +334,84 @@ __global__ void k_diag_inverse(int64_t n, const int64_t* __restrict__ diagpos, c
 void launch_diag_inverse(hipStream_t st, int64_t n, const int64_t* diagpos, const double* A, double* dinv) {
   hipLaunchKernelGGL(k_diag_inverse, dim3(gridn(n)), dim3(256), 0, st, n, diagpos, A, dinv);
 }
+// The two block products of the pressure step on FP32 copies of A_vp / A~_pv that use what the block structure gives away:
+// the three rows of a node share their vertex columns (padj), a pressure row has three consecutive entries per neighbour
+// node (nadj): 16 bytes per (node, vertex) pair instead of 36.  Vectors and sums stay FP64; like every matrix copy of the
+// preconditioner these are fixed linear maps.
+//   dv = vs - D^-1 A_vp dp        (8 lanes per node, update of a workgroup's 32 nodes = 96 consecutive entries through LDS)
+__global__ __launch_bounds__(256) void k_vel_correct32(int64_t N2, const int64_t* __restrict__ padj_ptr, const int32_t* __restrict__ padj,
+                                                       const float* __restrict__ avp, const double* __restrict__ dp,
+                                                       const double* __restrict__ dinv, const double* __restrict__ vs,
+                                                       double* __restrict__ dv) {
+  __shared__ double ssum[96];
+  const int sub = threadIdx.x & 7, g = threadIdx.x >> 3;
+  for (int64_t base = (int64_t)blockIdx.x * 32; base < N2; base += (int64_t)gridDim.x * 32) {
+    const int64_t r = base + g;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    if (r < N2) {
+      const int64_t a = padj_ptr[r], deg = padj_ptr[r + 1] - a;
+      const float* v = avp + 3 * a;
+      for (int64_t k = sub; k < deg; k += 8) {
+        const double p = dp[padj[a + k]];
+        s0 += (double)v[k] * p; s1 += (double)v[deg + k] * p; s2 += (double)v[2 * deg + k] * p;
+      }
+    }
+    s0 = group_sum<8>(s0); s1 = group_sum<8>(s1); s2 = group_sum<8>(s2);
+    if (sub == 0) { ssum[3 * g] = s0; ssum[3 * g + 1] = s1; ssum[3 * g + 2] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 96 && 3 * base + threadIdx.x < 3 * N2) {
+      const int64_t R = 3 * base + threadIdx.x;
+      dv[R] = (vs ? vs[R] : 0.0) - ssum[threadIdx.x] * dinv[R];
+    }
+    __syncthreads();
+  }
+}
+//   y = c - A~_pv w               (16 lanes per pressure row, four strips of neighbours at once)
+__global__ __launch_bounds__(256) void k_pres_rhs32(int64_t V, const int32_t* __restrict__ vrank, const int64_t* __restrict__ nadj_ptr,
+                                                    const int32_t* __restrict__ nadj, const int64_t* __restrict__ rowptr_pv,
+                                                    const float* __restrict__ apv, const double* __restrict__ w,
+                                                    const double* __restrict__ c, double* __restrict__ y) {
+  const int sub = threadIdx.x & 15;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t q = grp; q < V; q += ngrp) {
+    const int32_t r = vrank[q];
+    const int64_t a = nadj_ptr[r], deg = nadj_ptr[r + 1] - a;
+    const float* v = apv + rowptr_pv[q];
+    double s = 0.0;
+    for (int64_t k = sub; k < deg; k += 64) {
+      int nb[4];
+      float f[4][3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool in = k + 16 * j < deg;
+        const int64_t kk = in ? k + 16 * j : k;
+        nb[j] = nadj[a + kk];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) f[j][e] = in ? v[3 * kk + e] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double* ws = w + 3 * (int64_t)nb[j];
+        s += (double)f[j][0] * ws[0] + (double)f[j][1] * ws[1] + (double)f[j][2] * ws[2];
+      }
+    }
+    s = group_sum<16>(s);
+    if (sub == 0) y[q] = c[q] - s;
+  }
+}
+void launch_vel_correct32(hipStream_t st, int64_t N2, const int64_t* padj_ptr, const int32_t* padj, const float* avp, const double* dp,
+                          const double* dinv, const double* vs, double* dv) {
+  int64_t blocks = (N2 + 31) / 32;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(k_vel_correct32, dim3((unsigned)blocks), dim3(256), 0, st, N2, padj_ptr, padj, avp, dp, dinv, vs, dv);
+}
+void launch_pres_rhs32(hipStream_t st, int64_t V, const int32_t* vrank, const int64_t* nadj_ptr, const int32_t* nadj,
+                       const int64_t* rowptr_pv, const float* apv, const double* w, const double* c, double* y) {
+  int64_t blocks = (V + 15) / 16;
+  if (blocks > 32768) blocks = 32768;
+  hipLaunchKernelGGL(k_pres_rhs32, dim3((unsigned)blocks), dim3(256), 0, st, V, vrank, nadj_ptr, nadj, rowptr_pv, apv, w, c, y);
+}
 // y = alpha * (App x)[q] + beta * (Apv~ w)[q] + gamma * c[q]: pressure-row products (Schur operator, pressure rhs).
 // One wave per pressure row.
 __global__ __launch_bounds__(256) void k_pres_rows(int64_t V, const int64_t* __restrict__ rowptr_pp,

@@ -425,8 +425,11 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
     ctx->inner_its[0] += ctx->cheb_its_s + ctx->cheb_its_f;
   }
   // pressure: S dp = rp - Apv~ vs,  S x = App x - Apv~ D^-1 Avp x
-  launch_pres_rows(st, V, ctx->rowptr_pp.p, ctx->cols_pp.p, ctx->App.p, nullptr, 0.0, ctx->rowptr_pv.p, ctx->cols_pv.p,
-                   ctx->Apv.p, vs, -1.0, rp, 1.0, tp);
+  if (ctx->pv32_ok)
+    launch_pres_rhs32(st, V, ctx->vrank.p, ctx->nadj_ptr.p, ctx->nadj.p, ctx->rowptr_pv.p, ctx->Apv32.p, vs, rp, tp);
+  else
+    launch_pres_rows(st, V, ctx->rowptr_pp.p, ctx->cols_pp.p, ctx->App.p, nullptr, 0.0, ctx->rowptr_pv.p, ctx->cols_pv.p,
+                     ctx->Apv.p, vs, -1.0, rp, 1.0, tp);
   if (ctx->cheb_its_p > 0 && ctx->schur_fp32 && ctx->s_vals32.p) {
     // matrix values in FP32, vectors in FP64 (k_sweep_csr_mixed); schur_fp32 == 2: the all-FP32 sweep (measurement only)
     const double lmax = ctx->lmax_p, lmin = lmax / ctx->cheb_kappa_p, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
@@ -478,7 +481,10 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
                           ctx->inner_rtol, ctx->inner_maxit_p, &ctx->inner_its[1]));
   }
   // velocity correction and displacement
-  launch_vel_correct(st, n3, ctx->rowptr_vp.p, ctx->cols_vp.p, ctx->Avp.p, dp, ctx->diagpos3.p, ctx->Mvv.vals.p, vs, dv, ctx->vv_dinv.p);
+  if (ctx->pv32_ok)
+    launch_vel_correct32(st, N2, ctx->padj_ptr.p, ctx->padj.p, ctx->Avp32.p, dp, ctx->vv_dinv.p, vs, dv);
+  else
+    launch_vel_correct(st, n3, ctx->rowptr_vp.p, ctx->cols_vp.p, ctx->Avp.p, dp, ctx->diagpos3.p, ctx->Mvv.vals.p, vs, dv, ctx->vv_dinv.p);
   if (ctx->adv_is_db) {
     launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->adv_db.p, dv, w3, ctx->adv_rowmask.p);
     launch_axpby(st, td, 1.0, rd, -1.0, w3, n3);
@@ -1146,6 +1152,13 @@ int refresh_preconditioner(FsiCtx* ctx) {
       launch_extract_db(st, ctx->N2, npairs, ctx->nadj_ptr.p, ctx->rowptr3.p, ctx->Adv.p, ctx->adv_db.p, ctx->iflags.p, 1);
       HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
       ctx->adv_is_db = !(flags[1] & 8);
+      ctx->pv32_ok = false;
+      if (!(getenv("FSI_PV_FP32") && atoi(getenv("FSI_PV_FP32")) == 0)) {      // FP32 copies for the two block products of the pressure step
+        if (!ctx->Avp32.p) { HIPCHK(ctx->Avp32.alloc(ctx->Avp.n)); HIPCHK(ctx->Apv32.alloc(ctx->Apv.n)); }
+        launch_to_f32(st, (int64_t)ctx->Avp.n, ctx->Avp.p, ctx->Avp32.p);
+        launch_to_f32(st, (int64_t)ctx->Apv.n, ctx->Apv.p, ctx->Apv32.p);
+        ctx->pv32_ok = true;
+      }
       if (!ctx->vv_dinv.p) HIPCHK(ctx->vv_dinv.alloc(3 * ctx->N2));
       launch_diag_inverse(st, 3 * ctx->N2, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->vv_dinv.p);
       if (!ctx->adv_rowmask.p) HIPCHK(ctx->adv_rowmask.alloc(ctx->N2));
@@ -1383,7 +1396,7 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->sb_ptr.release(); ctx->sb_src.release(); ctx->sb_vals.release(); ctx->sb_dinv.release();
   ctx->sb_binv12.release(); ctx->sb_binv9.release();
   ctx->dd_db32.release(); ctx->vv_db32.release(); ctx->dd_dinv32.release(); ctx->vvf_dinv32.release();
-  ctx->adv_rowmask.release(); ctx->vv_dinv.release(); ctx->dd_chat.release(); ctx->ones32.release(); ctx->dd_rowflag.release(); ctx->dd_rec.release(); ctx->vv_rec.release(); ctx->sb_rec.release();
+  ctx->adv_rowmask.release(); ctx->vv_dinv.release(); ctx->Avp32.release(); ctx->Apv32.release(); ctx->dd_chat.release(); ctx->ones32.release(); ctx->dd_rowflag.release(); ctx->dd_rec.release(); ctx->vv_rec.release(); ctx->sb_rec.release();
   ctx->tile_ploc.release(); ctx->tile_uptr.release(); ctx->tile_ulist.release();
   for (auto* b : {&ctx->ss_rowptr, &ctx->ss_diagpos, &ctx->ss_src}) b->release();
   for (auto* b : {&ctx->node_solid, &ctx->vrank, &ctx->cols3, &ctx->cols_vp, &ctx->cols_pv, &ctx->cols_pp}) b->release();

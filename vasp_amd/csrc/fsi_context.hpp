@@ -270,6 +270,7 @@ struct FsiCtx {
   int64_t a32_ptail = 0, a32_tail_src = 0, a32_tail_nnz = 0;     // pressure rows: behind the padded node blocks, unpadded
   bool gcr_stagnated = false;                // the last cycle ended on 40 iterations without a 10 % gain
   int debug_prec_apply = 0;
+  fsi::DevBuf<float> Avp32, Apv32; bool pv32_ok = false;     // FSI_PV_FP32 (default on): FP32 copies for k_vel_correct32 / k_pres_rhs32
   fsi::DevBuf<double> vv_dinv;               // [3 N2] 1 / diag(Avv~), for the velocity correction
   fsi::DevBuf<uint8_t> adv_rowmask;          // [N2] 1: the node's A_dv rows have entries (solid nodes), 0: all zero, not streamed
   bool sweeps_fp16 = true;                   // FSI_SWEEPS_FP16=0: FP32 matrix values in the fine-level sweeps (k_sweep_tiled_f32 / k_sweep_sb_b3)

@@ -166,6 +166,10 @@ void launch_schur_full(hipStream_t st, int64_t V, const int64_t* s_rowptr, const
                        int32_t* flags);
 void launch_split(hipStream_t st, int64_t N2, int64_t V, const double* r, double* rd, double* rv, double* rp);
 void launch_merge(hipStream_t st, int64_t N2, int64_t V, const double* zd, const double* zv, const double* zp, double* z);
+void launch_vel_correct32(hipStream_t st, int64_t N2, const int64_t* padj_ptr, const int32_t* padj, const float* avp, const double* dp,
+                          const double* dinv, const double* vs, double* dv);
+void launch_pres_rhs32(hipStream_t st, int64_t V, const int32_t* vrank, const int64_t* nadj_ptr, const int32_t* nadj,
+                       const int64_t* rowptr_pv, const float* apv, const double* w, const double* c, double* y);
 void launch_vel_correct(hipStream_t st, int64_t n3, const int64_t* rowptr, const int32_t* cols, const double* vals,
                         const double* dp, const int64_t* diagpos3, const double* Avv, const double* vs, double* dv,
                         const double* dinv = nullptr);
