@@ -231,9 +231,10 @@ __global__ __launch_bounds__(256) void k_gcr_flush(double* __restrict__ Z, int64
 template <class QT>
 void dots_t(hipStream_t st, const void* Q, int64_t ldq, int64_t n, int m, const double* w, const double* r,
             double* scratch, double* out) {
+  static const int npmax = getenv("FSI_GCR_NP") ? atoi(getenv("FSI_GCR_NP")) : 128;      // 128: 3 000 workgroups at m = 180 (64: 4 % slower, 256: same)
   int np = (int)((n + 16383) / 16384);
   if (np < 1) np = 1;
-  if (np > 64) np = 64;
+  if (np > npmax) np = npmax;
   constexpr int NC = sizeof(QT) == 4 ? 8 : 4;
   const int ngroups = (m + NC - 1) / NC;
   hipLaunchKernelGGL((k_gcr_dots<QT, NC>), dim3(np, ngroups + 1), dim3(256), 0, st, static_cast<const QT*>(Q), ldq, n, m, w, r, scratch);
@@ -244,7 +245,7 @@ void axpy_t(hipStream_t st, const void* Q, int64_t ldq, int64_t n, int m, const 
             double* scratch, double* out2) {
   int64_t blocks = ((n >> 2) + 255) / 256;
   if (blocks < 1) blocks = 1;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 2048) blocks = 2048;               // 1024 ... 8192 measured: no difference
   hipLaunchKernelGGL(k_gcr_axpy<QT>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const QT*>(Q), ldq, n, m, h, w, r, scratch);
   hipLaunchKernelGGL(k_gcr_sum, dim3(2), dim3(256), 0, st, scratch, (int)blocks, out2);
 }
