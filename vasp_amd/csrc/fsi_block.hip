@@ -1000,7 +1000,6 @@ __global__ __launch_bounds__(256) void k_sweep_sb_h(int64_t nS, const int64_t* _
 void launch_sweep_sb_h(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const void* rec, const float* binv12, float c1, float c2,
                        const float* din, float* dout, float* x, float* r) {
   int64_t blocks = (nS + 15) / 16;
-  if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(k_sweep_sb_h, dim3((unsigned)blocks), dim3(256), 0, st, nS, sb_ptr, static_cast<const uint2*>(rec), binv12, c1, c2, din, dout, x, r);
 }
 
@@ -1218,7 +1217,6 @@ void launch_extract_db(hipStream_t st, int64_t N2, int64_t npairs, const int64_t
 void launch_spmv_db(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
                     const double* x, double* y, const uint8_t* rowmask) {
   int64_t blocks = (N2 + 15) / 16;
-  if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(k_spmv_db, dim3((unsigned)blocks), dim3(256), 0, st, N2, nadj_ptr, nadj, db, rowmask, x, y);
 }
 

@@ -358,7 +358,6 @@ void launch_spmv_compact(hipStream_t st, int64_t N2, int64_t V, const int64_t* r
   hipLaunchKernelGGL(k_spmv_compact, dim3((unsigned)blocks), dim3(256), 0, st, N2, nadj_ptr, nadj, padj_ptr, padj, cA, cP, x, y);
   if (V > 0) {                                                  // pressure rows: the generic kernel on the tail of the full matrix
     int64_t pb = (V + 3) / 4;
-    if (pb > 8192) pb = 8192;
     hipLaunchKernelGGL(k_spmv<SPMV_MONOLITHIC>, dim3((unsigned)pb), dim3(256), 0, st, V, rowptr + 6 * N2, cols, A, x, y + 6 * N2);
   }
 }
@@ -366,14 +365,12 @@ template <class VT>
 static void spmv_node6_any(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const VT* vals,
                            const double* x, double* y) {
   static const bool xcd = !(getenv("FSI_SPMV_XCD") && atoi(getenv("FSI_SPMV_XCD")) == 0);
-  int64_t blocks = (N2 + 3) / 4;
-  if (blocks > 8192) blocks = 8192;
+  int64_t blocks = (N2 + 3) / 4;                                 // one wave per node (see launch_spmv_node6p)
   blocks = (blocks + 7) & ~(int64_t)7;
   if (xcd) hipLaunchKernelGGL((k_spmv_node6<VT, true>), dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, cols, vals, x, y);
   else hipLaunchKernelGGL((k_spmv_node6<VT, false>), dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, cols, vals, x, y);
   if (V > 0) {                                                  // pressure rows: the generic kernel on the tail of the matrix
     int64_t pb = (V + 3) / 4;
-    if (pb > 8192) pb = 8192;
     hipLaunchKernelGGL((k_spmv<SPMV_MONOLITHIC, VT>), dim3((unsigned)pb), dim3(256), 0, st, V, rowptr + 6 * N2, cols, vals, x, y + 6 * N2);
   }
 }
@@ -466,14 +463,16 @@ void launch_pad_vals32(hipStream_t st, int64_t N2, int64_t V, const int64_t* row
 void launch_spmv_node6p(hipStream_t st, int64_t N2, int64_t V, const int64_t* p32, const int32_t* cols32, const float* vals,
                         const int64_t* rowptr, const int32_t* cols, int64_t tail_shift, const double* x, double* y) {
   static const bool xcd = !(getenv("FSI_SPMV_XCD") && atoi(getenv("FSI_SPMV_XCD")) == 0);
+  // one wave per node, no grid-stride loop: measured 1.87 ms per product against 2.23 ms with 8192 workgroups looping
+  // (row lengths differ by 3x between edge and vertex nodes; the hardware scheduler balances what a static stride cannot)
+  static const int64_t bmax = getenv("FSI_SPMV_BLOCKS") ? atoi(getenv("FSI_SPMV_BLOCKS")) : (int64_t)1 << 30;
   int64_t blocks = (N2 + 3) / 4;
-  if (blocks > 8192) blocks = 8192;
+  if (blocks > bmax) blocks = bmax;
   blocks = (blocks + 7) & ~(int64_t)7;
   if (xcd) hipLaunchKernelGGL(k_spmv_node6p<true>, dim3((unsigned)blocks), dim3(256), 0, st, N2, p32, cols32, vals, x, y);
   else hipLaunchKernelGGL(k_spmv_node6p<false>, dim3((unsigned)blocks), dim3(256), 0, st, N2, p32, cols32, vals, x, y);
   if (V > 0) {
     int64_t pb = (V + 3) / 4;
-    if (pb > 8192) pb = 8192;
     // the generic kernel indexes values and columns with the same pointer: hand it the value array shifted so that
     // vals32[rowptr[row]] is the row's first value
     hipLaunchKernelGGL((k_spmv<SPMV_MONOLITHIC, float>), dim3((unsigned)pb), dim3(256), 0, st, V, rowptr + 6 * N2, cols, vals + tail_shift, x, y + 6 * N2);
