@@ -36,7 +36,11 @@ established on the cylinder case (1 647 tets, 3 steps), where every step is chea
 6. what the gap looks like as data (round 2, last study): a factor on the interface load of 1 + 2.144e-5, 1 + 4.163e-5,
    1 + 5.676e-5 at steps 1, 2, 3 lands d_x on its three pins exactly and then v_x on its pins to 1.3e-9 relative (v follows
    from the d history through the penalty row), but the same run leaves d_y and d_z of the predeform pins 9.5e-5 and 4.2e-5
-   off (unfitted: -6.0e-5, +3.0e-5, -1.8e-5 for x, y, z): the difference is a field, not a scale factor of the response.  In
+   off (unfitted: -6.0e-5, +3.0e-5, -1.8e-5 for x, y, z): the difference is a field, not a scale factor of the response
+   (the tube's axis is y, vertex 0 sits on the interface at mid-length: at step 3 the gap is -1.9e-5 of the radial displacement plus a
+   circumferential part 45 % as large, where the displacement itself is 3.8 % circumferential - every global change of a
+   parameter, the load or a weight of the old / new stress term moves x, y, z alike, so the difference looks local and
+   mesh-dependent, like the Laplace footprint of item 2).  In
    load units it grows like 1 : 7.76 : 23.8 over the three steps - faster than the load (1 : 4 : 9) or the displacement
    (1 : 3.16 : 6.16) - and no term of the restated equations has that size and shape: convection and the ALE term together
    move d_x by 5e-7 .. 5e-6, the four quadratic pieces of the solid stress (lambda tr(eps) g, 2 mu g eps, lambda/2 |g|^2 I,
