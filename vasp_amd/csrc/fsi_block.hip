@@ -1624,33 +1624,18 @@ __global__ __launch_bounds__(256) void k_sweep_schur_tiled(int64_t n, const int6
   for (int i = threadIdx.x; i <= nrows; i += 256) sptr[i] = rowptr[r0 + i];
   __syncthreads();
   const int sub = threadIdx.x & 7, g = threadIdx.x >> 3;          // 8 lanes per row, 32 rows per pass
-  // the records of the next pass's row are requested before this pass's are used (same-box A/B: 22.9 against 23.7 us)
-  uint32_t q[8];
-  int64_t e0 = 0, b = 0;
-  if (g < nrows) { e0 = sptr[g] + sub; b = sptr[g + 1]; }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) q[j] = e0 + 8 * j < b ? rec[e0 + 8 * j] : 0u;        // zero record: value +0, local index 0
   for (int row = g; row < nrows; row += 32) {
-    uint32_t qn[8];
-    int64_t en = 0, bn = 0;
-    if (row + 32 < nrows) { en = sptr[row + 32] + sub; bn = sptr[row + 33]; }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) qn[j] = en + 8 * j < bn ? rec[en + 8 * j] : 0u;
+    const int64_t b = sptr[row + 1];
     double s = 0.0;
+    for (int64_t e = sptr[row] + sub; e < b; e += 64) {
+      uint32_t q[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s += (double)h2f(q[j] & 0xffffu) * sxd[q[j] >> 16];
-    for (int64_t e = e0 + 64; e < b; e += 64) {                                    // rows beyond 64 entries
-      uint32_t t[8];
+      for (int j = 0; j < 8; ++j) q[j] = e + 8 * j < b ? rec[e + 8 * j] : 0u;      // zero record: value +0, local index 0
 #pragma unroll
-      for (int j = 0; j < 8; ++j) t[j] = e + 8 * j < b ? rec[e + 8 * j] : 0u;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += (double)h2f(t[j] & 0xffffu) * sxd[t[j] >> 16];
+      for (int j = 0; j < 8; ++j) s += (double)h2f(q[j] & 0xffffu) * sxd[q[j] >> 16];
     }
     s = group_sum<8>(s);
     if (sub == 0) ssum[row] = s;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) q[j] = qn[j];
-    e0 = en; b = bn;
   }
   __syncthreads();
   if ((int)threadIdx.x < nrows) {
