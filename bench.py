@@ -39,6 +39,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_STORAGE_ENV = {"FSI_KRYLOV_FP32": "0", "FSI_OPERATOR_FP32": "0", "FSI_SCHUR_FP32": "0", "FSI_SWEEPS_FP16": "0"}
 
 
 def self_launch(args) -> int:
@@ -48,10 +49,29 @@ def self_launch(args) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()),
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--tets", str(args.tets),
-           "--dt", str(args.dt)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+           "--dt", str(args.dt), "--storage", args.storage] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+def fp64_storage_run(args) -> dict:
+    """The same workload once more in a fresh child process with every storage-precision choice switched off
+    (FP64_STORAGE_ENV): BASELINE.json configs[1] says "FP64", and the headline run keeps the Krylov basis, the Jacobian
+    copy of the inner products and the preconditioner matrices in FP32 / FP16 storage (all arithmetic on the Newton level
+    and every linear-solve verdict is FP64 in both).  This process has released its context before the child starts."""
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--tets", str(args.tets), "--dt", str(args.dt), "--no-cpu-baseline", "--storage", "fp64", "--no-fp64-line"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    t0 = time.perf_counter()
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True)
+    line = next((ln for ln in reversed(res.stdout.splitlines()) if ln.startswith("{")), None)
+    if res.returncode != 0 or line is None:
+        return {"error": f"child exited with {res.returncode}", "stderr_tail": res.stderr[-400:]}
+    j = json.loads(line)
+    return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "newton_iterations": j["newton_iterations"],
+            "krylov_iterations": j["krylov_iterations"], "phase_ms": j["phase_ms"], "env": FP64_STORAGE_ENV,
+            "storage_precisions": j["config"]["storage_precisions"], "roofline": j["roofline"], "wall_s": time.perf_counter() - t0}
 
 
 def cpu_baseline(budget_s: float = 25.0):
@@ -71,7 +91,13 @@ def main():
     ap.add_argument("--tets", type=int, default=int(os.environ.get("VASPFSI_BENCH_TETS", 1000000)))
     ap.add_argument("--dt", type=float, default=1e-3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--storage", choices=("default", "fp64"), default="default",
+                    help="fp64: every storage-precision choice off (FP64 Krylov basis, FP64 Jacobian in every product, FP64 "
+                         "Schur sweeps, FP32 instead of FP16 sweep matrices) - BASELINE.json configs[1] read literally")
+    ap.add_argument("--no-fp64-line", action="store_true", help="skip the second run that fills value_fp64_storage")
     args = ap.parse_args()
+    if args.storage == "fp64":           # read by fsi_create (getenv), so set before the library is touched
+        os.environ.update(FP64_STORAGE_ENV)
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
@@ -110,8 +136,6 @@ def main():
         fn.backend, fn.which = hb, which
     ns["backend"] = hb
     ns_cheb = (int(os.environ.get("FSI_CHEB_S", 300)), int(os.environ.get("FSI_CHEB_F", 4)))
-    solid_fp32 = int(os.environ.get("FSI_SOLID_FP32", 1)) != 0
-    solid_fused = solid_fp32 and int(os.environ.get("FSI_SOLID_BJ", 1)) != 0 and int(os.environ.get("FSI_SOLID_FUSED", 1)) != 0
     mesh = ns["mesh"]
     setup_s = time.perf_counter() - t_setup
     sink = io.StringIO()
@@ -157,6 +181,7 @@ def main():
         ndof_rank = hb.part.ndof if partitioned else ndof
         # ---- per kernel group: (GPU time attributed in the timed region [ms], launches, algorithmic bytes per launch) ----
         # (sweep kernels: average of sampled HIP-event launches x launches, the rest: every launch timed)
+        solid_fp32, solid_fused = bool(int(tm.get("sweep_flags", 0)) & 4), bool(int(tm.get("sweep_flags", 0)) & 8)
         f_launches = tm["precond_applies"] * ns_cheb[1]                                # fluid velocity sweeps
         sweeps = max(0, tm["inner_vv_iters"] - f_launches)                              # fine-level solid sweeps
         ss_avg = tm["solid_spmv_ms"] / max(1, tm["solid_spmv_calls"])
@@ -170,11 +195,12 @@ def main():
                    (tm["db_pairs"] * 8.0 + tm["db_nodes"] * 43.0)
         dbf_bytes = (tm["db_pairs"] * 14.0 + tm["tile_entries"] * 20.0 + tm["db_nodes"] * 24.0) if tiled else \
                     (tm["db_pairs"] * 16.0 + tm["db_nodes"] * 40.0)
-        fused = tiled and os.environ.get("FSI_FUSED_SWEEPS") != "0"     # product + Chebyshev update in one launch (default)
+        flags = int(tm.get("sweep_flags", 0))                            # the context's actual state (FsiTimers.sweep_flags)
+        fused = tiled and bool(flags & 1)                                # product + Chebyshev update in one launch (default)
         if fused:                                                        # + d, r, x read, x, r, d' written, product not stored
             sc_bytes += tm["db_nodes"] * 80.0
             dbf_bytes += tm["db_nodes"] * 96.0                            # and the float4 Jacobi scaling
-        fp16 = fused and os.environ.get("FSI_SWEEPS_FP16") != "0"        # packed FP16 records: 4 / 8 bytes per pair, 24 per solid block
+        fp16 = fused and bool(flags & 2)                                 # packed FP16 records: 4 / 8 bytes per pair, 24 per solid block
         if fp16:
             sc_bytes -= tm["db_pairs"] * 2.0
             dbf_bytes -= tm["db_pairs"] * 6.0
@@ -238,8 +264,9 @@ def main():
         # HBM traffic per launch from the PMC passes of this same command (tools/gpu_pmc_r2.sh -> profiles/r02_pmc_traffic.json:
         # 2 x FETCH_SIZE + WRITE_SIZE, the factors calibrated on known-byte streams); a group of kernels is averaged over its
         # launches
-        traffic = None
-        pmc = ROOT / "profiles" / "r02_pmc_traffic.json"
+        traffic, traffic_source = None, None
+        pmc = next((q for q in (ROOT / "profiles" / "r03_pmc_traffic.json", ROOT / "profiles" / "r02_pmc_traffic.json") if q.exists()),
+                   ROOT / "profiles" / "r03_pmc_traffic.json")
         groups = {"k_gcr_dots": [f"k_gcr_dots<{'double' if qb == 8 else 'float'}", f"k_gcr_axpy<{'double' if qb == 8 else 'float'}"],
                   "k_gcr_flush": ["k_gcr_flush<"],
                   "k_spmv_node6": ["k_spmv_node6<", "k_spmv_node6p<", "k_spmv<0,"], "k_spmv_compact": ["k_spmv_compact", "k_spmv<0,"],
@@ -250,7 +277,15 @@ def main():
                   "k_residual": ["k_residual"], "k_jacobian": ["k_jacobian<2>"]}
         if pmc.exists():
             with contextlib.suppress(Exception):
-                det = json.loads(pmc.read_text()).get("detail", {})
+                pj = json.loads(pmc.read_text())
+                det = pj.get("detail", {})
+                # the counters were collected on one workload: they describe this run only if it is the same one (fetch + write
+                # bytes per launch, FETCH_SIZE x 1024 x 2 and WRITE_SIZE x 1024 as calibrated in tools/gpu_pmc_r2.sh)
+                same = pj.get("tets") in (None, C) and pj.get("dofs") in (None, ndof) and world == 1
+                traffic_source = f"profiles/{pmc.name}" + ("" if pj.get("tets") else " (size not recorded: 1.12 M-tet bench mesh)")
+                if (pj.get("tets") is None and C != 1123200) or not same:
+                    det = {}
+                    traffic_source = None
                 for key, names in groups.items():
                     if dom.startswith(key):
                         # a name that ends inside its template argument list matches every instantiation
@@ -281,8 +316,8 @@ def main():
                                               f"FP{8 * qb}" + (" with an FP64 window of 32 columns" if qb == 4 else "")
                                               + f"; {op32} of {int(tm['spmv_calls'])} outer products on an FP32 copy of the Jacobian values, "
                                               "every linear answer judged on the FP64 residual of the FP64 matrix; preconditioner "
-                                              "sweeps: " + ("FP16" if fp16 else "FP32") + " matrix values, FP32 vectors (Schur: FP32 values, "
-                                              "FP64 vectors)")},
+                                              "sweeps: " + ("FP16" if fp16 else "FP32") + " matrix values, FP32 vectors (Schur: "
+                                              + {0: "FP16", 4: "FP32", 8: "FP64"}[int(tm["schur_elem_bytes"])] + " values, FP64 vectors)")},
             "dof_updates_per_s": total_newton * ndof / elapsed,
             "newton_iterations": n_newton, "krylov_iterations": n_krylov, "krylov_per_solve": krylov_per_solve,
             "phase_ms": {k: tm[k] for k in ("residual_ms", "jacobian_ms", "factor_ms", "spmv_ms", "precond_ms", "ortho_ms", "flush_ms", "krylov_ms")},
@@ -291,15 +326,23 @@ def main():
                                                "ortho_q_launches", "ortho_q_cols", "ortho_z_launches", "ortho_z_cols")},
             "setup_s": setup_s,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": d["frac_of_hbm_peak"], "traffic": traffic, "launches": d["launches"],
+                         "frac": d["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
+                         "launches": d["launches"],
                          "avg_launch_ms": d["avg_launch_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                          "share_of_timed_region": d["share_of_timed_region"]},
             "kernels": table,
         }
+    hb.close()                 # the context's HBM (Krylov store, matrices) is free again before anything else runs
+    if rank == 0:
+        out["config"]["storage"] = args.storage
+        if world == 1 and args.storage == "default" and not args.no_fp64_line:
+            f64 = fp64_storage_run(args)
+            out["value_fp64_storage"] = f64.get("value")        # Newton-iterations/s of the same 20 steps, all-FP64 storage
+            out["ms_per_step_fp64_storage"] = f64.get("ms_per_step")
+            out["fp64_storage"] = f64
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    hb.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -69,14 +69,16 @@ typedef struct FsiNewtonOpts {
   int32_t counter;             /* time-step counter of this call                                            */
   int32_t first_step_num;      /* counter value of the first step of this run (forces a Jacobian)           */
   double lin_rtol;             /* Krylov stop: ||r|| <= eta ||b|| (row-equilibrated norms),                  */
-                               /* eta = max(lin_rtol, min(1e-2, 1e-3 atol / ||b||_newton))  (inexact Newton) */
+                               /* eta = max(lin_rtol, min(1e-2, f atol / ||b||_newton)), f = 1e-2 unless      */
+                               /* fsi_set_newton_forcing changed it (f = 0: eta = lin_rtol, the direct-LU    */
+                               /* policy of the reference)                               (inexact Newton)   */
   int32_t lin_max_it;          /* Krylov iteration cap per linear solve                                     */
   int32_t lin_solver;          /* 0 = GCR with recycled directions, 1 = BiCGStab                            */
 } FsiNewtonOpts;
 
 typedef struct FsiNewtonIter {
   double residual;             /* ||b||_2   ("r (atol)")                                                    */
-  double rel_res;              /* ||du||_2  ("r (rel)")                                                     */
+  double rel_res;              /* ||du||_L2(Omega), dolfin.norm(Function, 'l2')  ("r (rel)")                */
   int32_t recomputed;          /* 1 if "Compute Jacobian matrix" happened before this iteration             */
   int32_t lin_iters;           /* Krylov iterations (new directions) of this iteration's linear solve       */
   double lin_relres;           /* achieved ||r||/||b||                                                      */
@@ -232,6 +234,11 @@ typedef struct FsiTimers {
   int64_t spmv_compact;                              /* 1: the outer product runs on the compact node rows            */
   int64_t node_pairs;    int64_t node_vertex_pairs;  /* P2 node pairs / node-vertex pairs of the matrix graph         */
   int64_t spmv_fp32_calls;                           /* outer products that ran on the FP32 copy of the matrix        */
+  int64_t sweep_flags;                               /* what the preconditioner sweeps actually run as (the context's
+                                                        state, not the environment's): bit 0 tiled sweeps fused with
+                                                        the Chebyshev update, 1 FP16 packed records, 2 solid block in
+                                                        FP32, 3 solid sweeps fused (block Jacobi), 4 solid two-level
+                                                        cycle ready, 5 displacement two-level cycle ready            */
 } FsiTimers;
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
 /* Measurement aid: streams `bytes` of the (idle) Krylov store once per kernel with 4-, 8-, 16- and 32-byte loads and

@@ -10,6 +10,10 @@ from conftest import GOLDEN, prepare_case
 
 pytestmark = pytest.mark.gpu
 
+# production defaults (mixed storage, forcing 1e-2) against exact solves on the known-answer case, per field; see
+# test_production_storage_precisions_do_not_change_the_result (values measured on MI355X are in DESIGN.md section 2)
+PRODUCTION_VS_EXACT_BOUND = {"d": 2e-5, "v": 2e-5, "p": 2e-5}
+
 
 def random_state(mesh, ndof, seed=0):
     rng = np.random.default_rng(seed)
@@ -120,18 +124,14 @@ def test_cylinder_three_steps_match_converged_golden(cylinder_case):
     hb.close()
 
 
-def test_offset_stenosis_known_answer_on_gpu(stenosis_case):
-    """The reference's primary known-answer test [REF tests/test_simulations.py:17-57] through the HIP path with the
+@pytest.fixture(scope="module")
+def known_answer_run(stenosis_case):
+    """The reference's primary known-answer case [REF tests/test_simulations.py:17-57] through the HIP path with the
     reference's Newton policy: tolerances 1e-6, Jacobian reuse, and every Newton system solved (forcing = 0: to 1e-10, the
-    stand-in for the reference's direct LU).  The HIP path must then follow the ORACLE's run of the same policy
-    (tests/golden/stenosis_ref.npz) iteration by iteration; against the reference's pins it inherits the oracle's
-    measured gap (tests/test_oracle_pins.py), bounded here at the same values."""
-    from test_oracle_pins import PIN_D, PIN_P, PIN_V, probe
+    stand-in for the reference's direct LU).  Returns (final state, Newton iterations per step)."""
     from vasp_amd.capi import HipBackend
     ns, desc, bc_values, pressure, hook = stenosis_case
-    mesh = ns["mesh"]
     hb = HipBackend(desc, lin_rtol=1e-10, newton_forcing=0.0)
-    gold = np.load(GOLDEN / "stenosis_ref.npz")
     its = []
     for k in range(5):
         g, P = boundary_data(stenosis_case, 0.01 * (k + 1))
@@ -141,6 +141,18 @@ def test_offset_stenosis_known_answer_on_gpu(stenosis_case):
         its.append(len(h))
         hb.shift()
     U = hb.get_state("n")
+    hb.close()
+    return U, its
+
+
+def test_offset_stenosis_known_answer_on_gpu(stenosis_case, known_answer_run):
+    """The HIP path must follow the ORACLE's run of the reference's policy (tests/golden/stenosis_ref.npz) iteration by
+    iteration; against the reference's pins it inherits the oracle's measured gap (tests/test_oracle_pins.py), bounded here
+    at the same values.  The reference's own tolerances are held by the strict-xfail test below."""
+    from test_oracle_pins import PIN_D, PIN_P, PIN_V, probe
+    ns, mesh = stenosis_case[0], stenosis_case[0]["mesh"]
+    U, its = known_answer_run
+    gold = np.load(GOLDEN / "stenosis_ref.npz")
     assert its == [int(i) for i in gold["iterations"]], (its, gold["iterations"])      # same quasi-Newton trajectory: 3 4 8 11 5
     G = gold["states"][4]
     N2 = mesh.num_nodes
@@ -153,6 +165,43 @@ def test_offset_stenosis_known_answer_on_gpu(stenosis_case):
     assert np.abs(v - PIN_V).max() < 4.8e-7, (v, PIN_V)
     assert abs(p - PIN_P) < 3.9e-4, (p, PIN_P)
     assert np.abs(d - PIN_D).max() < 1.4e-8, (d, PIN_D)
+
+
+@pytest.mark.xfail(strict=True, reason="the restated equations miss the reference's pins by 2.6e-5 (v) / 7e-4 (p); "
+                                       "DESIGN.md section 2 - flips together with tests/test_oracle_pins.py")
+def test_reference_tolerance_on_offset_stenosis_pins_on_gpu(stenosis_case, known_answer_run):
+    """The reference's asserts VERBATIM [REF tests/test_simulations.py:43-44,57: np.isclose defaults, rtol 1e-5 / atol 1e-8]
+    on the HIP path's output.  VERDICT r2 item 1a: the HIP side must flip with the oracle the day the gap closes."""
+    from test_oracle_pins import PIN_D, PIN_P, PIN_V, probe
+    ns, mesh = stenosis_case[0], stenosis_case[0]["mesh"]
+    U, _ = known_answer_run
+    v = probe(mesh, U, ns["probe_points"][5], 1)
+    p = probe(mesh, U, ns["probe_points"][5], 2)
+    d = probe(mesh, U, ns["solid_probe_points"][5], 0)
+    assert np.isclose(v, PIN_V).all()
+    assert np.isclose(p, PIN_P)
+    assert np.isclose(d, PIN_D).all()
+
+
+def test_forced_fp32_basis_reports_instead_of_overrunning(cylinder_case, monkeypatch):
+    """FSI_KRYLOV_FP32=1 sizes the basis store for 4-byte columns.  A tolerance FP32 storage cannot reach used to
+    switch to 8-byte columns in that same store (writes past the allocation); now the solve either succeeds in FP32 or
+    returns FSI_ERR_LINEAR with a message that names the switch - and the context stays usable."""
+    from vasp_amd.capi import FsiError, HipBackend
+    monkeypatch.setenv("FSI_KRYLOV_FP32", "1")
+    hb = HipBackend(cylinder_case[1], lin_rtol=1e-14, newton_forcing=0.0)
+    g, P = boundary_data(cylinder_case, 1e-3)
+    hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+    hb.assemble_residual(); hb.assemble_jacobian()
+    assert hb.timers()["q_elem_bytes"] == 4
+    try:
+        it, rr = hb.solve(lin_rtol=1e-14, lin_max_it=400)
+        assert rr <= 1e-12                                   # it may get there through restarts; then the answer is good
+    except FsiError as e:
+        assert e.code == 4 and ("FSI_KRYLOV_FP32" in str(e) or "GCR" in str(e)), (e.code, str(e))
+    it, rr = hb.solve(lin_rtol=1e-6)                         # the context is intact: a tolerance FP32 storage reaches
+    assert rr <= 1e-6
+    assert hb.timers()["q_elem_bytes"] == 4                  # and it never left the 4-byte layout
     hb.close()
 
 
@@ -187,10 +236,21 @@ def test_production_storage_precisions_do_not_change_the_result(stenosis_case, m
     U_ref, its_ref, kry_ref, tm_ref = run(lin_rtol=1e-10, newton_forcing=0.0)
     assert tm_ref["q_elem_bytes"] == 8 and tm_ref["spmv_fp32_calls"] == 0
     N2 = mesh.num_nodes
+    errs = {}
     for name, sl in (("d", slice(0, 3 * N2)), ("v", slice(3 * N2, 6 * N2)), ("p", slice(6 * N2, None))):
-        err = np.linalg.norm(U_prod[sl] - U_ref[sl]) / np.linalg.norm(U_ref[sl])
-        assert err < 2e-5, (name, err)                 # the policy's own stopping tolerance (1e-6 on the update) times its history
+        errs[name] = float(np.linalg.norm(U_prod[sl] - U_ref[sl]) / np.linalg.norm(U_ref[sl]))
+    print("production defaults vs exact solves, relative l2 distance per field:", errs)
     print("Newton iterations per step", its_prod, "vs exact solves", its_ref, "| Krylov iterations", kry_prod, "vs", kry_ref)
+    with contextlib.suppress(OSError):                 # kept with the round's measurements
+        import json
+        from conftest import ROOT
+        (ROOT / "gpurun_out").mkdir(exist_ok=True)
+        (ROOT / "gpurun_out" / "production_vs_exact.json").write_text(json.dumps(
+            dict(errors=errs, newton_prod=its_prod, newton_exact=its_ref, krylov_prod=kry_prod, krylov_exact=kry_ref)))
+    # Bounds = the measured distances (MI355X, round 3) with 2x head room; they are the policy's own stopping tolerance
+    # (1e-6 on the update, inexact solves with forcing 1e-2) accumulated over five steps, per field:
+    for name, bound in PRODUCTION_VS_EXACT_BOUND.items():
+        assert errs[name] < bound, (name, errs[name], bound)
 
 
 def test_robin_terms_match_oracle(tmp_path):

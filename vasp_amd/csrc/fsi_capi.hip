@@ -1033,9 +1033,22 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
     if (!(rnorm < 0.5 * rstart)) {
       // the cycle did not bring the true residual down: FP32 storage has lost this system (a tolerance near round-off,
       // or a cancellation the FP64 window did not cover).  Drop the kept directions and finish in FP64 from here.
+      if (ctx->kry_fp32_policy == 1) {
+        // FSI_KRYLOV_FP32=1 sized the basis store for 4-byte columns: there is no FP64 store to fall back to, and
+        // addressing it with 8-byte columns would run past the allocation.  The policy was forced, so say so.
+        char buf[200];
+        snprintf(buf, sizeof buf, "GCR: the FP32 Krylov basis forced by FSI_KRYLOV_FP32=1 cannot reach rtol %.1e on this system "
+                 "(true residual %.3e of |b| after a cycle); use the default policy", rtol, rnorm / bnorm);
+        ctx->err = buf;
+        *relres = rnorm / bnorm;
+        return FSI_ERR_LINEAR;
+      }
       gcr_reset(ctx);
       ctx->kry_fp32 = 0;
-      if (ctx->kry_fp32_policy == 2) ctx->kry_fp32_policy = 3;      // stays FP64 for the rest of this context's life
+      if (ctx->kry_fp32_policy == 2) {      // FP64 for the rest of this Jacobian's life; re-armed at the next refresh (twice at most)
+        ctx->kry_fp32_policy = 3;
+        ctx->kry_fp32_failures += 1;
+      }
     }
     rstart = rnorm;
   }
@@ -2401,6 +2414,12 @@ int fsi_assemble_jacobian(FsiCtx* ctx) {
     ctx->op32_ok = true;
   }
   gcr_reset(ctx);          // the recycled directions belong to the previous matrix
+  // what decides the storage precision of the basis belongs to the Jacobian that has just been replaced: the largest
+  // right-hand side seen (one large early |b|, e.g. the first step from rest, must not keep tol_hint low for the whole run)
+  // and a fall-back to FP64 after a failed cycle (a system that lost FP32 once may not lose it with the next matrix; after
+  // two such failures the context stays FP64)
+  ctx->bnorm_max = 0.0;
+  if (ctx->kry_fp32_policy == 3 && ctx->kry_fp32_failures < 2) ctx->kry_fp32_policy = 2;
   ctx->have_jacobian = true;
   ctx->have_monolithic_lu = false;
   const int rc = refresh_preconditioner(ctx);
@@ -2725,7 +2744,10 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
                    (int64_t)ctx->s_cols.n, ctx->V, ctx->t_flush.ms, ctx->t_flush.calls, ctx->t_sch.ms, ctx->t_sch.calls,
                    (int64_t)((ctx->schur_fp32 && ctx->s_vals32.p) ? ((ctx->schur_tiled && ctx->sweeps_fp16 && ctx->s_rec.p) ? 0 : 4) : 8),
                    (int64_t)(ctx->compact_ok && ctx->spmv_compact ? 1 : 0), (int64_t)ctx->h_nadj.size(), (int64_t)ctx->h_padj.size(),
-                   ctx->op32_products};
+                   ctx->op32_products,
+                   (int64_t)((ctx->tiled && ctx->fused_sweeps ? 1 : 0) | (ctx->tiled && ctx->fused_sweeps && ctx->sweeps_fp16 ? 2 : 0) |
+                             (ctx->solid_fp32 ? 4 : 0) | (ctx->solid_fp32 && ctx->solid_block_jacobi && ctx->solid_fused ? 8 : 0) |
+                             (ctx->sbmg_ready ? 16 : 0) | (ctx->mg_ready ? 32 : 0))};
   if (reset) {
     for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_flush, &ctx->t_sch, &ctx->t_kry, &ctx->t_ss, &ctx->t_db, &ctx->t_sc}) {
       t->ms = 0.0;

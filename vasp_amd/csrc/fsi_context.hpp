@@ -277,6 +277,7 @@ struct FsiCtx {
   fsi::DevBuf<uint32_t> dd_rec, vv_rec, sb_rec;   // packed FP16 records: [pairs], [pairs][2], [blocks][6] 32-bit words
   bool fused_sweeps = true;                  // FSI_FUSED_SWEEPS=0: product and Chebyshev update of the FP32 sweeps as two launches
 
+  int kry_fp32_failures = 0;                 // cycles that lost the system in FP32 storage (policy 2 -> 3); two of them pin FP64
   double tol_hint = 0.0, bnorm_max = 0.0;     // fsi_newton_solve -> solve_gcr: lowest linear tolerance to expect; largest |b| seen
   double gcr_reorth = 0.0;                   // FSI_GCR_REORTH: second Gram-Schmidt pass when |w'| < reorth |w| (0: automatic)
   double newton_forcing = 1e-2;              // inexact Newton: linear tolerance = forcing * atol / |b| (FSI_NEWTON_FORCING; 1e-2: same Newton counts as 1e-3 on the bench, 18 % fewer Krylov iterations)

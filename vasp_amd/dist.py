@@ -35,3 +35,14 @@ def aggregate(dist, elapsed_s: float, units: float, device: str = "cpu"):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(t.item()), float(u.item())
+
+
+def agree_flags(dist, flags, device: str = "cpu"):
+    """Job-wide OR of rank-local booleans: every rank gets the same list (identity for a single process).  The time
+    loop's stop / pause controls go through here so that all ranks leave the loop in the same step."""
+    if dist is None:
+        return [bool(f) for f in flags]
+    import torch
+    t = torch.tensor([1.0 if f else 0.0 for f in flags], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [bool(v > 0.0) for v in t.cpu().tolist()]

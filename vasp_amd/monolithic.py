@@ -272,6 +272,35 @@ def advance(ns, backend, bc_values, pressure, hook, first_step_num: int, out=pri
     return hist
 
 
+def stop_controls(results: Path, killtime, t_loop: float, agree=None, rank0: bool = True, out=print,
+                  poll_s: float = 5.0) -> bool:
+    """turtleFSI's stop controls after a time step: the wall-clock budget ``killtime`` and the sentinel files a user drops
+    into the results folder (``killturtle``: checkpoint and stop; ``pauseturtle``: wait until it is removed).  Returns
+    True when the run has to write a checkpoint and stop.
+
+    Every rank looks at its own clock and at the shared folder; the job acts on the OR of the local flags (``agree``:
+    ``DistBackend.agree_flags``), so all ranks leave the loop - or enter the collective gather of the stop checkpoint - in
+    the same step.  turtleFSI sums the flag over MPI before acting for the same reason.  Rank 0 removes the sentinel only
+    after that agreement."""
+    import contextlib
+    agree = agree or (lambda flags: [bool(f) for f in flags])
+    late = killtime is not None and _time.perf_counter() - t_loop > float(killtime)
+    kill, late = agree([(results / "killturtle").exists(), late])
+    stop = False
+    if late:
+        out("Reached killtime = %s s: writing a checkpoint and stopping" % killtime)
+        stop = True
+    if kill:
+        out("killturtle found: writing a checkpoint and stopping")
+        if rank0:
+            with contextlib.suppress(OSError):
+                (results / "killturtle").unlink()
+        stop = True
+    while agree([(results / "pauseturtle").exists()])[0]:
+        _time.sleep(poll_s)
+    return stop
+
+
 def _rank() -> int:
     import os
     return int(os.environ.get("RANK", 0))
@@ -325,17 +354,7 @@ def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_ba
         total_newton += len(hist)
         # turtleFSI's stop controls: wall-clock budget, and the sentinel files a user drops into the results folder
         # (``killturtle``: checkpoint and stop; ``pauseturtle``: wait until it is removed)
-        if killtime is not None and _time.perf_counter() - t_loop > float(killtime):
-            out("Reached killtime = %s s: writing a checkpoint and stopping" % killtime)
-            stop = True
-        if (results / "killturtle").exists():
-            out("killturtle found: writing a checkpoint and stopping")
-            if rank0:
-                with contextlib.suppress(OSError):
-                    (results / "killturtle").unlink()
-            stop = True
-        while (results / "pauseturtle").exists():
-            _time.sleep(5.0)
+        stop = stop_controls(results, killtime, t_loop, getattr(backend, "agree_flags", None), rank0, out)
         if ns.get("checkpoint_step") and (ns["counter"] % int(ns["checkpoint_step"]) == 0 or stop):
             x = ns["dvp_"]["n"].vector()
             if rank0:

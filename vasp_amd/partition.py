@@ -320,6 +320,11 @@ class DistBackend:
         self.dist.all_reduce(t, op={"sum": self.dist.ReduceOp.SUM, "min": self.dist.ReduceOp.MIN, "max": self.dist.ReduceOp.MAX}[op])
         return t.cpu().numpy()
 
+    def agree_flags(self, flags):
+        """Job-wide OR of rank-local booleans (the time loop's stop / pause controls): every rank gets the same answer."""
+        from .dist import agree_flags
+        return agree_flags(self.dist, flags, device=self.dev if self.on_gpu_wire else "cpu")
+
     def flow_stats(self):
         """HipBackend.flow_stats over the whole job: every rank contributes the cells it owns (fsi_flow_stats counts those)."""
         n = self.part.num_owned_cells
