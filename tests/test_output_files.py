@@ -77,31 +77,90 @@ def test_checkpoint_round_trip(tmp_path):
     assert g["cell_dofs"].data.shape == (30 * m.num_cells,) and not (tmp_path / "tmp_checkpoint_v1.h5").exists()
 
 
-def test_visualization_series_is_streamed_in_segments_and_continues_after_a_restart(tmp_path):
-    """A long series never sits in memory as a whole: frames go to <name>.h5, <name>_run_1.h5, ... in bounded segments,
-    and the XDMF names file and index per time step - what the reference's output_file_lists reads
-    [REF src/vasp/postprocessing/postprocessing_common.py:63-121] (a restarted turtleFSI run leaves the same pattern)."""
+def last_frame_as_predeform_mesh_reads_it(h5_path):
+    """REF src/vasp/postprocessing/predeform_mesh.py:55-57, restated without h5py: the displacement of "the last time
+    step" is dataset number len(keys) - 1 of /VisualisationVector in displacement.h5."""
+    g = read_h5(h5_path)["VisualisationVector"]
+    number_of_datasets = len(g.keys())
+    return g[f"{number_of_datasets - 1}"].data[:, :]
+
+
+def frames_as_create_hdf5_reads_them(viz_folder, field):
+    """REF src/vasp/postprocessing/postprocessing_fenics/create_hdf5.py:89-98,139-160, restated: the XDMF gives (file,
+    index) per time step; the first file is opened for VisualisationVector/0, then every step opens the file its entry
+    names and reads VisualisationVector/<index>."""
+    files, times, idx = parse_xdmf(viz_folder / f"{field}.xdmf")
+    first = read_h5(viz_folder / files[0])["VisualisationVector"]["0"].data[:, :]
+    out = [read_h5(viz_folder / f)["VisualisationVector"][str(i)].data[:, :] for f, i in zip(files, idx)]
+    return first, times, out
+
+
+def test_every_frame_of_a_run_is_appended_to_one_file_and_the_series_continues_after_a_restart(tmp_path):
+    """DOLFIN appends every frame to <name>.h5 and the consumers rely on it.  40 frames go
+    through the writer one at a time (nothing but the current frame is held); after EVERY append the file on disk is a
+    complete HDF5 file whose last dataset is the frame just written - the read of vasp-predeform-mesh - and the XDMF walk
+    of vasp-create-hdf5 returns every frame; a walker that shares no code with h5lite sees the same tree."""
+    from test_h5_structure_independent import Walker
     m = FsiMesh.read(GOLDEN / "cylinder" / "cylinder.h5")
     rng = np.random.default_rng(2)
-    frame = 8 * 3 * m.num_nodes
-    w = VisualizationWriter(tmp_path, m, save_deg=2, segment_bytes=2 * frame + 1)       # two frames per file
-    states = [rng.standard_normal(m.num_dofs) for _ in range(5)]
-    for k, s in enumerate(states):
-        w.write(s, 1e-3 * (k + 1))
-        assert sum(len(v) for v in w.frames.values()) <= 3 * 2                           # never more than one segment held
-    w.flush()
-    files, times, idx = parse_xdmf(tmp_path / "velocity.xdmf")
-    assert files == ["velocity.h5", "velocity.h5", "velocity_run_1.h5", "velocity_run_1.h5", "velocity_run_2.h5"]
-    assert idx == [0, 1, 0, 1, 0] and np.allclose(times, 1e-3 * np.arange(1, 6))
-    for k, (f, i) in enumerate(zip(files, idx)):
-        arr = read_h5(tmp_path / f)["VisualisationVector"][str(i)].data
-        assert np.array_equal(arr, m.split(states[k])[1])
-    assert "Mesh" in read_h5(tmp_path / "velocity.h5") and "Mesh" not in read_h5(tmp_path / "velocity_run_1.h5")
-    # --restart-folder: a new writer adopts the series and goes on in the next run file
+    w = VisualizationWriter(tmp_path, m, save_deg=2)
+    states = []
+    for k in range(40):
+        states.append(rng.standard_normal(m.num_dofs))
+        w.write(states[-1], 1e-3 * (k + 1))
+        assert not hasattr(w, "frames")                                                  # no frame store in the writer
+        if k in (0, 1, 7, 8, 9, 31, 32, 39):                                             # across symbol-node / B-tree growth
+            assert np.array_equal(last_frame_as_predeform_mesh_reads_it(tmp_path / "displacement.h5"), m.split(states[k])[0])
+    first, times, frames = frames_as_create_hdf5_reads_them(tmp_path, "velocity")
+    assert np.allclose(times, 1e-3 * np.arange(1, 41)) and np.array_equal(first, m.split(states[0])[1])
+    for k, fr in enumerate(frames):
+        assert np.array_equal(fr, m.split(states[k])[1])
+    files, _, idx = parse_xdmf(tmp_path / "pressure.xdmf")
+    assert files == ["pressure.h5"] * 40 and idx == list(range(40))                      # ONE file per field
+    assert sorted(p.name for p in tmp_path.glob("*.h5")) == ["displacement.h5", "pressure.h5", "velocity.h5"]
+    # independent structural walk: group entries name-sorted (the format's lookup order), raw data intact, EOF = file length
+    wk = Walker(tmp_path / "velocity.h5")
+    tree = wk.tree()
+    vec = [p for p in tree if p.startswith("/VisualisationVector/")]
+    assert vec == sorted(vec) and len(vec) == 40 and wk.super["eof_is_len"]
+    assert tree["/Mesh/0/mesh/topology"]["attributes"] and tree["/VisualisationVector"]["message_types"] == [0x0011]
+    for k in (0, 17, 39):
+        assert np.frombuffer(tree[f"/VisualisationVector/{k}"]["raw"], dtype="<f8").reshape(-1, 3).tolist() == m.split(states[k])[1].tolist()
+    w.close()
+    # --restart-folder: a new writer adopts the series and goes on in <name>_run_<N>.h5 behind the same XDMF (the pattern
+    # a restarted turtleFSI run leaves, resolved per time step by output_file_lists)
     w2 = VisualizationWriter(tmp_path, m, save_deg=2, run_index=3)
-    extra = rng.standard_normal(m.num_dofs)
-    w2.write(extra, 6e-3)
+    extra = [rng.standard_normal(m.num_dofs) for _ in range(2)]
+    for k, s_ in enumerate(extra):
+        w2.write(s_, 1e-3 * (41 + k))
     w2.flush()
     files, times, idx = parse_xdmf(tmp_path / "velocity.xdmf")
-    assert files[-1] == "velocity_run_3.h5" and idx[-1] == 0 and len(times) == 6 and times[-1] == 6e-3
-    assert np.array_equal(read_h5(tmp_path / "velocity_run_3.h5")["VisualisationVector"]["0"].data, m.split(extra)[1])
+    assert files[-2:] == ["velocity_run_3.h5"] * 2 and idx[-2:] == [0, 1] and len(times) == 42 and times[-1] == 42e-3
+    g3 = read_h5(tmp_path / "velocity_run_3.h5")
+    assert np.array_equal(g3["VisualisationVector"]["1"].data, m.split(extra[1])[1]) and "Mesh" in g3
+    _, _, frames = frames_as_create_hdf5_reads_them(tmp_path, "velocity")
+    assert len(frames) == 42 and np.array_equal(frames[-1], m.split(extra[1])[1]) and np.array_equal(frames[3], m.split(states[3])[1])
+
+
+def test_checkpoint_files_under_the_independent_walker(tmp_path):
+    """Checkpoint/checkpoint_{d1,v1,p1}.h5 in DOLFIN's write_checkpoint layout
+    [REF src/vasp/postprocessing/postprocessing_h5py/postprocessing_h5py_common.py:235-241,639-670], walked by the parser
+    that shares no code with h5lite: names, shapes, element types."""
+    from test_h5_structure_independent import Walker
+    import struct
+    m = FsiMesh.read(GOLDEN / "cylinder" / "cylinder.h5")
+    x = np.random.default_rng(3).standard_normal(m.num_dofs)
+    checkpoint(tmp_path, m, x, dict(dt=1e-3), 0.01, 9)
+    C, N2, V = m.num_cells, m.num_nodes, m.num_vertices
+    for name, nvec, ndofs in (("d1", 3 * N2, 30 * C), ("v1", 3 * N2, 30 * C), ("p1", V, 4 * C)):
+        wk = Walker(tmp_path / f"checkpoint_{name}.h5")
+        tree = wk.tree()
+        base = f"/{name}/{name}_0"
+        assert sorted(p for p in tree if tree[p]["kind"] == "dataset") == sorted(
+            f"{base}/{d}" for d in ("cell_dofs", "cells", "mesh/geometry", "mesh/topology", "vector", "x_cell_dofs"))
+        dims = lambda path: struct.unpack_from(f"<{tree[path]['dataspace'][1]}Q", tree[path]["dataspace"], 8)
+        assert dims(f"{base}/vector") == (nvec, 1) and dims(f"{base}/cell_dofs") == (ndofs,)
+        assert dims(f"{base}/x_cell_dofs") == (C + 1,) and dims(f"{base}/cells") == (C,)
+        assert dims(f"{base}/mesh/geometry") == (V, 3) and dims(f"{base}/mesh/topology") == (C, 4)
+        assert tree[f"{base}/vector"]["datatype"][0] & 0x0F == 1 and tree[f"{base}/cell_dofs"]["datatype"][0] & 0x0F == 0   # f64 / i64
+        assert wk.super["eof_is_len"]

@@ -206,8 +206,8 @@ class _Reader:
             raise H5Error("bad local heap signature")
         data_addr, = struct.unpack_from("<Q", b, heap_addr + 24)
         start = data_addr + self.base + off
-        end = b.index(b"\0", start)
-        return b[start:end].decode()
+        end = b.find(b"\0", start)
+        return bytes(b[start:end]).decode()
 
     def _group_entries(self, btree: int, heap: int):
         b = self.b
@@ -310,15 +310,17 @@ class _Writer:
     LEAF_K = 4
     INTERNAL_K = 16
 
-    def __init__(self):
+    def __init__(self, origin: int = 0):
         self.buf = bytearray()
+        self.origin = origin              # file offset of buf[0] (8-aligned): addresses handed out are absolute
 
     def _alloc(self, n: int) -> int:
         pos = _pad8(len(self.buf))
         self.buf.extend(b"\0" * (pos - len(self.buf) + n))
-        return pos
+        return pos + self.origin
 
     def _put(self, pos: int, data: bytes):
+        pos -= self.origin
         self.buf[pos:pos + len(data)] = data
 
     def _object_header(self, messages) -> int:
@@ -328,6 +330,19 @@ class _Writer:
         self._put(pos, hdr + body)
         return pos
 
+    def _dataset_header(self, shape, dtype, daddr: int, nbytes: int, attrs) -> int:
+        """Object header of a contiguous dataset whose raw data sits at ``daddr`` (already in the file or in this buffer)."""
+        msgs = [
+            _message(0x0001, _dataspace_message(shape)),
+            _message(0x0003, _dtype_message(dtype), flags=1),
+            _message(0x0005, bytes([2, 2, 2, 0])),  # fill value v2: late alloc, write-time ifset, undefined
+            _message(0x0008, struct.pack("<BBQQ", 3, 1, daddr, nbytes)),
+            _message(0x0012, struct.pack("<B3xI", 1, int(time.time()) & 0xFFFFFFFF)),
+        ]
+        for k, v in (attrs or {}).items():
+            msgs.append(_attribute_message(k, v))
+        return self._object_header(msgs)
+
     def _write_dataset(self, ds: Dataset) -> int:
         arr = np.ascontiguousarray(ds.data)
         if arr.dtype.byteorder == ">":
@@ -336,24 +351,29 @@ class _Writer:
         daddr = self._alloc(len(raw)) if raw else UNDEF
         if raw:
             self._put(daddr, raw)
-        msgs = [
-            _message(0x0001, _dataspace_message(arr.shape)),
-            _message(0x0003, _dtype_message(arr.dtype), flags=1),
-            _message(0x0005, bytes([2, 2, 2, 0])),  # fill value v2: late alloc, write-time ifset, undefined
-            _message(0x0008, struct.pack("<BBQQ", 3, 1, daddr, len(raw))),
-            _message(0x0012, struct.pack("<B3xI", 1, int(time.time()) & 0xFFFFFFFF)),
-        ]
-        for k, v in ds.attrs.items():
-            msgs.append(_attribute_message(k, v))
-        return self._object_header(msgs)
+        return self._dataset_header(arr.shape, arr.dtype, daddr, len(raw), ds.attrs)
 
     def _write_group(self, g: Group) -> int:
         names = sorted(g.keys())
-        child_addr = {}
+        child_addr, child_bt_heap = {}, {}
         for n in names:
             node = g[n]
             child_addr[n] = self._write_group(node) if isinstance(node, Group) else self._write_dataset(
                 node if isinstance(node, Dataset) else Dataset(np.asarray(node)))
+            if isinstance(node, Group):
+                child_bt_heap[n] = node._bt_heap
+        g._bt_heap = self._group_tables(names, child_addr, child_bt_heap)
+        g._snod_entry = dict(self._last_entry_pos)      # name -> file offset of its 40-byte symbol-table entry
+        msgs = [_message(0x0011, struct.pack("<QQ", *g._bt_heap))]
+        for k, v in g.attrs.items():
+            msgs.append(_attribute_message(k, v))
+        g._header = self._object_header(msgs)
+        return g._header
+
+    def _group_tables(self, names, child_addr, child_bt_heap):
+        """Local heap, symbol nodes and B-tree of an old-style group whose children (``names``, sorted) already have
+        object headers at ``child_addr``; returns (B-tree address, heap address)."""
+        self._last_entry_pos = {}
         # local heap: first 8 bytes reserved (empty string at offset 0)
         heap_data = bytearray(b"\0" * 8)
         name_off = {}
@@ -375,9 +395,9 @@ class _Writer:
             pos = self._alloc(8 + 40 * cap)
             body = b"SNOD" + struct.pack("<BxH", 1, len(ch))
             for n in ch:
-                node = g[n]
-                if isinstance(node, Group):
-                    body += struct.pack("<QQII", name_off[n], child_addr[n], 1, 0) + struct.pack("<QQ", *node._bt_heap)
+                self._last_entry_pos[n] = pos + len(body)
+                if n in child_bt_heap:
+                    body += struct.pack("<QQII", name_off[n], child_addr[n], 1, 0) + struct.pack("<QQ", *child_bt_heap[n])
                 else:
                     body += struct.pack("<QQII16x", name_off[n], child_addr[n], 0, 0)
             self._put(pos, body)
@@ -405,11 +425,7 @@ class _Writer:
                 bt = addrs[0]
                 break
             entries, level = nxt, level + 1
-        g._bt_heap = (bt, heap_addr)
-        msgs = [_message(0x0011, struct.pack("<QQ", bt, heap_addr))]
-        for k, v in g.attrs.items():
-            msgs.append(_attribute_message(k, v))
-        return self._object_header(msgs)
+        return bt, heap_addr
 
     def write(self, root: Group) -> bytes:
         self._alloc(96)  # superblock (56) + root symbol-table entry (40)
@@ -427,3 +443,101 @@ def write_h5(path, root: Group) -> None:
     data = _Writer().write(root)
     with open(path, "wb") as f:
         f.write(data)
+
+
+class H5Series:
+    """One HDF5 file with a group of datasets that GROWS: ``append`` adds ``/<series>/<name>`` without rewriting what is
+    already there.
+
+    DOLFIN's ``XDMFFile.write(u, t)`` appends every frame of a run to ``<name>.h5:/VisualisationVector/<k>``, and the
+    reference's consumers rely on it: ``vasp-predeform-mesh`` takes "the last dataset of displacement.h5"
+    [REF src/vasp/postprocessing/predeform_mesh.py:55-57], ``vasp-create-hdf5`` opens the file a frame's XDMF entry names
+    [REF src/vasp/postprocessing/postprocessing_fenics/create_hdf5.py:89-98,139-160].  So a series has to live in ONE file
+    however long the run is, at O(1 frame) of memory.
+
+    On disk (same subset as ``write_h5``: superblock v0, old-style groups, contiguous datasets): the static part (e.g.
+    ``/Mesh/0/mesh``) and an empty series group are written once.  A frame then costs
+      1. its raw data and its dataset object header at the end of the file (never touched again);
+      2. the series group's tables - local heap, symbol nodes, B-tree; ~60 bytes per frame, entries sorted by name as the
+         format requires - written afresh into the inactive one of two metadata regions (doubling in size when full);
+      3. three in-place patches: the group's symbol-table message, the cached copy of it in the parent's symbol-table entry,
+         and the end-of-file address in the superblock.
+    A reader that opens the file between two appends sees a complete file with k frames.
+    """
+
+    def __init__(self, path, static_root: Group, series: str = "VisualisationVector", reserve: int = 1 << 14):
+        if series in static_root:
+            raise H5Error(f"/{series} is managed by H5Series")
+        root = Group(static_root)
+        root.attrs = dict(getattr(static_root, "attrs", {}))
+        sg = Group()
+        root[series] = sg
+        w = _Writer()
+        data = w.write(root)
+        self.path, self.series = path, series
+        self._group_header = sg._header                      # object header of the series group: message body at + 16 + 8
+        self._parent_entry = root._snod_entry[series]        # its symbol-table entry in the root group (cached bt / heap at + 24)
+        self.names, self.addr = [], {}
+        self._f = open(path, "w+b")
+        self._f.write(data)
+        self._eof = len(data)
+        self._regions, self._cap, self._active = None, 0, 0
+        self._reserve = reserve
+        self._f.flush()
+
+    def __len__(self):
+        return len(self.names)
+
+    def _write_at(self, pos: int, data: bytes):
+        self._f.seek(pos)
+        self._f.write(data)
+
+    def append(self, name: str, arr: np.ndarray, attrs: Optional[Dict[str, object]] = None) -> None:
+        if name in self.addr:
+            raise H5Error(f"/{self.series}/{name} exists")
+        arr = np.ascontiguousarray(arr)
+        if arr.dtype.byteorder == ">":
+            arr = arr.astype(arr.dtype.newbyteorder("<"))
+        # 1. raw data + dataset header at the end of the file
+        daddr = _pad8(self._eof)
+        self._write_at(daddr, arr.tobytes())
+        w = _Writer(origin=_pad8(daddr + arr.nbytes))
+        hdr = w._dataset_header(arr.shape, arr.dtype, daddr if arr.nbytes else UNDEF, arr.nbytes, attrs)
+        self._write_at(w.origin, bytes(w.buf))
+        self._eof = w.origin + len(w.buf)
+        self.names.append(name)
+        self.addr[name] = hdr
+        # 2. the group's tables into the inactive metadata region
+        names = sorted(self.names)
+        probe = _Writer(origin=0)
+        probe._group_tables(names, self.addr, {})
+        need = _pad8(len(probe.buf))
+        if self._regions is None or need > self._cap:
+            self._cap = max(self._reserve, 2 * need)
+            a = _pad8(self._eof)
+            self._regions = (a, a + self._cap)
+            self._eof = a + 2 * self._cap
+            self._write_at(self._eof - 1, b"\0")              # the file really is that long
+            self._active = 1
+        region = self._regions[1 - self._active]
+        t = _Writer(origin=region)
+        bt, heap = t._group_tables(names, self.addr, {})
+        self._write_at(region, bytes(t.buf))
+        self._active = 1 - self._active
+        # 3. switch over: group header, parent's cached copy, end-of-file address
+        both = struct.pack("<QQ", bt, heap)
+        self._write_at(self._group_header + 16 + 8, both)
+        self._write_at(self._parent_entry + 24, both)
+        self._write_at(40, struct.pack("<Q", self._eof))     # superblock: base 24, free-space 32, end-of-file 40
+        self._f.flush()
+
+    def close(self):
+        if self._f is not None:
+            self._f.close()
+            self._f = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

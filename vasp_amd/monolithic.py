@@ -214,7 +214,7 @@ def prepare(argv: Optional[List[str]] = None):
     folder = Path(str(ns["folder"]))
     if ns.get("restart_folder"):
         # a restarted run continues in the folder it restarts from: the checkpoint is overwritten and the visualization
-        # series goes on in <name>_run_N.h5 behind the same xdmf (what output_file_lists expects of a restarted series
+        # series goes on in ONE new file per field, <name>_run_N.h5, behind the same xdmf (what output_file_lists expects of a restarted series
         # [REF src/vasp/postprocessing/postprocessing_common.py:63-121])
         results = Path(str(ns["restart_folder"]))
     elif ns.get("sub_folder") is not None:
@@ -366,7 +366,7 @@ def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_ba
         ns["counter"] += 1
         out("Solved for timestep %d, t = %.4f in %.1f s" % (ns["counter"], t, _time.perf_counter() - t0))
     if viz is not None:
-        viz.flush()
+        viz.close()
     ns["time_loop_seconds"] = _time.perf_counter() - t_loop
     ns["newton_iterations"] = total_newton
     with quiet:

@@ -44,17 +44,24 @@ def refine_topology(mesh: FsiMesh) -> np.ndarray:
 
 
 class VisualizationWriter:
-    """Streams frames to disk in bounded segments.
+    """Appends every saved frame to ``<name>.h5`` - one file per field and run, as DOLFIN's ``XDMFFile.write`` does.
 
-    A frame of the 1 M-tet bench mesh at save_deg 2 is 35 MB per vector field, a 951-step cycle 100 GB: the series is
-    therefore cut into files of at most ``segment_bytes`` of frames - ``<name>.h5`` (which also carries
-    ``/Mesh/0/mesh``), ``<name>_run_1.h5``, ... - and only the segment being filled is held in memory.  One XDMF per
-    field lists, per time step, the file and the index inside it, which is how the reference's consumers address
-    frames anyway [REF src/vasp/postprocessing/postprocessing_common.py:63-121] (a restarted turtleFSI run leaves the
-    same ``_run_N`` pattern behind).  ``run_index`` > 0 continues an existing series after ``--restart-folder``.
+    The reference's consumers rely on that: ``vasp-predeform-mesh`` takes the LAST dataset of ``displacement.h5``
+    [REF src/vasp/postprocessing/predeform_mesh.py:55-57], ``vasp-create-hdf5`` starts from ``VisualisationVector/0`` of
+    the first file the XDMF names and then follows (file, index) per time step
+    [REF src/vasp/postprocessing/postprocessing_fenics/create_hdf5.py:89-98,139-160].  Round 2 cut a series into 256 MB
+    files, which broke the first of the two at 1 M tets (a frame is 35 MB there: ``displacement.h5`` stopped growing after
+    seven frames).  Now a frame is appended in place (``h5lite.H5Series``: its data and header go to the end of the file, the
+    group tables are re-pointed) and only that frame is in memory, whatever the length of the run.
+
+    ``run_index`` > 0 continues a series after ``--restart-folder``: the new frames go to ``<name>_run_<N>.h5`` (with their
+    own ``/Mesh/0/mesh``) behind the same XDMF, the pattern a restarted turtleFSI run leaves and ``output_file_lists``
+    resolves per time step [REF src/vasp/postprocessing/postprocessing_common.py:63-121].
     """
 
-    def __init__(self, folder, mesh: FsiMesh, save_deg: int, run_index: int = 0, segment_bytes: int = 256 << 20):
+    FOOTER = "    </Grid>\n  </Domain>\n</Xdmf>\n"
+
+    def __init__(self, folder, mesh: FsiMesh, save_deg: int, run_index: int = 0):
         self.folder = Path(folder)
         self.folder.mkdir(parents=True, exist_ok=True)
         self.mesh, self.save_deg = mesh, int(save_deg)
@@ -64,18 +71,15 @@ class VisualizationWriter:
         else:
             self.geometry = mesh.coords
             self.topology = mesh.tets.astype(np.int64)
-        frame_bytes = 8 * 3 * len(self.geometry)
-        self.frames_per_segment = max(1, int(segment_bytes // frame_bytes))
+        self.run_index = int(run_index)
         self.entries = {name: [] for name, _, _ in FIELDS}     # per field: (time, h5 file name, index in that file)
-        self.segment = run_index                                # number of the file being filled (0: <name>.h5)
-        self.frames = {name: [] for name, _, _ in FIELDS}      # frames of the current segment only
-        self.flush_every = 20      # the segment being filled is rewritten whole: every few frames, and when it is full
-        self._dirty = False
+        self.series = {}                                        # per field: the open H5Series of this run
+        self.count = 0                                          # frames this run has written
         if run_index > 0:
             self._adopt_existing()
 
-    def _file(self, name: str, segment: int) -> str:
-        return f"{name}.h5" if segment == 0 else f"{name}_run_{segment}.h5"
+    def _file(self, name: str) -> str:
+        return f"{name}.h5" if self.run_index == 0 else f"{name}_run_{self.run_index}.h5"
 
     def _adopt_existing(self) -> None:
         import re
@@ -96,6 +100,16 @@ class VisualizationWriter:
     def times(self):
         return [e[0] for e in self.entries[FIELDS[0][0]]]
 
+    def _open(self, name: str):
+        from .h5lite import H5Series
+        meshg, zero, inner, root = Group(), Group(), Group(), Group()
+        inner["geometry"] = Dataset(np.ascontiguousarray(self.geometry))
+        inner["topology"] = Dataset(self.topology, {"celltype": "tetrahedron"})
+        zero["mesh"] = inner
+        meshg["0"] = zero
+        root["Mesh"] = meshg
+        return H5Series(self.folder / self._file(name), root, "VisualisationVector")
+
     def write(self, state: np.ndarray, t: float) -> None:
         d, v, p = self.mesh.split(state)
         V, N = self.mesh.num_vertices, len(self.geometry)
@@ -106,68 +120,66 @@ class VisualizationWriter:
         else:
             vals = (d[:V], v[:V], p[:, None])
         for (name, _, att), val in zip(FIELDS, vals):
-            self.entries[name].append((float(t), self._file(name, self.segment), len(self.frames[name])))
-            self.frames[name].append(np.ascontiguousarray(val, dtype=np.float64).reshape(N, -1).copy())
-        self._dirty = True
-        nseg = len(self.frames[FIELDS[0][0]])
-        if nseg >= self.frames_per_segment:
-            self.flush()
-            self.frames = {name: [] for name, _, _ in FIELDS}
-            self.segment += 1
-        elif len(self.times) <= 3 or nseg % self.flush_every == 0:
-            self.flush()
+            if name not in self.series:
+                self.series[name] = self._open(name)
+            self.series[name].append(str(self.count), np.ascontiguousarray(val, dtype=np.float64).reshape(N, -1))
+            self.entries[name].append((float(t), self._file(name), self.count))
+            self._xdmf_append(name, att)
+        self.count += 1
 
     def flush(self) -> None:
-        if self._dirty:
-            for name, _, att in FIELDS:
-                self._flush(name, att)
-            self._dirty = False
+        """Every ``write`` leaves complete files behind; kept for the driver's end-of-run call."""
+        for sfile in self.series.values():
+            sfile._f.flush()
 
-    def _flush(self, name: str, att: str) -> None:
-        root = Group()
-        if self.segment == 0:
-            meshg, zero, inner = Group(), Group(), Group()
-            inner["geometry"] = Dataset(np.ascontiguousarray(self.geometry))
-            inner["topology"] = Dataset(self.topology, {"celltype": "tetrahedron"})
-            zero["mesh"] = inner
-            meshg["0"] = zero
-            root["Mesh"] = meshg
-        vec = Group()
-        for k, fr in enumerate(self.frames[name]):
-            vec[str(k)] = Dataset(fr)
-        root["VisualisationVector"] = vec
-        fname = self._file(name, self.segment)
-        tmp = self.folder / f"tmp_{fname}"
-        write_h5(tmp, root)
-        os.replace(tmp, self.folder / fname)
-        N, M = len(self.geometry), len(self.topology)
-        ndim = "3" if att == "Vector" else "1"
-        lines = f'''<?xml version="1.0"?>
+    def close(self) -> None:
+        for sfile in self.series.values():
+            sfile.close()
+        self.series = {}
+
+    def _xdmf_entry(self, name: str, att: str, k: int) -> str:
+        t, h5name, idx = self.entries[name][k]
+        N, ndim = len(self.geometry), ("3" if att == "Vector" else "1")
+        text = ""
+        if k > 0:
+            text += f'''      <Grid>
+        <xi:include xpointer="xpointer(//Grid[@Name=&quot;TimeSeries_{name}&quot;]/Grid[1]/*[self::Topology or self::Geometry])" />
+'''
+        return text + f'''        <Time Value="{t!r}" />
+        <Attribute Name="{name}" AttributeType="{att}" Center="Node">
+          <DataItem Dimensions="{N} {ndim}" Format="HDF">{h5name}:/VisualisationVector/{idx}</DataItem>
+        </Attribute>
+      </Grid>
+'''
+
+    def _xdmf_append(self, name: str, att: str) -> None:
+        """The XDMF of a field grows by one <Grid> per frame: the new entry overwrites the closing tags, which follow it
+        again (O(1) per frame; the first frame of a run writes the whole text, earlier runs' entries included)."""
+        path = self.folder / f"{name}.xdmf"
+        k = len(self.entries[name]) - 1
+        if self.count == 0 or not path.exists():
+            N, M = len(self.geometry), len(self.topology)
+            mesh_file = self.entries[name][0][1]
+            text = f'''<?xml version="1.0"?>
 <!DOCTYPE Xdmf SYSTEM "Xdmf.dtd" []>
 <Xdmf Version="3.0" xmlns:xi="http://www.w3.org/2001/XInclude">
   <Domain>
     <Grid Name="TimeSeries_{name}" GridType="Collection" CollectionType="Temporal">
       <Grid Name="mesh" GridType="Uniform">
         <Topology NumberOfElements="{M}" TopologyType="Tetrahedron" NodesPerElement="4">
-          <DataItem Dimensions="{M} 4" NumberType="UInt" Format="HDF">{name}.h5:/Mesh/0/mesh/topology</DataItem>
+          <DataItem Dimensions="{M} 4" NumberType="UInt" Format="HDF">{mesh_file}:/Mesh/0/mesh/topology</DataItem>
         </Topology>
         <Geometry GeometryType="XYZ">
-          <DataItem Dimensions="{N} 3" Format="HDF">{name}.h5:/Mesh/0/mesh/geometry</DataItem>
+          <DataItem Dimensions="{N} 3" Format="HDF">{mesh_file}:/Mesh/0/mesh/geometry</DataItem>
         </Geometry>
 '''
-        for k, (t, h5name, idx) in enumerate(self.entries[name]):
-            if k > 0:
-                lines += f'''      <Grid>
-        <xi:include xpointer="xpointer(//Grid[@Name=&quot;TimeSeries_{name}&quot;]/Grid[1]/*[self::Topology or self::Geometry])" />
-'''
-            lines += f'''        <Time Value="{t!r}" />
-        <Attribute Name="{name}" AttributeType="{att}" Center="Node">
-          <DataItem Dimensions="{N} {ndim}" Format="HDF">{h5name}:/VisualisationVector/{idx}</DataItem>
-        </Attribute>
-      </Grid>
-'''
-        lines += "    </Grid>\n  </Domain>\n</Xdmf>\n"
-        (self.folder / f"{name}.xdmf").write_text(lines)
+            for j in range(k + 1):
+                text += self._xdmf_entry(name, att, j)
+            path.write_text(text + self.FOOTER)
+            return
+        with open(path, "r+b") as f:
+            f.seek(-len(self.FOOTER.encode()), os.SEEK_END)
+            f.write((self._xdmf_entry(name, att, k) + self.FOOTER).encode())
 
 
 def _json_default(o):
