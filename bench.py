@@ -74,7 +74,7 @@ def fp64_storage_run(args) -> dict:
             "storage_precisions": j["config"]["storage_precisions"], "roofline": j["roofline"], "wall_s": time.perf_counter() - t0}
 
 
-def cpu_baseline(budget_s: float = 25.0):
+def cpu_baseline(budget_s: float = 30.0):
     """The CPU port of the same algorithm (oracle/: C element routines under OpenMP for the assembly, exact sparse LU
     for the solve - the reference's own linear solver is a direct LU, MUMPS) timed on the host cores on a bounded sample
     of the bench workload: the same offset-stenosis problem on a mesh of the same generator, sized so that the run takes

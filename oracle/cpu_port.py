@@ -22,7 +22,11 @@ from pathlib import Path
 import numpy as np
 
 
-def timed_newton_run(budget_s: float = 25.0, tets: int = 6500) -> dict:
+def timed_newton_run(budget_s: float = 25.0, tets: int = 6500, steps: int = 20) -> dict:
+    """One Jacobian lifetime of the reference's policy (``recompute_tstep = 20`` [REF offset_stenosis.py:44-48]): the first
+    step assembles the Jacobian and factorises it, the other 19 re-use the factors - timed separately, because the
+    reference amortises its factorisation exactly this way and a one-step sample understates the CPU path by an order of
+    magnitude.  ``budget_s`` only bounds the steady steps: the refresh step takes what it takes."""
     from vasp_amd.meshgen import write_mesh
     from vasp_amd.monolithic import prepare
     from .backend import OracleBackend
@@ -38,8 +42,9 @@ def timed_newton_run(budget_s: float = 25.0, tets: int = 6500) -> dict:
     ob = OracleBackend(desc)            # includes A_pre = assemble(J_linear), as the reference's solver_setup
     kind = "port"
     its, step, t = 0, 0, 0.0
-    t_first = None
-    while time.perf_counter() - t0 < budget_s or its == 0:
+    t_first, its_first = None, 0
+    t_steady0 = None
+    while step < steps and (step < 2 or time.perf_counter() - t_steady0 < max(budget_s, 1.0)):
         t += 0.001
         with contextlib.redirect_stdout(io.StringIO()):
             ns["t"] = t
@@ -52,7 +57,8 @@ def timed_newton_run(budget_s: float = 25.0, tets: int = 6500) -> dict:
         its += len(hist)
         step += 1
         if t_first is None:
-            t_first = time.perf_counter() - t0
+            t_first, its_first = time.perf_counter() - t0, len(hist)
+            t_steady0 = time.perf_counter()
     dt = time.perf_counter() - t0
     o = ob.o
     cores = c_oracle.load().fsi_c_num_threads() if o.c is not None else 1
@@ -74,10 +80,24 @@ def timed_newton_run(budget_s: float = 25.0, tets: int = 6500) -> dict:
             o.c.spmv(A, x)
             reps += 1
         spmv_gbs = reps * (A.nnz * 12.0 + A.shape[0] * 20.0) / (time.perf_counter() - tb) / 1e9
-    return {"value": its / dt, "unit": "Newton-iterations/s", "cores": int(cores), "kind": kind,
+    steady_s = dt - t_first
+    steady_its, steady_steps = its - its_first, step - 1
+    steady_rate = steady_its / steady_s if steady_steps > 0 and steady_s > 0 else None
+    # one Jacobian lifetime = the refresh step + (steps - 1) steady steps; if the budget cut the run short the remaining
+    # steady steps are priced at the measured steady rate
+    life_s = t_first + (steady_s / steady_steps * (steps - 1) if steady_steps > 0 else 0.0)
+    life_its = its_first + (steady_its / steady_steps * (steps - 1) if steady_steps > 0 else 0.0)
+    return {"value": life_its / life_s, "unit": "Newton-iterations/s", "cores": int(cores), "kind": kind,
             "sample": f"offset_stenosis on a {len(o.tets)}-tet mesh of the bench's generator ({o.ndof} dofs), dt=1e-3, theta=0.501, "
-                      f"quasi-Newton atol=rtol=1e-6 recompute_tstep=20: {step} time steps, {its} Newton iterations in {dt:.1f} s "
-                      f"incl. Jacobian assembly + sparse LU every 20 steps (first step {t_first:.1f} s); assembly in C/OpenMP on "
-                      f"{cores} threads, LU/triangular solves SuperLU on 1 thread (the reference's linear solver is a direct LU)",
-            "dof_updates_per_s": its * o.ndof / dt,
+                      f"quasi-Newton atol=rtol=1e-6 recompute_tstep=20, ONE Jacobian lifetime of {steps} time steps: the refresh step "
+                      f"(Jacobian assembly + sparse LU) {t_first:.1f} s for {its_first} Newton iterations, then {steady_steps} steady "
+                      f"steps re-using the factors, {steady_its} Newton iterations in {steady_s:.1f} s; `value` = iterations of the "
+                      f"lifetime / its time.  Assembly in C/OpenMP on {cores} threads, LU and triangular solves SuperLU on 1 thread "
+                      f"(the reference's linear solver is a direct LU, MUMPS).  The generator's next mesh size is 48 000 tets, "
+                      f"whose serial LU alone takes tens of minutes: the 6 000-tet sample is what fits a bench run",
+            "steady_state": {"value": steady_rate, "unit": "Newton-iterations/s", "steps": steady_steps, "newton_iterations": steady_its,
+                             "seconds": steady_s},
+            "refresh_step": {"seconds": t_first, "newton_iterations": its_first},
+            "lifetime_steps": steps, "tets": int(len(o.tets)), "dofs": int(o.ndof),
+            "dof_updates_per_s": life_its / life_s * o.ndof,
             "residual_assembly_tets_per_s": res_rate, "spmv_GBps": spmv_gbs, "host_cpus": os.cpu_count()}

@@ -118,14 +118,19 @@ def test_owned_rows_of_the_local_assembly_are_the_global_rows(cylinder_case):
         assert Ag[p.l2g_dofs[rows]].getnnz() == sub[rows].getnnz()
 
 
-def _halo_worker(rank, world, port, mesh_path, q):
+def _halo_worker(rank, world, port, mesh_path, q, avf_dir=None):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import tempfile
+    from pathlib import Path
     import torch
     import torch.distributed as dist
-    from conftest import prepare_case
+    from conftest import make_avf_case, prepare_case
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    _, desc, *_ = prepare_case("cylinder", mesh_path, tempfile.mkdtemp())
+    if avf_dir is not None:                 # the avf problem file on the two-region tube, geodesic partition
+        os.environ["VASPFSI_PARTITION"] = "geodesic"
+        _, desc, *_ = make_avf_case(Path(avf_dir) / f"rank{rank}")
+    else:
+        _, desc, *_ = prepare_case("cylinder", mesh_path, tempfile.mkdtemp())
     p = Partition(desc, rank, world)
     x = np.random.default_rng(7).standard_normal(6 * p.N2 + p.V)             # the same global vector on every rank
     xl = p.restrict(x)
@@ -159,3 +164,54 @@ def test_halo_exchange_over_gloo_two_ranks():
     for _, err, dot_all, dot_ref in res:
         assert err == 0.0                                                      # ghosts now hold their owners' values
         assert dot_all == pytest.approx(dot_ref, rel=1e-13)
+
+
+def test_halo_exchange_over_gloo_two_ranks_on_the_avf_problem_with_the_geodesic_partition(tmp_path):
+    """the AVF workload [REF src/vasp/simulations/avf.py:55-84: two solid regions, list-valued ids] on the
+    two-region tube of conftest.make_avf_case, cut by graph distance instead of along an axis: same exactness statements
+    as above (ghosts hold their owners' values after one exchange, owned dots add up to the global dot)."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_halo_worker, args=(r, 2, port, None, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for _, err, dot_all, dot_ref in res:
+        assert err == 0.0
+        assert dot_all == pytest.approx(dot_ref, rel=1e-13)
+
+
+def test_geodesic_partition_follows_the_vessels_where_an_axis_slab_cuts_them_all():
+    """Two vessels side by side (the generated tube twice, 20 mm apart - the situation of an artery next to a vein
+    [REF src/vasp/simulations/avf.py:55-59]): slabs along the longest axis cut BOTH at every rank boundary, graph-distance
+    slabs give each of two ranks one whole vessel (no ghost node at all); "auto" picks the smaller local problem.  On a
+    single straight tube the two orderings give the same partition, so nothing changes for the bench workload."""
+    from vasp_amd.mesh import FsiMesh
+    from vasp_amd.meshgen import generate
+    from vasp_amd.partition import balanced_owners, local_node_counts
+    m = generate(6000)
+    one = FsiMesh.from_arrays(m["coords"], m["tets"], m["cell_markers"], m["facets"], m["facet_markers"])
+    c2 = m["coords"].copy()
+    c2[:, 1] += 0.02
+    V = len(c2)
+    two = FsiMesh.from_arrays(np.concatenate([m["coords"], c2]), np.concatenate([m["tets"], m["tets"] + V]),
+                              np.concatenate([m["cell_markers"]] * 2), np.concatenate([m["facets"], m["facets"] + V]),
+                              np.concatenate([m["facet_markers"]] * 2))
+    n = two.num_nodes
+    counts = {meth: local_node_counts(balanced_owners(two.node_coords, two.tet_nodes, 2, 2, method=meth), two.tet_nodes, 2, 2)
+              for meth in ("slab", "geodesic", "auto")}
+    assert counts["geodesic"].tolist() == [n // 2, n // 2]                       # one vessel each, nothing shared
+    assert counts["slab"].min() > 1.15 * (n // 2)                                # both vessels cut: > 15 % ghost nodes
+    assert counts["auto"].tolist() == counts["geodesic"].tolist()
+    for world in (2, 4):
+        a = balanced_owners(one.node_coords, one.tet_nodes, world, 2, method="slab")
+        b = balanced_owners(one.node_coords, one.tet_nodes, world, 2, method="geodesic")
+        assert np.array_equal(a, balanced_owners(one.node_coords, one.tet_nodes, world, 2, method="auto"))
+        assert local_node_counts(b, one.tet_nodes, world, 2).max() <= 1.02 * local_node_counts(a, one.tet_nodes, world, 2).max()

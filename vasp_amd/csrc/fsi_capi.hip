@@ -348,7 +348,36 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         float *cr = ctx->sbmg_work.p, *cd = cr + n4c, *cd2 = cr + 2 * n4c, *cx = cr + 3 * n4c, *crhs = cr + 4 * n4c;
         launch_sbmg_restrict(st, nc, ctx->sbmg_chptr.p, ctx->sbmg_child.p, ctx->sbmg_chw.p, ctx->snode.p, ctx->rowscale.p,
                              ctx->sbmg_flag.p, ctx->sbmg_cflag.p, fr, crhs);
-        {
+        if (ctx->l3.ready) {
+          // a few two-grid cycles on the P1 level with the dense aggregate level below it (fsi_amg.hip): smoothing on
+          // [lmax / alpha, lmax], then per cycle  e = P A3^-1 P^T r  as the next direction, one sweep that applies it and
+          // restarts the recurrence, `post` smoothing sweeps
+          const L3Level& L3 = ctx->l3;
+          const double cl = ctx->sbmg_clmax, clmin = cl / L3.alpha, cth = 0.5 * (cl + clmin), cde = 0.5 * (cl - clmin), csig = cth / cde;
+          double crho = 1.0 / csig;
+          launch_cheb_init_b3(st, nc, crhs, ctx->sbmg_cbinv12.p, (float)(1.0 / cth), cx, cr, cd);
+          HIPCHK(hipMemsetAsync(cd2, 0, n4c * sizeof(float), st));
+          float *ca = cd, *cb = cd2;
+          auto csweep = [&](float c1, float c2) {
+            launch_sweep_sb_b3(st, nc, ctx->sbmg_cptr.p, ctx->sbmg_ccol.p, ctx->sbmg_cvals.p, ctx->sbmg_cbinv12.p, c1, c2, ca, cb, cx, cr, 1);
+            std::swap(ca, cb);
+          };
+          for (int k = 0; k < L3.pre; ++k) {
+            const double rn = 1.0 / (2.0 * csig - crho);
+            csweep((float)(rn * crho), (float)(2.0 * rn / cde));
+            crho = rn;
+          }
+          for (int cyc = 0; cyc < L3.cycles; ++cyc) {
+            l3_correct(ctx, cr, ca);
+            csweep(0.f, (float)(1.0 / cth));
+            crho = 1.0 / csig;
+            for (int k = 0; k < L3.post; ++k) {
+              const double rn = 1.0 / (2.0 * csig - crho);
+              csweep((float)(rn * crho), (float)(2.0 * rn / cde));
+              crho = rn;
+            }
+          }
+        } else {
           const double cl = ctx->sbmg_clmax, clmin = cl / ctx->sbmg_ckappa, cth = 0.5 * (cl + clmin), cde = 0.5 * (cl - clmin), csig = cth / cde;
           double crho = 1.0 / csig;
           launch_cheb_init_b3(st, nc, crhs, ctx->sbmg_cbinv12.p, (float)(1.0 / cth), cx, cr, cd);
@@ -1229,6 +1258,11 @@ int refresh_preconditioner(FsiCtx* ctx) {
       std::memcpy(&rowmax, &flags[2], sizeof rowmax);
       ctx->sbmg_ready = !(flags[1] & 64) && std::isfinite(rowmax) && rowmax > 0.f;
       ctx->sbmg_clmax = rowmax;
+      ctx->l3.ready = false;
+      if (ctx->sbmg_ready && ctx->solid_l3) {
+        if (!ctx->l3.built) FSICHK(l3_build(ctx));
+        FSICHK(l3_refresh(ctx));
+      }
       HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
       if (getenv("FSI_DEBUG")) fprintf(stderr, "[fsi] solid two-level: %lld coarse nodes, clmax %.3f, ready %d\n", (long long)ctx->sbmg_nc, rowmax, (int)ctx->sbmg_ready);
     }
@@ -1392,6 +1426,7 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->sbmg_par.release(); ctx->sbmg_ccol.release(); ctx->sbmg_child.release(); ctx->sbmg_cfine.release(); ctx->sbmg_pw.release();
   ctx->sbmg_chw.release(); ctx->sbmg_cvals.release(); ctx->sbmg_cbinv12.release(); ctx->sbmg_work.release(); ctx->sbmg_cptr.release();
   ctx->sbmg_chptr.release(); ctx->sbmg_flag.release(); ctx->sbmg_cflag.release();
+  ctx->l3.release();
   ctx->s_vals32.release(); ctx->s_dinv32.release(); ctx->s_work32.release(); ctx->s_rec.release(); ctx->s_dinv.release();
   ctx->s_ploc.release(); ctx->s_tile_uptr.release(); ctx->s_tile_ulist.release();
   ctx->fs_rows.release(); ctx->fs_col.release(); ctx->fs_ptr.release(); ctx->fs_src.release();
@@ -2034,6 +2069,16 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
             }
             ctx->sbmg_nc = nsc;
             ctx->sbmg_nblk = (int64_t)sccol.size();
+            if (const char* e = getenv("FSI_SOLID_L3")) ctx->solid_l3 = atoi(e);
+            if (ctx->solid_l3) {                   // what the level-3 set-up (fsi_amg.hip) needs on the host
+              ctx->h_sc_ptr = scptr;
+              ctx->h_sc_col = sccol;
+              ctx->h_sc_xyz.resize(3 * (size_t)nsc);
+              for (int64_t I = 0; I < nsc; ++I) {
+                const int32_t nd = ctx->h_rank2node[ctx->h_snode[scfine[I]]];      // a vertex: nd < V
+                for (int c = 0; c < 3; ++c) ctx->h_sc_xyz[3 * (size_t)I + c] = ctx->h_coords[3 * (size_t)nd + c];
+              }
+            }
             FSICHK(upload(ctx, ctx->sbmg_par, spar));
             FSICHK(upload(ctx, ctx->sbmg_pw, spw));
             FSICHK(upload(ctx, ctx->sbmg_chptr, schptr));

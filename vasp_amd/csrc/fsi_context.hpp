@@ -39,6 +39,25 @@ struct DevBuf {
   }
 };
 
+// Third level of the solid block's cycle: smoothed aggregation with a dense, explicitly inverted coarsest operator
+// (fsi_amg.hip).  P: frozen prolongator, 3x6 blocks, stored by vertex (pptr / pcol) and by aggregate (tptr / tvert / tblk).
+struct L3Level {
+  bool built = false, usable = false, ready = false;
+  int aggsize = 48, deg = 1, pre = 6, post = 6, cycles = 3;
+  double alpha = 30.0;                         // smoothing interval of the P1 level inside the cycle: [lmax / alpha, lmax]
+  int64_t nagg = 0, nd = 0, ndp = 0, npb = 0, ntrip = 0, npair = 0, nslot = 0;
+  DevBuf<int64_t> pptr, tptr;
+  DevBuf<int32_t> pcol, tvert, tblk, tcol, trip_e, trip_b, trip_t, pair_b, pair_t;
+  DevBuf<float> pval, T, Ainv, r3, x3;
+  DevBuf<double> A3, panelR, panelC, dinv, diag;
+  DevBuf<uint8_t> dead;
+  void release() {
+    pptr.release(); tptr.release(); pcol.release(); tvert.release(); tblk.release(); tcol.release(); trip_e.release();
+    trip_b.release(); trip_t.release(); pair_b.release(); pair_t.release(); pval.release(); T.release(); Ainv.release();
+    r3.release(); x3.release(); A3.release(); panelR.release(); panelC.release(); dinv.release(); diag.release(); dead.release();
+  }
+};
+
 // One colour of the multicolour ordering: `ngroups` groups of `group_rows` consecutive rows starting at `first_row`
 // (6 rows per P2 node for the d/v block, 1 row per vertex for the pressure block).
 struct Level {
@@ -219,6 +238,11 @@ struct FsiCtx {
   fsi::DevBuf<float> sbmg_pw, sbmg_chw, sbmg_cvals, sbmg_cbinv12, sbmg_work;
   fsi::DevBuf<int64_t> sbmg_cptr, sbmg_chptr;
   fsi::DevBuf<uint8_t> sbmg_flag, sbmg_cflag;
+  std::vector<int64_t> h_sc_ptr;             // host copies of the P1 level's pattern and vertex coordinates (level-3 set-up)
+  std::vector<int32_t> h_sc_col;
+  std::vector<double> h_sc_xyz;
+  fsi::L3Level l3;                           // FSI_SOLID_L3=0: the P1 level is "solved" by sbmg_cits plain sweeps as in round 2
+  int solid_l3 = 1;
   int sbmg_pre = 16, sbmg_post = 16, sbmg_cits = 200;
   double sbmg_alpha = 200.0, sbmg_ckappa = 4000.0, sbmg_clmax = 2.0;
   int64_t nfs = 0;                           // fluid-interior velocity rows with solid columns (coupling of the predictor)

@@ -78,6 +78,11 @@ void launch_l2norm(hipStream_t st, int64_t C, const ElemArrays& ea, const double
 void launch_jacobian(hipStream_t st, int part, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
                      const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals);
 
+// fsi_amg.hip — dense third level of the solid block's cycle (see there)
+int l3_build(FsiCtx* ctx);                                   // once per context: aggregates + frozen smoothed prolongator (host)
+int l3_refresh(FsiCtx* ctx);                                 // every Jacobian: Galerkin operator + explicit inverse (device)
+void l3_correct(FsiCtx* ctx, const float* r4, float* e4);    // e = P A3^-1 P^T r, three launches
+
 // fsi_post.hip — solid stress / strain and wall shear stress (cell-local DG1 projections)
 hipError_t upload_post_tables(const double* qw, const double* dN, const double* L);
 void launch_stress_strain(hipStream_t st, int64_t ncell, const ElemArrays& ea, const ElemParams& ep, const double* U,

@@ -41,12 +41,47 @@ def node_owners(node_coords: np.ndarray, world: int) -> np.ndarray:
     return owner
 
 
-def balanced_owners(node_coords: np.ndarray, tn: np.ndarray, world: int, overlap: int, rounds: int = 1) -> np.ndarray:
-    """Slabs as in ``node_owners``, with the cuts moved so that the *local* node counts (owned + ghost layers: what a
-    rank's kernels run over) are equal - end slabs have one ghost side, interior slabs two."""
-    n = len(node_coords)
+def axis_order(node_coords: np.ndarray) -> np.ndarray:
+    """Nodes sorted along the longest axis of the mesh: contiguous runs are slabs (cross-sections of a tube)."""
     axis = int(np.argmax(np.ptp(node_coords, axis=0)))
-    order = np.argsort(node_coords[:, axis], kind="stable")
+    return np.argsort(node_coords[:, axis], kind="stable")
+
+
+def geodesic_order(node_coords: np.ndarray, tn: np.ndarray) -> np.ndarray:
+    """Nodes sorted by their graph distance from one end of the mesh (breadth-first levels over the element graph, ties
+    along the longest axis): contiguous runs are *geodesic* slabs - cross-sections that follow a vessel around bends and
+    into its branches, which is what a slab along a coordinate axis is on a straight tube only.  The AVF workload
+    [REF src/vasp/simulations/avf.py:55-59: artery + vein joined at the anastomosis] is not a tube; an axis slab there
+    cuts both vessels at once, a geodesic slab cuts where the front is.  Components that are not connected to the
+    start node follow one after the other, each from its own end."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import shortest_path
+    n = len(node_coords)
+    tn = np.asarray(tn, dtype=np.int64)
+    ii, jj = np.triu_indices(tn.shape[1], 1)
+    r, c = tn[:, ii].ravel(), tn[:, jj].ravel()
+    g = sp.coo_matrix((np.ones(len(r), dtype=np.int8), (r, c)), shape=(n, n)).tocsr()
+    g.data[:] = 1
+    axis = int(np.argmax(np.ptp(node_coords, axis=0)))
+    along = np.argsort(node_coords[:, axis], kind="stable")
+    level = np.full(n, -1, dtype=np.int64)
+    base = 0
+    for start in along:                                   # one pass per connected component, from its lowest end
+        if level[start] >= 0:
+            continue
+        dist = shortest_path(g, method="D", directed=False, unweighted=True, indices=int(start))
+        reach = np.isfinite(dist)
+        level[reach] = base + dist[reach].astype(np.int64)
+        base = int(level[reach].max()) + 1
+        if (level >= 0).all():
+            break
+    return np.lexsort((node_coords[:, axis], level))
+
+
+def owners_from_order(order: np.ndarray, tn: np.ndarray, world: int, overlap: int, rounds: int = 1) -> np.ndarray:
+    """``world`` contiguous runs of the node sequence ``order``, with the cuts moved so that the *local* node counts
+    (owned + ghost layers: what a rank's kernels run over) are equal - end runs have one ghost side, interior runs two."""
+    n = len(order)
     share = np.full(world, n / world)
     owner = np.empty(n, dtype=np.int32)
     for it in range(rounds + 1):
@@ -59,6 +94,33 @@ def balanced_owners(node_coords: np.ndarray, tn: np.ndarray, world: int, overlap
         share = np.maximum((n + ghosts.sum()) / world - ghosts, 0.25 * n / world)
         share *= n / share.sum()
     return owner
+
+
+def local_node_counts(owner: np.ndarray, tn: np.ndarray, world: int, overlap: int) -> np.ndarray:
+    return np.array([int(local_sets(owner, tn, q, overlap)[2].sum()) for q in range(world)])
+
+
+def balanced_owners(node_coords: np.ndarray, tn: np.ndarray, world: int, overlap: int, rounds: int = 1,
+                    method: Optional[str] = None) -> np.ndarray:
+    """Owner rank of every P2 node.  ``method`` (default: $VASPFSI_PARTITION, else "auto"):
+
+    * "slab": runs of the nodes sorted along the longest axis (round 1/2; right for a tube);
+    * "geodesic": runs of the nodes sorted by graph distance from one end (``geodesic_order``; bends and branches);
+    * "auto": both are built and the one whose largest rank-local problem (owned + ghost nodes) is smaller wins - on a
+      straight tube the two agree and the slab is kept."""
+    import os
+    method = method or os.environ.get("VASPFSI_PARTITION", "auto")
+    if world == 1:
+        return np.zeros(len(node_coords), dtype=np.int32)
+    if method not in ("slab", "geodesic", "auto"):
+        raise ValueError(f"VASPFSI_PARTITION={method!r}: expected slab, geodesic or auto")
+    slab = owners_from_order(axis_order(node_coords), tn, world, overlap, rounds) if method != "geodesic" else None
+    if method == "slab":
+        return slab
+    geo = owners_from_order(geodesic_order(node_coords, tn), tn, world, overlap, rounds)
+    if method == "geodesic":
+        return geo
+    return geo if local_node_counts(geo, tn, world, overlap).max() < local_node_counts(slab, tn, world, overlap).max() else slab
 
 
 def _p2_node_coords(desc: dict) -> np.ndarray:
