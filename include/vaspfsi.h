@@ -159,6 +159,17 @@ int fsi_set_partition(FsiCtx* ctx, int64_t num_owned_cells, int64_t n_ghost, con
                       int64_t n_identity, const int64_t* identity_dofs, int64_t n_send, const int64_t* send_dofs,
                       double* sendbuf_dev, double* recvbuf_dev, const FsiComm* comm);
 
+/* Collectives issued by the library itself (VASPFSI_RCCL=1 in vasp_amd/partition.py): after fsi_set_partition, hand the
+ * library an RCCL communicator and it queues ncclAllReduce (Krylov coefficient vectors in device memory) and grouped
+ * ncclSend / ncclRecv (halo) on its solver stream; the FsiComm callbacks are then no longer called.  Counterpart of the MPI
+ * reductions inside the reference's solver run [REF docs/simulation.md:14-32; simulation_common.py:217-220].
+ * fsi_rccl_unique_id: 128 bytes from ncclGetUniqueId, made by one rank and broadcast by the caller.  send_counts[p] /
+ * recv_counts[p]: doubles exchanged with rank p, in the order of the partition's send / ghost lists (peers ascending).
+ * RCCL is resolved with dlopen at the first call; FSI_ERR_DEVICE if it is not available. */
+int fsi_rccl_unique_id(void* id128);
+int fsi_set_rccl(FsiCtx* ctx, const void* id128, int32_t rank, int32_t world, const int64_t* send_counts,
+                 const int64_t* recv_counts);
+
 /* ---- state / introspection (checkpoint, restart, parity dumps) --------------------------------------- */
 /* which: 0 = dvp_["n"], 1 = dvp_["n-1"], 2 = last rhs b, 3 = last update du.  User layout, length ndof. */
 int fsi_get_state(FsiCtx* ctx, int which, double* out);
@@ -238,7 +249,11 @@ typedef struct FsiTimers {
                                                         state, not the environment's): bit 0 tiled sweeps fused with
                                                         the Chebyshev update, 1 FP16 packed records, 2 solid block in
                                                         FP32, 3 solid sweeps fused (block Jacobi), 4 solid two-level
-                                                        cycle ready, 5 displacement two-level cycle ready            */
+                                                        cycle ready, 5 displacement two-level cycle ready, 6 solid
+                                                        dense third level ready                                       */
+  int64_t part_allreduces;                           /* partitioned runs: all-reduces issued inside Krylov iterations
+                                                        (one per Gram-Schmidt pass; + one per pass of the FP64 window
+                                                        while Q is FP32; + one when an iteration looks converged)    */
 } FsiTimers;
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
 /* Measurement aid: streams `bytes` of the (idle) Krylov store once per kernel with 4-, 8-, 16- and 32-byte loads and

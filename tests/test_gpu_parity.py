@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 # production defaults (mixed storage, forcing 1e-2) against exact solves on the known-answer case, per field; see
 # test_production_storage_precisions_do_not_change_the_result (values measured on MI355X are in DESIGN.md section 2)
-PRODUCTION_VS_EXACT_BOUND = {"d": 2e-5, "v": 2e-5, "p": 2e-5}
+PRODUCTION_VS_EXACT_BOUND = {"d": 2e-6, "v": 1.2e-5, "p": 3e-6}      # measured 9.5e-7, 5.8e-6, 1.4e-6
 
 
 def random_state(mesh, ndof, seed=0):
@@ -587,6 +587,58 @@ def test_aneurysm_three_steps_match_converged_golden(tmp_path):
             err = np.linalg.norm(U[sl] - G[k][sl]) / np.linalg.norm(G[k][sl])
             assert err < 1e-6, (k, name, err)
     hb.close()
+
+
+# BASELINE configs[4] ("mixed FP64 assembly / FP32 Krylov" on the aneurysm / Robin workload) against the oracle's converged
+# run, per field (bound = 2x the value measured on MI355X in round 3; the values are in DESIGN.md section 2):
+#   "own":   the problem file's own tolerances (atol 1e-10, rtol 1e-9 [REF src/vasp/simulations/aneurysm.py:48-49]); the
+#            storage policy decides (these tolerances select the FP64 basis);
+#   "mixed": tolerances 1e-6 (the other problem files' choice), for which the policy selects the FP32 Krylov basis, the FP32
+#            Jacobian copy inside the iterations and FP16 preconditioner matrices.
+CONFIG5_BOUND = {"own": {"d": 2e-6, "v": 2e-6, "p": 2e-6}, "mixed": {"d": 2e-4, "v": 2e-4, "p": 2e-4}}
+
+
+@pytest.mark.parametrize("mode", ["own", "mixed"])
+def test_aneurysm_production_defaults_against_the_converged_oracle_run(tmp_path, mode):
+    """the production defaults (storage chosen by the policy, forcing 1e-2) had never been
+    compared with the oracle on the aneurysm / Robin workload - the golden test above drives Newton to 1e-11 with every
+    linear system solved to 1e-10.  Three steps with the problem file's Jacobian policy; the states must stay within the
+    Newton stopping tolerance of the oracle's converged states (tests/golden/aneurysm_tight.npz)."""
+    from vasp_amd.capi import HipBackend
+    G = np.load(GOLDEN / "aneurysm_tight.npz")["states"]
+    case = prepare_case("aneurysm", GOLDEN / "aneurysm" / "small_aneurysm.h5", tmp_path, extra=("inlet_id=4",))
+    ns, desc = case[0], case[1]
+    mesh = ns["mesh"]
+    atol, rtol = (ns["atol"], ns["rtol"]) if mode == "own" else (1e-6, 1e-6)
+    hb = HipBackend(desc)                                                    # production defaults
+    N2 = mesh.num_nodes
+    worst, its, kry = {"d": 0.0, "v": 0.0, "p": 0.0}, [], 0
+    for k in range(3):
+        g, P = boundary_data(case, 1e-3 * (k + 1))
+        hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+        h = hb.newton_solve(counter=k, first_step_num=0, atol=atol, rtol=rtol, max_it=ns["max_it"], lmbda=1.0,
+                            recompute=ns["recompute"], recompute_tstep=ns["recompute_tstep"])
+        its.append(len(h)); kry += sum(it[3] for it in h)
+        hb.shift()
+        U = hb.get_state("n")
+        assert np.isfinite(U).all()
+        for name, sl in (("d", slice(0, 3 * N2)), ("v", slice(3 * N2, 6 * N2)), ("p", slice(6 * N2, None))):
+            worst[name] = max(worst[name], float(np.linalg.norm(U[sl] - G[k][sl]) / np.linalg.norm(G[k][sl])))
+    tm = hb.timers()
+    hb.close()
+    print(f"aneurysm [{mode}] atol {atol:g} rtol {rtol:g}, Q in FP{8 * tm['q_elem_bytes']}: distance to the converged oracle states",
+          worst, "Newton", its, "Krylov", kry)
+    with contextlib.suppress(OSError):
+        import json
+        from conftest import ROOT
+        (ROOT / "gpurun_out").mkdir(exist_ok=True)
+        (ROOT / "gpurun_out" / f"config5_aneurysm_{mode}.json").write_text(json.dumps(
+            dict(errors=worst, newton=its, krylov=kry, q_elem_bytes=tm["q_elem_bytes"], spmv_fp32_calls=tm["spmv_fp32_calls"],
+                 atol=atol, rtol=rtol)))
+    if mode == "mixed":
+        assert tm["q_elem_bytes"] == 4 and tm["spmv_fp32_calls"] > 0          # the mixed mode really ran
+    for name, bound in CONFIG5_BOUND[mode].items():
+        assert worst[name] < bound, (name, worst[name], bound)
 
 
 def test_stress_strain_kernel_matches_oracle(cyl, cylinder_case):

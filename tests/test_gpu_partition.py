@@ -33,13 +33,17 @@ def _time_steps(backend, ns, bc_values, pressure, hook):
     return hist_all
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, world, port, q, backend="gloo", library_rccl=False):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", VASPFSI_RCCL="1" if library_rccl else "0")
     import tempfile
+    import torch
     import torch.distributed as dist
     from conftest import prepare_case
     from vasp_amd.partition import DistBackend
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     ns, desc, bc_values, pressure, hook = prepare_case("cylinder", GOLDEN / "cylinder" / "cylinder.h5", tempfile.mkdtemp(),
                                                         T="0.003")
     db = DistBackend(desc, dist, device=0, lin_rtol=1e-12)
@@ -51,15 +55,21 @@ def _worker(rank, world, port, q):
     pts = mesh.cell_midpoints()[::97] + 1e-6
     cells, bary = mesh.locate(pts)
     diag = (db.flow_stats(), db.probe(cells, bary), db.get_values("n", np.arange(0, db.ndof_global, 53)))
+    tm = db.timers()
     if rank == 0:
-        q.put((x, hist, b_norm, diag))
+        q.put((x, hist, b_norm, diag, dict(allreduces=tm["part_allreduces"], krylov=tm["krylov_iters"], solves=tm["krylov_solves"],
+                                           q_bytes=tm["q_elem_bytes"], library_rccl=db.library_rccl)))
     dist.barrier()
     db.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_partitioned_steps_match_single_context(world, tmp_path):
+@pytest.mark.parametrize("world,transport", [(2, "gloo"), (3, "gloo"), (1, "library-rccl")])
+def test_partitioned_steps_match_single_context(world, transport, tmp_path):
+    """2 / 3 ranks on the one card over host-staged gloo; and the wire path of a real multi-GPU job with ONE rank: process
+    group "nccl", VASPFSI_RCCL=1, i.e. ncclCommInitRank + ncclAllReduce on device memory + the grouped send / recv issued by
+    libvaspfsi.so on its own stream (RCCL refuses two ranks on one device, so one rank is what a 1-GPU box can run; the
+    multi-rank logic is the same code as the gloo runs, the transport the same calls as this run)."""
     import torch.multiprocessing as mp
     from conftest import prepare_case
     from vasp_amd.capi import HipBackend
@@ -68,10 +78,11 @@ def test_partitioned_steps_match_single_context(world, tmp_path):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    extra = ("nccl", True) if transport == "library-rccl" else ("gloo", False)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q) + extra) for r in range(world)]
     for p in procs:
         p.start()
-    x_part, hist_part, b_part, diag_part = q.get(timeout=900)
+    x_part, hist_part, b_part, diag_part, comm = q.get(timeout=900)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -103,6 +114,12 @@ def test_partitioned_steps_match_single_context(world, tmp_path):
         assert np.abs(diag_part[1][:, cols] - diag_one[1][:, cols]).max() <= 1e-7 * sc
     assert np.abs(diag_part[2] - diag_one[2]).max() <= 1e-7 * max(scale)
     assert np.abs(diag_one[2] - x_one[::53]).max() == 0.0
+    # one all-reduce per Krylov iteration (the coefficients, |w|^2, w.r and the lagged |r|^2 travel as one
+    # vector; round 2: three per iteration).  On top: a repeated Gram-Schmidt pass now and then, and one confirming reduction
+    # when an iteration looks converged.
+    print("all-reduces inside Krylov iterations:", comm)
+    assert comm["library_rccl"] == (transport == "library-rccl")
+    assert comm["q_bytes"] == 8 and comm["allreduces"] <= 1.25 * comm["krylov"] + 2 * comm["solves"], comm
     print("krylov iterations per Newton iteration:", world, "ranks", [it[3] for h in hist_part for it in h], "single",
           [it[3] for h in hist_one for it in h])
 

@@ -22,6 +22,7 @@ EXPORTED_SYMBOLS = (
     "fsi_assemble_residual", "fsi_assemble_jacobian", "fsi_solve", "fsi_newton_solve", "fsi_shift",
     "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_get_matrix", "fsi_spmv",
     "fsi_get_timers", "fsi_get_values", "fsi_stress_strain", "fsi_wall_shear_stress", "fsi_calibration_streams", "fsi_set_newton_forcing", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
+    "fsi_rccl_unique_id", "fsi_set_rccl",
 )
 
 
@@ -65,7 +66,7 @@ class FsiTimers(C.Structure):
                 ("krylov_dirs", C.c_int64), ("krylov_cap", C.c_int64), ("schur_nnz", C.c_int64), ("schur_rows", C.c_int64),
                 ("flush_ms", C.c_double), ("flush_calls", C.c_int64), ("schur_ms", C.c_double), ("schur_calls", C.c_int64),
                 ("schur_elem_bytes", C.c_int64), ("spmv_compact", C.c_int64), ("node_pairs", C.c_int64),
-                ("node_vertex_pairs", C.c_int64), ("spmv_fp32_calls", C.c_int64), ("sweep_flags", C.c_int64)]
+                ("node_vertex_pairs", C.c_int64), ("spmv_fp32_calls", C.c_int64), ("sweep_flags", C.c_int64), ("part_allreduces", C.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -257,6 +257,7 @@ int l3_build(FsiCtx* ctx) {
   if (const char* e = getenv("FSI_L3_POST")) L.post = std::max(1, atoi(e));
   if (const char* e = getenv("FSI_L3_CYCLES")) L.cycles = std::max(1, atoi(e));
   if (const char* e = getenv("FSI_L3_ALPHA")) L.alpha = atof(e);
+  if (const char* e = getenv("FSI_L3_TRUE_LMAX")) L.true_lmax = atoi(e);
   L.built = true;                       // one attempt per context, whatever comes of it
   if (nc < 4 * L.aggsize || ctx->h_sc_xyz.size() != 3 * (size_t)nc) return FSI_OK;      // too small to be worth a level
   std::vector<float> cvals(9 * (size_t)nblk), binv(12 * (size_t)nc);
@@ -279,6 +280,38 @@ int l3_build(FsiCtx* ctx) {
   for (int32_t I = 0; I < nagg; ++I) for (int c = 0; c < 3; ++c) cen[3 * (size_t)I + c] /= std::max(1, cnt[I]);
   for (int64_t v = 0; v < nc; ++v) { double s = 0; for (int c = 0; c < 3; ++c) { const double d = xyz[3 * v + c] - cen[3 * (size_t)agg[v] + c]; s += d * d; } rad[agg[v]] += s; }
   for (int32_t I = 0; I < nagg; ++I) rad[I] = std::sqrt(rad[I] / std::max(1, cnt[I])) + 1e-300;
+  // an aggregate whose free vertices are (nearly) collinear, or fewer than three, cannot carry three rotations: their
+  // columns would be linearly dependent and the coarse matrix singular.  R = sum (|d|^2 I - d d^T) over the free vertices
+  // is the rotation block of the tentative Gram matrix; its smallest eigenvalue decides.
+  std::vector<uint8_t> norot(nagg, 0);
+  {
+    std::vector<std::array<double, 9>> R(nagg, std::array<double, 9>{});
+    std::vector<int32_t> nfree(nagg, 0);
+    for (int64_t v = 0; v < nc; ++v) {
+      if (cflag[v]) continue;
+      const int32_t I = agg[v];
+      double d[3];
+      for (int c = 0; c < 3; ++c) d[c] = (xyz[3 * v + c] - cen[3 * (size_t)I + c]) / rad[I];
+      const double d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) R[I][3 * a + b] += (a == b ? d2 : 0.0) - d[a] * d[b];
+      nfree[I] += 1;
+    }
+    for (int32_t I = 0; I < nagg; ++I) {
+      // smallest eigenvalue of the symmetric 3x3 by a few cyclic Jacobi rotations
+      double a[3][3];
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) a[r][c] = R[I][3 * r + c];
+      for (int sweep = 0; sweep < 8; ++sweep)
+        for (int p_ = 0; p_ < 2; ++p_)
+          for (int q = p_ + 1; q < 3; ++q) {
+            if (std::fabs(a[p_][q]) < 1e-300) continue;
+            const double th = 0.5 * std::atan2(2.0 * a[p_][q], a[q][q] - a[p_][p_]), cs = std::cos(th), sn = std::sin(th);
+            for (int k = 0; k < 3; ++k) { const double x = a[k][p_], y = a[k][q]; a[k][p_] = cs * x - sn * y; a[k][q] = sn * x + cs * y; }
+            for (int k = 0; k < 3; ++k) { const double x = a[p_][k], y = a[q][k]; a[p_][k] = cs * x - sn * y; a[q][k] = sn * x + cs * y; }
+          }
+      const double emin = std::min(a[0][0], std::min(a[1][1], a[2][2])), tr = a[0][0] + a[1][1] + a[2][2];
+      norot[I] = nfree[I] < 3 || !(emin > 1e-3 * tr);
+    }
+  }
   std::vector<Row> P(nc);
   for (int64_t v = 0; v < nc; ++v) {
     if (cflag[v]) continue;
@@ -287,13 +320,44 @@ int l3_build(FsiCtx* ctx) {
                  dz = (xyz[3 * v + 2] - cen[3 * (size_t)I + 2]) / rad[I];
     Blk b{};
     b[0] = 1; b[7] = 1; b[14] = 1;                     // translations
-    b[4] = dz; b[5] = -dy;                             // row x: rotations about (x, y, z) -> (0, z, -y)
-    b[6 + 3] = -dz; b[6 + 5] = dx;                     // row y: (-z, 0, x)
-    b[12 + 3] = dy; b[12 + 4] = -dx;                   // row z: (y, -x, 0)
+    if (!norot[I]) {
+      b[4] = dz; b[5] = -dy;                           // row x: rotations about (x, y, z) -> (0, z, -y)
+      b[6 + 3] = -dz; b[6 + 5] = dx;                   // row y: (-z, 0, x)
+      b[12 + 3] = dy; b[12 + 4] = -dx;                 // row z: (y, -x, 0)
+    }
     P[v][I] = b;
   }
+  // largest eigenvalue of B^-1 A on this level by power iteration (the level's sweeps use a Gershgorin bound, several
+  // times larger; a damping 4 / (3 bound) would leave the prolongator almost unsmoothed)
+  double lmax = ctx->sbmg_clmax;
+  {
+    std::vector<double> x(3 * (size_t)nc), y(3 * (size_t)nc);
+    for (int64_t i = 0; i < 3 * nc; ++i) x[i] = cflag[i / 3] ? 0.0 : ((i * 2654435761u) % 1000) / 500.0 - 1.0;
+    double lam = 0.0;
+    for (int it = 0; it < 30; ++it) {
+      double nx = 0.0, ny = 0.0;
+      for (int64_t i = 0; i < nc; ++i) {
+        double t[3] = {0, 0, 0};
+        if (!cflag[i])
+          for (int64_t e = ptr[i]; e < ptr[i + 1]; ++e) {
+            const float* a = &cvals[9 * (size_t)e];
+            const double* xj = &x[3 * (size_t)col[e]];
+            for (int c = 0; c < 3; ++c) t[c] += a[3 * c] * xj[0] + a[3 * c + 1] * xj[1] + a[3 * c + 2] * xj[2];
+          }
+        const float* bi = &binv[12 * (size_t)i];
+        for (int c = 0; c < 3; ++c) y[3 * i + c] = cflag[i] ? 0.0 : bi[4 * c] * t[0] + bi[4 * c + 1] * t[1] + bi[4 * c + 2] * t[2];
+      }
+      for (int64_t i = 0; i < 3 * nc; ++i) { nx += x[i] * x[i]; ny += y[i] * y[i]; }
+      if (!(nx > 0.0) || !(ny > 0.0)) break;
+      lam = std::sqrt(ny / nx);
+      const double s = 1.0 / std::sqrt(ny);
+      for (int64_t i = 0; i < 3 * nc; ++i) x[i] = y[i] * s;
+    }
+    if (lam > 0.0 && std::isfinite(lam)) lmax = std::min(lmax, 1.1 * lam);
+  }
+  L.lmax = lmax;
   // prolongator smoothing: P <- (I - w B^-1 A) P, w = 4 / (3 lmax), with the block-Jacobi scaling of the level's sweeps
-  const double w = (4.0 / 3.0) / std::max(1e-30, ctx->sbmg_clmax);
+  const double w = (4.0 / 3.0) / std::max(1e-30, lmax);
   for (int s = 0; s < L.deg; ++s) {
     std::vector<Row> Q(nc);
     for (int64_t i = 0; i < nc; ++i) {
@@ -388,8 +452,9 @@ int l3_build(FsiCtx* ctx) {
   L.usable = true;
   if (getenv("FSI_DEBUG"))
     fprintf(stderr, "[fsi] solid level 3: %lld vertices -> %d aggregates (%lld unknowns, padded %lld), P %.1f blocks per vertex, "
-            "%lld + %lld Galerkin index triples / pairs\n", (long long)nc, nagg, (long long)L.nd, (long long)L.ndp,
-            (double)npb / std::max<int64_t>(1, nc), (long long)L.ntrip, (long long)L.npair);
+            "%lld + %lld Galerkin index triples / pairs; lmax(B^-1 A) %.3f (Gershgorin bound %.3f), %d aggregates without rotations\n",
+            (long long)nc, nagg, (long long)L.nd, (long long)L.ndp, (double)npb / std::max<int64_t>(1, nc), (long long)L.ntrip,
+            (long long)L.npair, L.lmax, ctx->sbmg_clmax, (int)std::count(norot.begin(), norot.end(), (uint8_t)1));
   return FSI_OK;
 }
 

@@ -1849,3 +1849,26 @@ void launch_residual_csr(hipStream_t st, int64_t n, const int64_t* rowptr, const
 }
 
 }  // namespace fsi
+
+// ---- helpers of the coarse levels' power iteration (largest eigenvalue of the scaled operator, in the sweeps' own layout) --
+namespace fsi {
+__global__ void k_f32_ripple4(int64_t n, float* __restrict__ x) {          // float4 per node, pad lane zero
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t h = (uint32_t)(i * 2654435761u) ^ (uint32_t)(i >> 7);
+    const float a = ((h & 1023) / 512.0f - 1.0f), b = (((h >> 10) & 1023) / 512.0f - 1.0f), c = (((h >> 20) & 1023) / 512.0f - 1.0f);
+    reinterpret_cast<float4*>(x)[i] = make_float4(a, b, c, 0.f);
+  }
+}
+__global__ __launch_bounds__(256) void k_f32_sumsq(int64_t n, const float* __restrict__ x, double* __restrict__ out) {
+  double s = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += (double)x[i] * x[i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0 && s != 0.0) unsafeAtomicAdd(out, s);
+}
+void launch_f32_ripple4(hipStream_t st, int64_t nnodes, float* x) {
+  hipLaunchKernelGGL(k_f32_ripple4, dim3(gridn(nnodes)), dim3(256), 0, st, nnodes, x);
+}
+void launch_f32_sumsq(hipStream_t st, int64_t n, const float* x, double* out) {
+  hipLaunchKernelGGL(k_f32_sumsq, dim3(gridn(n) > 1024 ? 1024 : gridn(n)), dim3(256), 0, st, n, x, out);
+}
+}  // namespace fsi

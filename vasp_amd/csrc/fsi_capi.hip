@@ -97,6 +97,7 @@ int norm2(FsiCtx* ctx, const double* x, double* out) {
 int allreduce(FsiCtx* ctx, double* v, int n) {
   if (!ctx->part) return FSI_OK;
   ctx->allreduce_calls += 1;
+  if (ctx->rccl) return rccl_allreduce_host(ctx, v, n);
   if (ctx->comm.allreduce_sum(ctx->comm.user, v, n) != 0) { ctx->err = "allreduce callback failed"; return FSI_ERR_DEVICE; }
   return FSI_OK;
 }
@@ -105,7 +106,8 @@ int allreduce(FsiCtx* ctx, double* v, int n) {
 int agree(FsiCtx* ctx, int rc) {
   if (!ctx->part) return rc;
   double bad = rc == FSI_OK ? 0.0 : 1.0;
-  if (ctx->comm.allreduce_sum(ctx->comm.user, &bad, 1) != 0) { ctx->err = "allreduce callback failed"; return FSI_ERR_DEVICE; }
+  if (ctx->rccl) { if (rccl_allreduce_host(ctx, &bad, 1) != FSI_OK) return FSI_ERR_DEVICE; }
+  else if (ctx->comm.allreduce_sum(ctx->comm.user, &bad, 1) != 0) { ctx->err = "allreduce callback failed"; return FSI_ERR_DEVICE; }
   ctx->allreduce_calls += 1;
   if (rc == FSI_OK && bad > 0.0) { ctx->err = "another rank of the partitioned job reported an error"; return FSI_ERR_LINEAR; }
   return rc;
@@ -124,6 +126,11 @@ int halo_update(FsiCtx* ctx, double* x) {
   if (!ctx->part) return FSI_OK;
   ctx->halo_calls += 1;
   if (ctx->nsend) launch_gather(ctx->stream, ctx->sendbuf, x, ctx->send_idx.p, ctx->nsend);
+  if (ctx->rccl) {      // pack -> grouped send / recv -> unpack, all on the solver stream: the host does not wait
+    FSICHK(rccl_halo(ctx));
+    if (ctx->nghost) launch_scatter(ctx->stream, x, ctx->recvbuf, ctx->ghost_idx.p, ctx->nghost);
+    return FSI_OK;
+  }
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (ctx->comm.halo_exchange(ctx->comm.user) != 0) { ctx->err = "halo_exchange callback failed"; return FSI_ERR_DEVICE; }
   if (ctx->nghost) launch_scatter(ctx->stream, x, ctx->recvbuf, ctx->ghost_idx.p, ctx->nghost);
@@ -353,7 +360,8 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
           // [lmax / alpha, lmax], then per cycle  e = P A3^-1 P^T r  as the next direction, one sweep that applies it and
           // restarts the recurrence, `post` smoothing sweeps
           const L3Level& L3 = ctx->l3;
-          const double cl = ctx->sbmg_clmax, clmin = cl / L3.alpha, cth = 0.5 * (cl + clmin), cde = 0.5 * (cl - clmin), csig = cth / cde;
+          const double cl = ctx->sbmg_clmax;
+          const double clmin = cl / L3.alpha, cth = 0.5 * (cl + clmin), cde = 0.5 * (cl - clmin), csig = cth / cde;
           double crho = 1.0 / csig;
           launch_cheb_init_b3(st, nc, crhs, ctx->sbmg_cbinv12.p, (float)(1.0 / cth), cx, cr, cd);
           HIPCHK(hipMemsetAsync(cd2, 0, n4c * sizeof(float), st));
@@ -834,6 +842,7 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
   double best = rnorm;
   int since_gain = 0;
   ctx->gcr_stagnated = false;
+  bool rr_pending = false;     // partitioned: the last update's local |r|^2 has not been all-reduced yet (it rides with the next pass)
   while (rnorm > target && *iters < max_it) {
     if (since_gain >= 40 && (f32 || rnorm <= 100.0 * target)) { ctx->gcr_stagnated = true; break; }
     if (ctx->part && ctx->ras) {
@@ -895,6 +904,7 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
           if (ctx->part) {
             FSICHK(gcr_read(ctx, ctx->hcoef_hot.p, nh + 2, hh_hot));
             FSICHK(allreduce(ctx, hh_hot, nh + 2));
+            ctx->part_allreduces += 1;
             HIPCHK(hipMemcpyAsync(ctx->hcoef_hot.p, hh_hot, (size_t)nh * sizeof(double), hipMemcpyHostToDevice, st));
             Phase ph(ctx, &ctx->t_ortho);
             launch_gcr_axpy(st, false, ctx->KQh.p, ctx->ldq, n, nh, ctx->hcoef_hot.p, w, nullptr, ctx->scratch.p, ctx->gcr_out.p);
@@ -909,19 +919,44 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
       for (int pass = 0; pass < 2; ++pass) {
         double h2[2] = {0.0, 0.0};
         if (ctx->part) {
+          // ONE all-reduce per pass: the m coefficients, |w|^2, w.r and - riding along - this rank's part of |r|^2 as the
+          // previous iteration's update kernel left it (the exact norm of the residual this iteration starts from).  What the
+          // update needs follows without a second reduction: |w'|^2 = |w|^2 - |h|^2 (the pass is repeated when that
+          // cancels by more than 1 / reorth, and the repeat measures |w'|^2 directly), w'.r = w.r because r is kept
+          // orthogonal to every q.
           {
             Phase ph(ctx, &ctx->t_ortho);
-            launch_gcr_dots(st, f32, ctx->KQ.p, ctx->ldq, n, m, w, nullptr, ctx->scratch.p, ctx->hcoef.p);
+            launch_gcr_dots(st, f32, ctx->KQ.p, ctx->ldq, n, m, w, r, ctx->scratch.p, ctx->hcoef.p);
           }
-          FSICHK(gcr_read(ctx, ctx->hcoef.p, m + 2, hh));
-          FSICHK(allreduce(ctx, hh, m + 2));
-          HIPCHK(hipMemcpyAsync(ctx->hcoef.p, hh, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
-          {
+          if (ctx->rccl) {
+            // the library's own communicator: the reduction runs on the coefficient vector where it is (device memory, solver
+            // stream) and the update kernel is queued right behind it; the host reads the reduced numbers once, for its
+            // bookkeeping, exactly as in a single context
+            if (rr_pending) HIPCHK(hipMemcpyAsync(ctx->hcoef.p + m + 2, ctx->gcr_out.p + 4, sizeof(double), hipMemcpyDeviceToDevice, st));
+            else HIPCHK(hipMemsetAsync(ctx->hcoef.p + m + 2, 0, sizeof(double), st));
+            FSICHK(rccl_allreduce_dev(ctx, ctx->hcoef.p, m + 3));
+            {
+              Phase ph(ctx, &ctx->t_ortho);
+              launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, w, nullptr, ctx->scratch.p, ctx->gcr_out.p + 2);
+            }
+            HIPCHK(hipMemcpyAsync(hh, ctx->hcoef.p, (size_t)(m + 3) * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+          } else {
+            HIPCHK(hipMemcpyAsync(hh, ctx->hcoef.p, (size_t)(m + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
+            if (rr_pending) HIPCHK(hipMemcpyAsync(hh + m + 2, ctx->gcr_out.p + 4, sizeof(double), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (!rr_pending) hh[m + 2] = 0.0;
+            FSICHK(allreduce(ctx, hh, m + 3));
+            HIPCHK(hipMemcpyAsync(ctx->hcoef.p, hh, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
             Phase ph(ctx, &ctx->t_ortho);
-            launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, w, r, ctx->scratch.p, ctx->gcr_out.p);
+            launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, w, nullptr, ctx->scratch.p, ctx->gcr_out.p + 2);
           }
-          FSICHK(gcr_read(ctx, ctx->gcr_out.p, 2, h2));
-          FSICHK(allreduce(ctx, h2, 2));
+          ctx->part_allreduces += 1;
+          if (rr_pending) { rn2 = hh[m + 2]; rr_pending = false; }      // exact |r|^2 before this iteration's update
+          double hsq = 0.0;
+          for (int j = 0; j < m; ++j) hsq += hh[j] * hh[j];
+          h2[0] = std::max(hh[m] - hsq, 0.0);
+          h2[1] = hh[m + 1];
         } else {
           {
             Phase ph(ctx, &ctx->t_ortho);
@@ -993,9 +1028,24 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
     ctx->kry_iters += 1;
     // |r|: the recurrence value; read back (it is one host wait, shared with nothing else) because the analytic
     // |r|^2 - alpha^2 loses its digits exactly when the iteration converges fast
-    FSICHK(gcr_read(ctx, ctx->gcr_out.p + 4, 1, hh));
-    FSICHK(allreduce(ctx, hh, 1));
-    rnorm = std::sqrt(std::max(hh[0], 0.0));
+    if (ctx->part) {
+      // |r'|^2 = |r|^2 - alpha^2 from the exact |r|^2 this iteration started with; the exact value of |r'|^2 (this rank's
+      // part is in gcr_out[4]) travels with the next pass's reduction.  Only an iteration that looks converged pays a
+      // reduction of its own, to be sure.
+      rn2 = std::max(rn2 - alpha * alpha, 0.0);
+      rr_pending = true;
+      if (std::sqrt(rn2) <= target || !std::isfinite(rn2)) {
+        FSICHK(gcr_read(ctx, ctx->gcr_out.p + 4, 1, hh));
+        FSICHK(allreduce(ctx, hh, 1));
+        ctx->part_allreduces += 1;
+        rn2 = hh[0];
+        rr_pending = false;
+      }
+      rnorm = std::sqrt(std::max(rn2, 0.0));
+    } else {
+      FSICHK(gcr_read(ctx, ctx->gcr_out.p + 4, 1, hh));
+      rnorm = std::sqrt(std::max(hh[0], 0.0));
+    }
     if (ctx->debug_gcr && (*iters % 10 == 0)) {
       fprintf(stderr, "[gcr] it %d |r| %.3e target %.3e m %d  |h_j| > 1e-6/1e-9/1e-12 |w|: %.2f %.2f %.2f of the columns\n", *iters, rnorm, target, m,
               (double)ctx->dbg_sig6 / std::max<int64_t>(1, ctx->dbg_cols), (double)ctx->dbg_sig9 / std::max<int64_t>(1, ctx->dbg_cols),
@@ -1159,6 +1209,39 @@ int solve_bicgstab(FsiCtx* ctx, const double* rhs, double* x, double rtol, int m
 }  // namespace
 
 // Factorisations for the active preconditioner, from the row-equilibrated Jacobian in ctx->A.
+namespace {
+// Largest eigenvalue of a coarse level's scaled operator by power iteration with the level's own sweep kernel: a sweep with
+// c1 = 0, c2 = 1 on a zero residual returns d_out = -(scaled operator) d_in.  The Gershgorin row-sum bound the levels used
+// in round 2 is 2.2x the true value on the solid vertices of the bench mesh - every Chebyshev interval [bound / kappa, bound]
+// built on it reaches that much less far down the spectrum for the same number of sweeps.  work: 4 vectors of n4 floats.
+template <class Sweep>
+int coarse_power_lmax(FsiCtx* ctx, int64_t nnodes, float* work, Sweep&& sweep, double bound, double* out) {
+  hipStream_t st = ctx->stream;
+  const int64_t n4 = 4 * nnodes;
+  float *r = work, *da = work + n4, *db = work + 2 * n4, *x = work + 3 * n4;
+  launch_f32_ripple4(st, nnodes, da);
+  double* acc = ctx->scratch.p + 4100;
+  HIPCHK(hipMemsetAsync(acc, 0, 2 * sizeof(double), st));
+  const int its = 30;
+  for (int k = 0; k < its; ++k) {
+    HIPCHK(hipMemsetAsync(r, 0, n4 * sizeof(float), st));
+    sweep(da, db, x, r);
+    std::swap(da, db);
+    if (k == its - 2) launch_f32_sumsq(st, n4, da, acc);
+    if (k == its - 1) launch_f32_sumsq(st, n4, da, acc + 1);
+  }
+  double h[2] = {0.0, 0.0};
+  HIPCHK(hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  *out = bound;
+  if (h[0] > 0.0 && h[1] > 0.0 && std::isfinite(h[0]) && std::isfinite(h[1])) {
+    const double lam = std::sqrt(h[1] / h[0]);
+    if (std::isfinite(lam) && lam > 0.0) *out = std::min(bound, 1.2 * lam);      // same head room as the fine levels' estimates
+  }
+  return FSI_OK;
+}
+}  // namespace
+
 int refresh_preconditioner(FsiCtx* ctx) {
   Phase ph(ctx, &ctx->t_fac);
   hipStream_t st = ctx->stream;
@@ -1223,7 +1306,16 @@ int refresh_preconditioner(FsiCtx* ctx) {
         float rowmax;
         std::memcpy(&rowmax, &flags[2], sizeof rowmax);
         ctx->mg_ready = !(flags[1] & (32 | 64)) && std::isfinite(rowmax) && rowmax > 0.f;
-        ctx->mg_clmax = rowmax;                   // Gershgorin bound of the Jacobi-scaled coarse operator
+        ctx->mg_clmax = ctx->mg_gersh = rowmax;   // Gershgorin bound of the Jacobi-scaled coarse operator
+        if (ctx->mg_ready && ctx->coarse_power) {
+          double lam = rowmax;
+          FSICHK(coarse_power_lmax(ctx, ctx->mg_nc, ctx->mg_work.p,
+                                   [&](const float* din, float* dout, float* x, float* r) {
+                                     launch_sweep_sc_f32(st, ctx->mg_nc, ctx->mg_cptr.p, ctx->mg_ccol.p, ctx->mg_cc.p, ctx->mg_cflag.p, 0.f, 1.f, din, dout, x, r);
+                                   }, rowmax, &lam));
+          if (getenv("FSI_DEBUG")) fprintf(stderr, "[fsi] displacement coarse level: lmax %.3f by power iteration (Gershgorin bound %.3f)\n", lam, (double)rowmax);
+          ctx->mg_clmax = lam;
+        }
         HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
       }
       launch_to_f32(st, 3 * npairs, ctx->dd_db.p, ctx->dd_db32.p);
@@ -1257,7 +1349,16 @@ int refresh_preconditioner(FsiCtx* ctx) {
       float rowmax;
       std::memcpy(&rowmax, &flags[2], sizeof rowmax);
       ctx->sbmg_ready = !(flags[1] & 64) && std::isfinite(rowmax) && rowmax > 0.f;
-      ctx->sbmg_clmax = rowmax;
+      ctx->sbmg_clmax = ctx->sbmg_gersh = rowmax;
+      if (ctx->sbmg_ready && ctx->coarse_power) {
+        double lam = rowmax;
+        FSICHK(coarse_power_lmax(ctx, ctx->sbmg_nc, ctx->sbmg_work.p,
+                                 [&](const float* din, float* dout, float* x, float* r) {
+                                   launch_sweep_sb_b3(st, ctx->sbmg_nc, ctx->sbmg_cptr.p, ctx->sbmg_ccol.p, ctx->sbmg_cvals.p, ctx->sbmg_cbinv12.p, 0.f, 1.f, din, dout, x, r, 1);
+                                 }, rowmax, &lam));
+        if (getenv("FSI_DEBUG")) fprintf(stderr, "[fsi] solid coarse level: lmax %.3f by power iteration (Gershgorin bound %.3f)\n", lam, (double)rowmax);
+        ctx->sbmg_clmax = lam;
+      }
       ctx->l3.ready = false;
       if (ctx->sbmg_ready && ctx->solid_l3) {
         if (!ctx->l3.built) FSICHK(l3_build(ctx));
@@ -1287,8 +1388,21 @@ int refresh_preconditioner(FsiCtx* ctx) {
     }
     FSICHK(power_lmax_op(ctx, 3 * ctx->N2, [&](const double* in, double* o) { launch_spmv_db(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->vv_db.p, in, o); },
                          ctx->Mvv.vals.p, ctx->diagpos3.p, ctx->mask_f.p, ctx->blk.p, &ctx->lmax_f));
-    FSICHK(power_lmax(ctx, CsrRef{3 * ctx->N2, ctx->rowptr3.p, ctx->cols3.p, ctx->Mdd.vals.p, ctx->diagpos3.p}, nullptr,
-                      ctx->blk.p, &ctx->lmax_d));
+    {
+      // The displacement block (solid mass + mesh Laplacian with a constant coefficient) does not change from one Jacobian
+      // to the next for the forms VaSP uses, and its 40 power iterations on a 3 N2-row CSR matrix were 60 ms of every
+      // refresh: the estimate is kept while a checksum of the block's values (sum of squares, one pass) stays the same.
+      double cs = 0.0;
+      FSICHK(dot_n(ctx, ctx->Mdd.vals.p, ctx->Mdd.vals.p, (int64_t)ctx->Mdd.nnz, &cs));
+      if (ctx->lmax_d_cached > 0.0 && std::isfinite(cs) && std::fabs(cs - ctx->dd_checksum) <= 1e-12 * std::fabs(cs)) {
+        ctx->lmax_d = ctx->lmax_d_cached;
+      } else {
+        FSICHK(power_lmax(ctx, CsrRef{3 * ctx->N2, ctx->rowptr3.p, ctx->cols3.p, ctx->Mdd.vals.p, ctx->diagpos3.p}, nullptr,
+                          ctx->blk.p, &ctx->lmax_d));
+        ctx->lmax_d_cached = ctx->lmax_d;
+        ctx->dd_checksum = cs;
+      }
+    }
     FSICHK(power_lmax_op(ctx, ctx->V, [&](const double* in, double* o) { schur_apply(ctx, in, o, ctx->blk.p + 19 * 3 * ctx->N2); },
                          ctx->s_vals.p, ctx->s_diagpos.p, nullptr, ctx->blk.p, &ctx->lmax_p));
     if (ctx->schur_fp32) {
@@ -1350,6 +1464,8 @@ int refresh_preconditioner(FsiCtx* ctx) {
       prev_out = zout;
       if (attempt == 7) { ctx->prec_bad = true; break; }      // reported by fsi_solve: assembling such a Jacobian is legal
       ctx->lmax_s *= 1.6; ctx->lmax_f *= 1.6; ctx->lmax_p *= 1.6; ctx->lmax_d *= 1.6;
+      ctx->sbmg_clmax = std::min(ctx->sbmg_clmax * 1.6, std::max(ctx->sbmg_clmax, (double)ctx->sbmg_gersh));      // towards the row-sum bounds
+      ctx->mg_clmax = std::min(ctx->mg_clmax * 1.6, std::max(ctx->mg_clmax, (double)ctx->mg_gersh));
     }
     return FSI_OK;
   }
@@ -1427,6 +1543,7 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->sbmg_chw.release(); ctx->sbmg_cvals.release(); ctx->sbmg_cbinv12.release(); ctx->sbmg_work.release(); ctx->sbmg_cptr.release();
   ctx->sbmg_chptr.release(); ctx->sbmg_flag.release(); ctx->sbmg_cflag.release();
   ctx->l3.release();
+  rccl_destroy(ctx);
   ctx->s_vals32.release(); ctx->s_dinv32.release(); ctx->s_work32.release(); ctx->s_rec.release(); ctx->s_dinv.release();
   ctx->s_ploc.release(); ctx->s_tile_uptr.release(); ctx->s_tile_ulist.release();
   ctx->fs_rows.release(); ctx->fs_col.release(); ctx->fs_ptr.release(); ctx->fs_src.release();
@@ -2024,6 +2141,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
         FSICHK(upload(ctx, ctx->mg_cones, cones));
         // the same hierarchy on the compact solid numbering (3x3-block operator of the velocity predictor)
         if (const char* e = getenv("FSI_SOLID_MG")) ctx->solid_mg = atoi(e);
+        if (const char* e = getenv("FSI_COARSE_POWER")) ctx->coarse_power = atoi(e);
         if (const char* e = getenv("FSI_SBMG_PRE")) ctx->sbmg_pre = atoi(e);
         if (const char* e = getenv("FSI_SBMG_POST")) ctx->sbmg_post = atoi(e);
         if (const char* e = getenv("FSI_SBMG_CITS")) ctx->sbmg_cits = atoi(e);
@@ -2221,7 +2339,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   ctx->kry_cap = cap;
   HIPCHK(ctx->KZ.alloc((size_t)cap * ctx->ldz));
   HIPCHK(ctx->KQ.alloc((size_t)cap * ctx->ldq * (ctx->kry_fp32_policy == 1 ? 4 : 8)));      // FP64-sized unless FP32 is forced
-  HIPCHK(ctx->hcoef.alloc(cap + 2));
+  HIPCHK(ctx->hcoef.alloc(cap + 4));
   if (ctx->kry_fp32_policy != 0) { HIPCHK(ctx->KQh.alloc((size_t)32 * ctx->ldq)); HIPCHK(ctx->hcoef_hot.alloc(40)); }
   ctx->hot_slots.assign(32, -1);
   HIPCHK(ctx->gcr_out.alloc(8));
@@ -2307,6 +2425,18 @@ int fsi_set_partition(FsiCtx* ctx, int64_t num_owned_cells, int64_t n_ghost, con
   if (ctx->comm.allreduce_sum(ctx->comm.user, &overlap, 1) != 0) { ctx->err = "allreduce callback failed"; return FSI_ERR_DEVICE; }
   ctx->ras = overlap > 0.0;
   return FSI_OK;
+}
+
+int fsi_rccl_unique_id(void* id128) {
+  if (!id128) return FSI_ERR_INVALID;
+  std::string err;
+  return rccl_unique_id(id128, &err);
+}
+
+int fsi_set_rccl(FsiCtx* ctx, const void* id128, int32_t rank, int32_t world, const int64_t* send_counts, const int64_t* recv_counts) {
+  if (!ctx) return FSI_ERR_INVALID;
+  if (!id128 || world < 1 || rank < 0 || rank >= world || !send_counts || !recv_counts) { ctx->err = "fsi_set_rccl: bad arguments"; return FSI_ERR_INVALID; }
+  return rccl_init(ctx, id128, rank, world, send_counts, recv_counts);
 }
 
 int fsi_set_pressure_facets(FsiCtx* ctx, int64_t nf, const int32_t* facet_nodes, const int32_t* plus_cell) {
@@ -2792,7 +2922,8 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
                    ctx->op32_products,
                    (int64_t)((ctx->tiled && ctx->fused_sweeps ? 1 : 0) | (ctx->tiled && ctx->fused_sweeps && ctx->sweeps_fp16 ? 2 : 0) |
                              (ctx->solid_fp32 ? 4 : 0) | (ctx->solid_fp32 && ctx->solid_block_jacobi && ctx->solid_fused ? 8 : 0) |
-                             (ctx->sbmg_ready ? 16 : 0) | (ctx->mg_ready ? 32 : 0))};
+                             (ctx->sbmg_ready ? 16 : 0) | (ctx->mg_ready ? 32 : 0) | (ctx->l3.ready ? 64 : 0)),
+                   ctx->part_allreduces};
   if (reset) {
     for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_flush, &ctx->t_sch, &ctx->t_kry, &ctx->t_ss, &ctx->t_db, &ctx->t_sc}) {
       t->ms = 0.0;
@@ -2803,6 +2934,7 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
     ctx->inner_its[0] = ctx->inner_its[1] = ctx->inner_its[2] = 0;
     ctx->inner_calls = 0;
     ctx->ortho_q_cols = ctx->ortho_q_launches = ctx->ortho_z_cols = ctx->ortho_z_launches = 0;
+    ctx->part_allreduces = 0;
     ctx->sample_budget = 16;      // the sweep kernels of the next 16 preconditioner applications are sampled with events
   }
   return FSI_OK;

@@ -45,6 +45,8 @@ struct L3Level {
   bool built = false, usable = false, ready = false;
   int aggsize = 48, deg = 1, pre = 6, post = 6, cycles = 3;
   double alpha = 30.0;                         // smoothing interval of the P1 level inside the cycle: [lmax / alpha, lmax]
+  double lmax = 0.0;                           // largest eigenvalue of B^-1 A2 (host power iteration at build time)
+  int true_lmax = 0;                           // 1: the cycle's smoothing interval ends at 1.1 lmax instead of the Gershgorin bound
   int64_t nagg = 0, nd = 0, ndp = 0, npb = 0, ntrip = 0, npair = 0, nslot = 0;
   DevBuf<int64_t> pptr, tptr;
   DevBuf<int32_t> pcol, tvert, tblk, tcol, trip_e, trip_b, trip_t, pair_b, pair_t;
@@ -166,6 +168,13 @@ struct FsiCtx {
   double *sendbuf = nullptr, *recvbuf = nullptr;
   FsiComm comm{};
   int64_t halo_calls = 0, allreduce_calls = 0;
+  // library-side RCCL transport (fsi_set_rccl, fsi_rccl.hip): communicator, per-peer halo counts (doubles), staging buffer
+  bool rccl = false;
+  void* rccl_comm = nullptr;
+  int rccl_rank = 0, rccl_world = 1;
+  std::vector<int64_t> rccl_send, rccl_recv;
+  fsi::DevBuf<double> rccl_red;
+  int64_t rccl_allreduces = 0, rccl_halos = 0;
   bool ras = false;                          // restricted additive Schwarz on the overlap: agreed by all ranks in fsi_set_partition
   bool debug_gcr = false;
   int64_t dbg_cols = 0, dbg_sig6 = 0, dbg_sig9 = 0, dbg_sig12 = 0;   // FSI_DEBUG_GCR: how many Gram-Schmidt coefficients matter
@@ -301,6 +310,10 @@ struct FsiCtx {
   fsi::DevBuf<uint32_t> dd_rec, vv_rec, sb_rec;   // packed FP16 records: [pairs], [pairs][2], [blocks][6] 32-bit words
   bool fused_sweeps = true;                  // FSI_FUSED_SWEEPS=0: product and Chebyshev update of the FP32 sweeps as two launches
 
+  float sbmg_gersh = 2.f, mg_gersh = 2.f;     // the row-sum bounds of the two coarse levels (fallback of the self-test)
+  int coarse_power = 1;                      // FSI_COARSE_POWER=0: coarse levels' Chebyshev intervals end at the Gershgorin bound (round 2)
+  double lmax_d_cached = 0.0, dd_checksum = 0.0;   // largest eigenvalue of the (constant) displacement block, and what it was computed for
+  int64_t part_allreduces = 0;               // partitioned runs: all-reduces issued inside the Krylov iterations (tests count them)
   int kry_fp32_failures = 0;                 // cycles that lost the system in FP32 storage (policy 2 -> 3); two of them pin FP64
   double tol_hint = 0.0, bnorm_max = 0.0;     // fsi_newton_solve -> solve_gcr: lowest linear tolerance to expect; largest |b| seen
   double gcr_reorth = 0.0;                   // FSI_GCR_REORTH: second Gram-Schmidt pass when |w'| < reorth |w| (0: automatic)

@@ -78,6 +78,17 @@ void launch_l2norm(hipStream_t st, int64_t C, const ElemArrays& ea, const double
 void launch_jacobian(hipStream_t st, int part, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
                      const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals);
 
+void launch_f32_ripple4(hipStream_t st, int64_t nnodes, float* x);                 // pseudo-random float4 per node, pad lane 0
+void launch_f32_sumsq(hipStream_t st, int64_t n, const float* x, double* out);      // out += sum x^2 (out zeroed by the caller)
+
+// fsi_rccl.hip — collectives issued by the library on the solver stream (RCCL resolved with dlopen)
+int rccl_unique_id(void* out128, std::string* err);
+int rccl_init(FsiCtx* ctx, const void* id128, int rank, int world, const int64_t* send_counts, const int64_t* recv_counts);
+void rccl_destroy(FsiCtx* ctx);
+int rccl_allreduce_dev(FsiCtx* ctx, double* dptr, int64_t n);   // in place, device memory, on the solver stream
+int rccl_allreduce_host(FsiCtx* ctx, double* v, int n);         // host values through a staging buffer (one wait)
+int rccl_halo(FsiCtx* ctx);                                     // sendbuf -> peers' recvbuf, grouped send / recv
+
 // fsi_amg.hip — dense third level of the solid block's cycle (see there)
 int l3_build(FsiCtx* ctx);                                   // once per context: aggregates + frozen smoothed prolongator (host)
 int l3_refresh(FsiCtx* ctx);                                 // every Jacobian: Galerkin operator + explicit inverse (device)

@@ -299,6 +299,24 @@ class DistBackend:
                                                   C.c_void_p(self.sendbuf.data_ptr()), C.c_void_p(self.recvbuf.data_ptr()),
                                                   C.byref(self._comm)))
         self.history = self.hb.history
+        # VASPFSI_RCCL=1: the library issues the collectives itself on its solver stream (fsi_set_rccl): no callback, no
+        # host staging, no device synchronise per exchange.  Needs one rank per GPU (RCCL refuses two ranks on one device);
+        # the torch.distributed transport above stays the default.
+        self.library_rccl = False
+        if os.environ.get("VASPFSI_RCCL", "0") == "1":
+            if not self.on_gpu_wire:
+                raise RuntimeError("VASPFSI_RCCL=1 needs the nccl backend (one rank per GPU)")
+            ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if self.rank == 0:
+                buf = (C.c_char * 128)()
+                self.hb._check(self.lib.fsi_rccl_unique_id(buf))
+                ident.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+            dist.broadcast(ident, src=0)
+            raw = bytes(ident.cpu().numpy().tobytes())
+            sc = np.ascontiguousarray(p.send_counts, dtype=np.int64)
+            rc = np.ascontiguousarray(p.recv_counts, dtype=np.int64)
+            self.hb._check(self.lib.fsi_set_rccl(self.ctx, C.c_char_p(raw), self.rank, self.world, _ptr(sc), _ptr(rc)))
+            self.library_rccl = True
 
     # ---- transport (called back from inside fsi_solve / fsi_newton_solve) ------------------------------------------
     def _allreduce(self, _user, vals, n):
