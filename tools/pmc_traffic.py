@@ -5,7 +5,7 @@ the driver first streams a known number of bytes with 4-, 8-, 16- and 32-byte lo
 (k_cal_read<T> / k_cal_write<T>); the factor bytes / (counter * 1024) of the matching width corrects every other kernel.
 
     python tools/pmc_traffic.py FETCH_summary.csv WRITE_summary.csv CAL_BYTES [CAL_FETCH_summary.csv CAL_WRITE_summary.csv]
-        > profiles/r02_pmc_traffic.json
+        > profiles/r03_pmc_traffic.json
 (the calibration kernels may come from a separate, short run of tools/pmc_driver.py: last two arguments)
 """
 import csv, json, sys
@@ -18,6 +18,15 @@ def load(path):
 
 fetch, write, cal_bytes = load(sys.argv[1]), load(sys.argv[2]), float(sys.argv[3])
 cal_fetch, cal_write = (load(sys.argv[4]), load(sys.argv[5])) if len(sys.argv) > 5 else (fetch, write)
+# the bench line of the profiled command (7th argument): which workload the counters belong to - bench.py only quotes them for
+# a run of the same size
+workload = {}
+if len(sys.argv) > 6:
+    try:
+        j = json.loads(open(sys.argv[6]).read().strip().splitlines()[-1])
+        workload = {"tets": j["config"]["tets"], "dofs": j["config"]["dofs"], "steps": j["steps"], "warmup": j["warmup"]}
+    except Exception as e:                      # the counters are still valid; only the tag is missing
+        workload = {"workload_error": str(e)}
 def factor(table, kern, typ):
     for name, (v, n) in table.items():
         if kern in name and typ in name and v > 0:
@@ -48,5 +57,5 @@ for name in sorted(set(fetch) | set(write)):
     per_launch[short] = f + w
     detail[short] = {"fetch_bytes": f, "write_bytes": w, "raw_fetch_KiB": fetch.get(name, (0.0, 0))[0],
                      "raw_write_KiB": write.get(name, (0.0, 0))[0], "launches": fetch.get(name, (0, 0))[1], "widths": [rk, wk]}
-print(json.dumps({"unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, KiB counters x 1024 x calibration factor of the access width)",
+print(json.dumps({**workload, "unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, KiB counters x 1024 x calibration factor of the access width)",
                   "calibration_bytes": cal_bytes, "calibration_factors": cal, "per_launch_bytes": per_launch, "detail": detail}, indent=1))

@@ -1533,9 +1533,9 @@ __global__ __launch_bounds__(256) void k_sweep_csr_f32(int64_t n, const int64_t*
 // noise per sweep, which on a coarse mesh with a pressure-dominated right-hand side exceeded the velocity residual the outer
 // iteration was trying to reduce (tests/test_gpu_parity.py::test_properties_on_generated_mesh made no progress at all).
 // The vectors are 5 V doubles against ~65 V matrix entries: the bytes per sweep are those of the all-FP32 form.
-template <int LPR, int KS>       // lanes per row, strips issued together: LPR x KS entries per round
+template <int LPR, int KS, class VT = float>       // lanes per row, strips issued together: LPR x KS entries per round; VT: value storage
 __global__ __launch_bounds__(256) void k_sweep_csr_mixed(int64_t n, const int64_t* __restrict__ rowptr,
-                                                         const int32_t* __restrict__ cols, const float* __restrict__ vals,
+                                                         const int32_t* __restrict__ cols, const VT* __restrict__ vals,
                                                          const int64_t* __restrict__ diagpos, const double* __restrict__ dvals,
                                                          double c1, double c2, const double* __restrict__ din,
                                                          double* __restrict__ dout, double* __restrict__ x, double* __restrict__ r) {
@@ -1554,14 +1554,14 @@ __global__ __launch_bounds__(256) void k_sweep_csr_mixed(int64_t n, const int64_
       const int64_t b = rowptr[i + 1];
       for (int64_t e = rowptr[i] + sub; e < b; e += LPR * KS) {
         int k[KS];
-        float v[KS];
+        VT v[KS];
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
           const bool in = e + j * LPR < b;
           const int64_t ej = in ? e + j * LPR : e;
           k[j] = cols[ej];
           v[j] = vals[ej];
-          if (!in) v[j] = 0.f;
+          if (!in) v[j] = (VT)0;
         }
         double dj[KS];
 #pragma unroll
@@ -1596,6 +1596,15 @@ void launch_sweep_csr_mixed(hipStream_t st, int64_t n, const int64_t* rowptr, co
     hipLaunchKernelGGL((k_sweep_csr_mixed<4, 16>), dim3((unsigned)blocks), dim3(256), 0, st, n, rowptr, cols, vals, diagpos, dvals, c1, c2, din, dout, x, r);
   else
     hipLaunchKernelGGL((k_sweep_csr_mixed<8, 8>), dim3((unsigned)blocks), dim3(256), 0, st, n, rowptr, cols, vals, diagpos, dvals, c1, c2, din, dout, x, r);
+}
+// all-FP64 storage (FSI_SCHUR_FP32=0, the "FP64" reading of BASELINE configs[1]): the same fused sweep on the FP64 values;
+// round 2 ran this case as a generic CSR product plus a separate update kernel (two launches, 54 us per sweep)
+void launch_sweep_csr_f64(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const double* vals,
+                          const int64_t* diagpos, double c1, double c2, const double* din, double* dout, double* x, double* r) {
+  int64_t blocks = (n + 31) / 32;
+  if (blocks > 32768) blocks = 32768;
+  hipLaunchKernelGGL((k_sweep_csr_mixed<8, 8, double>), dim3((unsigned)blocks), dim3(256), 0, st, n, rowptr, cols, vals, diagpos, vals, c1, c2,
+                     din, dout, x, r);
 }
 // The Schur sweep on packed records (FP16 value + 16-bit tile-local column, 4 bytes per entry instead of 8) with the d entries
 // of a 256-row tile's columns staged once in LDS (FP64; the tile of a two-ring pattern sees ~2-3 k distinct columns).

@@ -502,6 +502,22 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
       }
     }
     ctx->inner_its[1] += ctx->cheb_its_p;
+  } else if (ctx->cheb_its_p > 0 && ctx->fused_sweeps) {
+    // all-FP64 Schur sweeps, product fused with the Chebyshev update (one launch per sweep)
+    const double lmax = ctx->lmax_p, lmin = lmax / ctx->cheb_kappa_p, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
+    double rho = 1.0 / sig;
+    double *pr = IW, *pa = IW + V, *pb = IW + 2 * V;
+    launch_cheb_init(st, V, nullptr, tp, ctx->s_diagpos.p, ctx->s_vals.p, 1.0 / th, dp, pr, pa);
+    for (int k = 0; k < ctx->cheb_its_p; ++k) {
+      const double rn = 1.0 / (2.0 * sig - rho);
+      const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->sch_ev0[0];
+      if (timed) (void)hipEventRecord(ctx->sch_ev0[k], st);
+      launch_sweep_csr_f64(st, V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->s_vals.p, ctx->s_diagpos.p, rn * rho, 2.0 * rn / de, pa, pb, dp, pr);
+      if (timed) { (void)hipEventRecord(ctx->sch_ev1[k], st); ctx->sch_samples_pending = k + 1; }
+      std::swap(pa, pb);
+      rho = rn;
+    }
+    ctx->inner_its[1] += ctx->cheb_its_p;
   } else if (ctx->cheb_its_p > 0) {
     int sample = 0;
     cheb_solve_op(ctx, V,
@@ -1104,7 +1120,18 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
     const bool f32 = ctx->kry_fp32 != 0;
     const double target = f32 ? std::max(rtol * bnorm, 1e-5 * rstart) : rtol * bnorm;
     FSICHK(gcr_cycle(ctx, r, x, target, ctx->gs_rtol, max_it, iters, &rnorm));
-    if (!f32) break;
+    if (!f32) {
+      // FP64 basis: one cycle, unless it stalled above the target (a tolerance near round-off: the recurrence residual and
+      // the true one have drifted apart).  Then the cycle is restarted from the true residual b - A x - with every kept
+      // direction still in place, so the restart costs one product and one projection - at most twice.
+      if (ctx->gcr_stagnated && rnorm > rtol * bnorm && cyc < 2 && *iters < max_it) {
+        FSICHK(true_residual());
+        if (rnorm <= rtol * bnorm) break;
+        rstart = rnorm;
+        continue;
+      }
+      break;
+    }
     const bool final_cycle = target <= rtol * bnorm * (1.0 + 1e-12);
     if (final_cycle && rtol >= 1e-4 && !ctx->op32_ok) break;
     FSICHK(true_residual());
@@ -1132,9 +1159,9 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
     rstart = rnorm;
   }
   *relres = rnorm / bnorm;
-  // stagnation within a factor 10 of a tolerance below 1e-9: the answer is as accurate as FP64 makes it on this system, and
+  // stagnation within a factor 100 of a tolerance below 1e-9 (after the restarts above): the answer is as accurate as FP64 makes it on this system, and
   // the caller (Newton's own residual check) judges the step; reported through relres
-  if (ctx->gcr_stagnated && rtol <= 1e-9 && rnorm <= 10.0 * rtol * bnorm) return FSI_OK;
+  if (ctx->gcr_stagnated && rtol <= 1e-9 && rnorm <= 100.0 * rtol * bnorm) return FSI_OK;
   if (!(rnorm <= rtol * bnorm)) {
     char buf[160];
     snprintf(buf, sizeof buf, "GCR: no convergence in %d iterations (relres %.3e, tol %.1e)", *iters, *relres, rtol);

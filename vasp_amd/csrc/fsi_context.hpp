@@ -223,7 +223,7 @@ struct FsiCtx {
   fsi::DevBuf<double> mg_Ac;
   fsi::DevBuf<float> mg_cc, mg_d0, mg_dcinv4, mg_cones, mg_work;
   fsi::DevBuf<uint8_t> mg_cflag;
-  int mg_pre = 4, mg_post = 6, mg_cits = 40;  // fine Chebyshev sweeps before / after the coarse solve; coarse sweeps
+  int mg_pre = 3, mg_post = 5, mg_cits = 24;  // fine Chebyshev sweeps before / after the coarse solve; coarse sweeps (round 2: 4, 6, 40 on the Gershgorin interval)
   double mg_alpha = 20.0, mg_ckappa = 250.0, mg_clmax = 2.0;   // smoothing interval [lmax/alpha, lmax]; coarse interval
   fsi::SubMat Mdd, Mvv, Ms;                  // A_dd, Avv~, sparsified Schur complement (ILU only)
   fsi::DevBuf<double> blk;                   // work vectors of the block preconditioner
@@ -250,9 +250,9 @@ struct FsiCtx {
   std::vector<int64_t> h_sc_ptr;             // host copies of the P1 level's pattern and vertex coordinates (level-3 set-up)
   std::vector<int32_t> h_sc_col;
   std::vector<double> h_sc_xyz;
-  fsi::L3Level l3;                           // FSI_SOLID_L3=0: the P1 level is "solved" by sbmg_cits plain sweeps as in round 2
-  int solid_l3 = 1;
-  int sbmg_pre = 16, sbmg_post = 16, sbmg_cits = 200;
+  fsi::L3Level l3;                           // FSI_SOLID_L3=1: two-grid cycles with the dense aggregate level instead of sbmg_cits plain sweeps
+  int solid_l3 = 0;                          // measured in round 3: no gain over plain sweeps on a correct interval
+  int sbmg_pre = 16, sbmg_post = 16, sbmg_cits = 90;      // round 2: 200 coarse sweeps on an interval that ended at 2.2x the largest eigenvalue
   double sbmg_alpha = 200.0, sbmg_ckappa = 4000.0, sbmg_clmax = 2.0;
   int64_t nfs = 0;                           // fluid-interior velocity rows with solid columns (coupling of the predictor)
   fsi::DevBuf<int32_t> fs_rows, fs_col;

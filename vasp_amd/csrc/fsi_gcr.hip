@@ -235,9 +235,16 @@ void dots_t(hipStream_t st, const void* Q, int64_t ldq, int64_t n, int m, const 
   int np = (int)((n + 16383) / 16384);
   if (np < 1) np = 1;
   if (np > npmax) np = npmax;
-  constexpr int NC = sizeof(QT) == 4 ? 8 : 4;
-  const int ngroups = (m + NC - 1) / NC;
-  hipLaunchKernelGGL((k_gcr_dots<QT, NC>), dim3(np, ngroups + 1), dim3(256), 0, st, static_cast<const QT*>(Q), ldq, n, m, w, r, scratch);
+  // columns per read of w: 8 for FP32 and (round 3) for FP64 columns: w is re-read for 1/8 instead of 1/4 of Q's bytes; FSI_GCR_NC64=4: round 2
+  static const int nc64 = getenv("FSI_GCR_NC64") ? atoi(getenv("FSI_GCR_NC64")) : 8;      // measured: 1 930 -> 1 898 ms per 20 bench steps
+  if (sizeof(QT) == 8 && nc64 == 8) {
+    const int ngroups = (m + 7) / 8;
+    hipLaunchKernelGGL((k_gcr_dots<QT, 8>), dim3(np, ngroups + 1), dim3(256), 0, st, static_cast<const QT*>(Q), ldq, n, m, w, r, scratch);
+  } else {
+    constexpr int NC = sizeof(QT) == 4 ? 8 : 4;
+    const int ngroups = (m + NC - 1) / NC;
+    hipLaunchKernelGGL((k_gcr_dots<QT, NC>), dim3(np, ngroups + 1), dim3(256), 0, st, static_cast<const QT*>(Q), ldq, n, m, w, r, scratch);
+  }
   hipLaunchKernelGGL(k_gcr_sum, dim3(m + 2), dim3(256), 0, st, scratch, np, out);
 }
 template <class QT>

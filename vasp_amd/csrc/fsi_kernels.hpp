@@ -78,6 +78,8 @@ void launch_l2norm(hipStream_t st, int64_t C, const ElemArrays& ea, const double
 void launch_jacobian(hipStream_t st, int part, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
                      const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals);
 
+void launch_sweep_csr_f64(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const double* vals,
+                          const int64_t* diagpos, double c1, double c2, const double* din, double* dout, double* x, double* r);
 void launch_f32_ripple4(hipStream_t st, int64_t nnodes, float* x);                 // pseudo-random float4 per node, pad lane 0
 void launch_f32_sumsq(hipStream_t st, int64_t n, const float* x, double* out);      // out += sum x^2 (out zeroed by the caller)
 
