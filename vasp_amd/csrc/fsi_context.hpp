@@ -313,6 +313,19 @@ struct FsiCtx {
   float sbmg_gersh = 2.f, mg_gersh = 2.f;     // the row-sum bounds of the two coarse levels (fallback of the self-test)
   int coarse_power = 1;                      // FSI_COARSE_POWER=0: coarse levels' Chebyshev intervals end at the Gershgorin bound (round 2)
   double lmax_d_cached = 0.0, dd_checksum = 0.0;   // largest eigenvalue of the (constant) displacement block, and what it was computed for
+  // Compression of the kept Krylov space (FSI_KRYLOV_COMPRESS="soft:keep", off by default): when more
+  // than `soft` directions are kept at the end of a solve they are replaced by `keep` combinations - the part of the space
+  // on which the preconditioned operator B = A M^-1 deviates most from the identity (dominant right singular vectors of
+  // Q^T (B - I) Q, which the Gram-Schmidt coefficients give for free: B q_k = (B r_k - B r_{k+1}) / alpha_k) plus the last
+  // solutions.  rz_C[i + cap j] = q_i . B q_j, rz_known[j]: column j is known.
+  int rz_soft = 0, rz_keep = 0;
+  std::vector<double> rz_C, rz_prev_h, rz_a;
+  std::vector<uint8_t> rz_known;
+  std::vector<std::vector<double>> rz_sols;
+  int rz_prev_slot = -1;
+  double rz_prev_alpha = 0.0;
+  int64_t rz_compressions = 0;
+  fsi::DevBuf<double> rz_coef;
   int64_t part_allreduces = 0;               // partitioned runs: all-reduces issued inside the Krylov iterations (tests count them)
   int kry_fp32_failures = 0;                 // cycles that lost the system in FP32 storage (policy 2 -> 3); two of them pin FP64
   double tol_hint = 0.0, bnorm_max = 0.0;     // fsi_newton_solve -> solve_gcr: lowest linear tolerance to expect; largest |b| seen

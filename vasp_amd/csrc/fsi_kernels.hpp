@@ -153,6 +153,7 @@ void launch_gcr_update(hipStream_t st, bool fp32, void* Q, int64_t ldq, double* 
                        const double* w, const double* z, double inv_wn, double alpha, double* r, double* qd,
                        double* scratch, double* out1);
 // x += sum_j y[j] Z_j; Z_slots[k] = sum_j cn[k * m + j] Z_j for k < knew (<= 32); cn has gcr_flush_width(knew) columns
+void launch_gcr_combine(hipStream_t st, int elem_bytes, void* S, int64_t ld, int64_t n, int m, const double* c, int knew, int64_t out0);
 int gcr_flush_width(int knew);
 void launch_gcr_flush(hipStream_t st, double* Z, int64_t ldz, int64_t n, int m, const double* y, const double* cn,
                       const int32_t* slots, int knew, double* x);
