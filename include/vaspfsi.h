@@ -252,8 +252,9 @@ typedef struct FsiTimers {
                                                         cycle ready, 5 displacement two-level cycle ready, 6 solid
                                                         dense third level ready                                       */
   int64_t part_allreduces;                           /* partitioned runs: all-reduces issued inside Krylov iterations
-                                                        (one per Gram-Schmidt pass; + one per pass of the FP64 window
-                                                        while Q is FP32; + one when an iteration looks converged)    */
+                                                        (FP64 basis: one per Gram-Schmidt pass; FP32 basis: two per pass
+                                                        + one for its FP64 window; + one when an iteration looks
+                                                        converged)                                                    */
 } FsiTimers;
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
 /* Measurement aid: streams `bytes` of the (idle) Krylov store once per kernel with 4-, 8-, 16- and 32-byte loads and

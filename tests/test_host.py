@@ -301,3 +301,17 @@ def test_host_state_is_fetched_only_when_a_hook_reads_it(tmp_path):
                         "--save-step", "1000", "--checkpoint-step", "1000", "--new-arguments",
                         f"mesh_path={GOLDEN / 'cylinder' / 'cylinder.h5'}"], backend_factory=Counting, out=print)
     assert calls.count("n") <= 1 and "n-1" not in calls          # only the checkpoint / frame of step 0 reads the vector
+
+
+def test_config_file_is_read_and_the_command_line_wins(tmp_path):
+    """`turtleFSI -p problem -c my_config.config` [REF docs/simulation.md:19-31]: `key = value` lines, option names without
+    their dashes or problem-file parameters; precedence file < command line, as ConfigArgParse gives turtleFSI."""
+    from vasp_amd.monolithic import parse
+    cfg = tmp_path / "my_config.config"
+    cfg.write_text("# a comment\ndt = 0.002\nend-time: 0.5\ntheta 0.6\nsave-deg = 2\nverbose = False\n"
+                   "mesh_path = some/mesh.h5   ; problem-file key\nfsi_region = [0.0, 1.0, 2.0, 3.5]\n")
+    a = parse(["-p", "cylinder", "-c", str(cfg)])
+    assert a["dt"] == 0.002 and a["T"] == 0.5 and a["theta"] == 0.6 and a["save_deg"] == 2 and a["verbose"] is False
+    assert a["mesh_path"] == "some/mesh.h5" and a["fsi_region"] == [0.0, 1.0, 2.0, 3.5] and "config" not in a
+    b = parse(["-p", "cylinder", "-c", str(cfg), "-dt", "0.01", "--new-arguments", "mesh_path=other.h5"])
+    assert b["dt"] == 0.01 and b["T"] == 0.5 and b["mesh_path"] == "other.h5"

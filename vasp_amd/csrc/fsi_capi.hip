@@ -1109,25 +1109,35 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
       for (int pass = 0; pass < 2; ++pass) {
         double h2[2] = {0.0, 0.0};
         if (ctx->part) {
-          // ONE all-reduce per pass: the m coefficients, |w|^2, w.r and - riding along - this rank's part of |r|^2 as the
-          // previous iteration's update kernel left it (the exact norm of the residual this iteration starts from).  What the
-          // update needs follows without a second reduction: |w'|^2 = |w|^2 - |h|^2 (the pass is repeated when that
-          // cancels by more than 1 / reorth, and the repeat measures |w'|^2 directly), w'.r = w.r because r is kept
-          // orthogonal to every q.
+          // ONE all-reduce per pass while the basis is FP64: the m coefficients, |w|^2, w.r and - riding along - this rank's
+          // part of |r|^2 as the previous iteration's update kernel left it (the exact norm of the residual this iteration
+          // starts from).  What the update needs follows without a second reduction: |w'|^2 = |w|^2 - |h|^2 (the pass is
+          // repeated when that cancels by more than 1 / reorth, and the repeat measures |w'|^2 directly), w'.r = w.r because
+          // r is kept orthogonal to every q.  With an FP32 basis the identity is not good enough: the stored columns are
+          // orthonormal to 1e-7 only, |w'|^2 comes out wrong by h^T (Q^T Q - I) h, the new column is then not a unit vector
+          // and every later projection on it is off by that factor (measured: a 2-rank run lost a cycle and fell back to
+          // FP64, a 1-rank run needed 184 instead of 50 iterations every other time) - so the FP32 basis pays a second,
+          // two-number reduction for the exact |w'|^2 and w'.r after the update of w, as in round 2.
           {
             Phase ph(ctx, &ctx->t_ortho);
             launch_gcr_dots(st, f32, ctx->KQ.p, ctx->ldq, n, m, w, r, ctx->scratch.p, ctx->hcoef.p);
           }
-          if (ctx->rccl) {
-            // the library's own communicator: the reduction runs on the coefficient vector where it is (device memory, solver
-            // stream) and the update kernel is queued right behind it; the host reads the reduced numbers once, for its
+          static const bool rccl_host = getenv("FSI_RCCL_HOST_REDUCE") != nullptr;      // debugging aid: stage the reductions through the host
+          double exact2[2] = {0.0, 0.0};
+          if (ctx->rccl && !rccl_host) {
+            // the library's own communicator: the reductions run on the vectors where they are (device memory, solver stream)
+            // and the update kernel is queued right behind them; the host reads the reduced numbers once per pass, for its
             // bookkeeping, exactly as in a single context
             if (rr_pending) HIPCHK(hipMemcpyAsync(ctx->hcoef.p + m + 2, ctx->gcr_out.p + 4, sizeof(double), hipMemcpyDeviceToDevice, st));
             else HIPCHK(hipMemsetAsync(ctx->hcoef.p + m + 2, 0, sizeof(double), st));
             FSICHK(rccl_allreduce_dev(ctx, ctx->hcoef.p, m + 3));
             {
               Phase ph(ctx, &ctx->t_ortho);
-              launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, w, nullptr, ctx->scratch.p, ctx->gcr_out.p + 2);
+              launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, w, r, ctx->scratch.p, ctx->gcr_out.p + 2);
+            }
+            if (f32) {
+              FSICHK(rccl_allreduce_dev(ctx, ctx->gcr_out.p + 2, 2));
+              HIPCHK(hipMemcpyAsync(exact2, ctx->gcr_out.p + 2, sizeof exact2, hipMemcpyDeviceToHost, st));
             }
             HIPCHK(hipMemcpyAsync(hh, ctx->hcoef.p, (size_t)(m + 3) * sizeof(double), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
@@ -1138,15 +1148,24 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
             if (!rr_pending) hh[m + 2] = 0.0;
             FSICHK(allreduce(ctx, hh, m + 3));
             HIPCHK(hipMemcpyAsync(ctx->hcoef.p, hh, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
-            Phase ph(ctx, &ctx->t_ortho);
-            launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, w, nullptr, ctx->scratch.p, ctx->gcr_out.p + 2);
+            {
+              Phase ph(ctx, &ctx->t_ortho);
+              launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, w, r, ctx->scratch.p, ctx->gcr_out.p + 2);
+            }
+            if (f32) {
+              FSICHK(gcr_read(ctx, ctx->gcr_out.p + 2, 2, exact2));
+              FSICHK(allreduce(ctx, exact2, 2));
+            }
           }
-          ctx->part_allreduces += 1;
+          ctx->part_allreduces += f32 ? 2 : 1;
           if (rr_pending) { rn2 = hh[m + 2]; rr_pending = false; }      // exact |r|^2 before this iteration's update
           double hsq = 0.0;
           for (int j = 0; j < m; ++j) hsq += hh[j] * hh[j];
-          h2[0] = std::max(hh[m] - hsq, 0.0);
-          h2[1] = hh[m + 1];
+          h2[0] = f32 ? exact2[0] : std::max(hh[m] - hsq, 0.0);
+          h2[1] = f32 ? exact2[1] : hh[m + 1];
+          if (ctx->debug_gcr && *iters < 6)
+            fprintf(stderr, "[gcr]   partitioned pass %d: |w|^2 %.6e |h|^2 %.6e w.r %.6e lagged |r|^2 %.6e window: nh %d |w|^2 %.6e\n", pass, hh[m], hsq,
+                    hh[m + 1], hh[m + 2], nh, nh > 0 ? hh_hot[nh] : 0.0);
         } else {
           {
             Phase ph(ctx, &ctx->t_ortho);
@@ -1183,7 +1202,12 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
         w0 = wn;
       }
     }
-    if (!(wn > 0.0) || !std::isfinite(wn)) { ctx->err = "GCR breakdown (A M^-1 r vanished or is not finite)"; return FSI_ERR_LINEAR; }
+    if (!(wn > 0.0) || !std::isfinite(wn)) {
+      char buf[200];
+      snprintf(buf, sizeof buf, "GCR breakdown (A M^-1 r vanished or is not finite): |w'| %.3e, |w| %.3e, w.r %.3e, %d kept, iteration %d", wn, w0, wr, m, *iters);
+      ctx->err = buf;
+      return FSI_ERR_LINEAR;
+    }
     const double alpha = wr / wn;          // q . r with q = w / wn
     if (ctx->rz_soft > 0) rz_record(ctx, htot, m, slot, wn, alpha);
     if (f32) {                              // the exact q goes into the FP64 window (ring of 32)

@@ -64,8 +64,31 @@ def parse(argv: Optional[List[str]] = None) -> Dict[str, object]:
     ap.add_argument("--checkpoint-step", dest="checkpoint_step", type=int, default=None)
     ap.add_argument("--killtime", type=float, default=None)
     ap.add_argument("--new-arguments", dest="new_arguments", nargs="*", default=[])
+    ap.add_argument("-c", "--config", dest="config", default=None,
+                    help="config file with `key = value` lines (keys: the option names without dashes, or any problem-file "
+                         "parameter); the command line wins over the file [REF docs/simulation.md:19-31]")
     ns = ap.parse_args(argv)
-    out = {k: v for k, v in vars(ns).items() if v is not None and k != "new_arguments"}
+    out = {}
+    if ns.config is not None:          # turtleFSI's ConfigArgParse behaviour: file < command line
+        names = {o.lstrip("-"): a.dest for a in ap._actions for o in a.option_strings}
+        types = {a.dest: a.type for a in ap._actions}
+        for raw in Path(ns.config).read_text().splitlines():
+            line = raw.split("#", 1)[0].split(";", 1)[0].strip()
+            if not line or line.startswith("["):
+                continue
+            for sep in ("=", ":", None):
+                parts = line.split(sep, 1)
+                if len(parts) == 2:
+                    break
+            if len(parts) != 2:
+                raise SystemExit(f"{ns.config}: cannot parse {raw!r} (expected `key = value`)")
+            key, val = parts[0].strip().lstrip("-"), parts[1].strip()
+            dest = names.get(key, key.replace("-", "_"))
+            if dest in ("config", "new_arguments"):
+                continue
+            conv = types.get(dest)
+            out[dest] = conv(val) if conv not in (None, _coerce) else _coerce(val)
+    out.update({k: v for k, v in vars(ns).items() if v is not None and k not in ("new_arguments", "config")})
     for kv in ns.new_arguments:
         if "=" not in kv:
             raise SystemExit(f"--new-arguments expects key=value, got {kv!r}")

@@ -275,7 +275,7 @@ class DistBackend:
         overlap = int(os.environ.get("VASPFSI_OVERLAP", 2)) if overlap is None else overlap
         self.part = Partition(desc, self.rank, self.world, owner, overlap)
         self.ndof_global = 6 * self.part.N2 + self.part.V
-        self.hb = HipBackend(self.part.local_desc, device=device, **kw)
+        self.hb = HipBackend(self.part.local_desc, device=device, num_owned_cells=self.part.num_owned_cells, **kw)
         self.lib, self.ctx, self.ndof = self.hb.lib, self.hb.ctx, self.ndof_global
         dev = torch.device("cuda", device)
         self.dev = dev
