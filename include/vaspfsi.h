@@ -42,7 +42,10 @@ typedef struct FsiMeshDesc {
   const double* coords;        /* [V][3] vertex coordinates                                                 */
   const int32_t* tet_nodes;    /* [C][10] P2 node ids, UFC local order (4 vertices, 6 edges), rows of the   */
                                /*         vertex part ascending                                             */
-  const int32_t* cell_kind;    /* [C] 0 = fluid, 1 = solid                                                  */
+  const int32_t* cell_kind;    /* [C] 0 = fluid, 1 = solid.  Cell ORDER is the caller's and is kept (every cell    */
+                               /* index of this API refers to it); it decides the locality of the element       */
+                               /* kernels: hand the cells over along a space-filling curve (the Python binding   */
+                               /* does: vasp_amd.capi.cell_locality_order), not in sweeps over the domain        */
   const int32_t* cell_region;  /* [C] index into fluid_props / solid_props                                  */
 } FsiMeshDesc;
 
