@@ -495,16 +495,17 @@ def test_two_level_displacement_solve_is_a_preconditioner_only(stenosis_case, mo
     out = {}
     for mg in ("1", "0"):
         monkeypatch.setenv("FSI_DD_MG", mg)
-        # one decade above the round-off floor of this case (|b| ~ 1e-11, see the five-step golden test): at the floor the
-        # Krylov counts are decided by stagnation restarts, not by the preconditioner this test compares
-        hb = HipBackend(desc, lin_rtol=1e-10)
+        # three decades above the round-off floor of this case (|b| ~ 1e-11, see the five-step golden test): near the floor
+        # the Krylov counts are decided by stagnation restarts and by the summation order of the atomics (387 in one process,
+        # 620 in another, for the same two-level run at 1e-10), not by the preconditioner this test compares
+        hb = HipBackend(desc, lin_rtol=1e-8)
         its = 0
         for k in range(2):
             g, P = boundary_data(stenosis_case, 0.01 * (k + 1))
             hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
-            hist = hb.newton_solve(counter=k, first_step_num=0, atol=1e-10, rtol=1e-14, max_it=50, lmbda=1.0, recompute=20,
+            hist = hb.newton_solve(counter=k, first_step_num=0, atol=1e-8, rtol=1e-14, max_it=50, lmbda=1.0, recompute=20,
                                    recompute_tstep=20)
-            assert hist[-1][0] < 1e-10
+            assert hist[-1][0] < 1e-8
             its += sum(h[3] for h in hist)
             hb.shift()
         out[mg] = (hb.get_state("n"), its)
@@ -513,7 +514,7 @@ def test_two_level_displacement_solve_is_a_preconditioner_only(stenosis_case, mo
     print("krylov iterations: two-level", its1, "one-level", its0)
     mesh = ns["mesh"]
     for name, a, b in zip("dvp", mesh.split(x1), mesh.split(x0)):
-        assert np.abs(a - b).max() <= 1e-7 * np.abs(b).max(), name
+        assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max(), name       # both runs stop on |b| < 1e-8 of a quasi-Newton loop
     assert its1 <= 1.25 * its0
 
 

@@ -185,7 +185,10 @@ __global__ __launch_bounds__(64, WAVES) void k_residual(ElemArrays ea, ElemParam
     int32_t dof[2] = {0, 0};
     __syncthreads();                                 // the previous pair's contraction has finished with sS / sU
     for (int t = 0; t < ncell; ++t) {
-      dof[t] = ea.cell_dofs[(c0 + t) * NLOC + lane];
+      // the 64 local dofs from 10 node ranks + 4 pressure rows (56 bytes per cell; the 64-entry dof map is 256): lane l < 60
+      // is (field l / 30, component (l % 30) / 10, node l % 10) -> dof 6 rank + 3 field + component
+      dof[t] = lane < 60 ? 6 * ea.cell_rank[(c0 + t) * 10 + lane % 10] + 3 * (lane / 30) + (lane % 30) / 10
+                         : ea.cell_prow[(c0 + t) * 4 + lane - 60];
       sU[t][lane] = U[dof[t]];
       sU1[t][lane] = U1[dof[t]];
     }

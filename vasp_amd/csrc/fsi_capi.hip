@@ -69,7 +69,7 @@ int upload(FsiCtx* ctx, DevBuf<T>& buf, const std::vector<T>& h) {
 }
 
 ElemArrays elem_arrays(FsiCtx* c) {
-  return ElemArrays{c->geom.p, c->cell_dofs.p, c->cell_kind.p, c->cell_region.p, c->cell_rank.p, c->enbr.p, c->epnbr.p};
+  return ElemArrays{c->geom.p, c->cell_dofs.p, c->cell_kind.p, c->cell_region.p, c->cell_rank.p, c->cell_prow.p, c->enbr.p, c->epnbr.p};
 }
 ElemParams elem_params(FsiCtx* c) {
   ElemParams ep;
@@ -1766,7 +1766,7 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->gv_idx.release();
   if (ctx->gcr_host) { (void)hipHostFree(ctx->gcr_host); ctx->gcr_host = nullptr; }
   DevBuf<int32_t>* i32[] = {&ctx->user2solver, &ctx->solver2user, &ctx->cell_dofs, &ctx->cell_kind, &ctx->cell_region,
-                            &ctx->cell_rank, &ctx->nadj, &ctx->padj, &ctx->cols, &ctx->iflags, &ctx->bc_dofs,
+                            &ctx->cell_rank, &ctx->cell_prow, &ctx->nadj, &ctx->padj, &ctx->cols, &ctx->iflags, &ctx->bc_dofs,
                             &ctx->pf_dofs, &ctx->rb_row, &ctx->rb_col};
   for (auto* b : i32) b->release();
   DevBuf<int64_t>* i64[] = {&ctx->nadj_ptr, &ctx->padj_ptr, &ctx->rowptr, &ctx->diagpos, &ctx->rb_pos};
@@ -2035,7 +2035,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   ctx->nnz = rowptr[ctx->ndof];
 
   // ---- element tables --------------------------------------------------------------------------------------
-  std::vector<int32_t> cell_dofs((size_t)C * NLOC), cell_rank((size_t)C * 10), tet_vertices((size_t)C * 4);
+  std::vector<int32_t> cell_dofs((size_t)C * NLOC), cell_rank((size_t)C * 10), tet_vertices((size_t)C * 4), cell_prow((size_t)C * 4);
   std::vector<uint16_t> enbr((size_t)C * 100), epnbr((size_t)C * 40);
   for (int64_t c = 0; c < C; ++c) {
     for (int a = 0; a < 10; ++a) {
@@ -2056,6 +2056,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
     }
     for (int a = 0; a < 4; ++a) {
       cell_dofs[c * NLOC + 60 + a] = (int32_t)(6 * N2 + ctx->h_prank[tn[10 * c + a]]);
+      cell_prow[4 * c + a] = cell_dofs[c * NLOC + 60 + a];
       tet_vertices[4 * c + a] = tn[10 * c + a];
     }
   }
@@ -2074,6 +2075,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   FSICHK(upload(ctx, ctx->solver2user, solver2user));
   FSICHK(upload(ctx, ctx->cell_dofs, cell_dofs));
   FSICHK(upload(ctx, ctx->cell_rank, cell_rank));
+  FSICHK(upload(ctx, ctx->cell_prow, cell_prow));
   FSICHK(upload(ctx, ctx->enbr, enbr));
   FSICHK(upload(ctx, ctx->epnbr, epnbr));
   FSICHK(upload(ctx, ctx->cell_kind, std::vector<int32_t>(mesh->cell_kind, mesh->cell_kind + C)));

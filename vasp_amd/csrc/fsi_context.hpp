@@ -112,6 +112,7 @@ struct FsiCtx {
   fsi::DevBuf<uint16_t> enbr;                // [C][10][10] index of node b in adj(node a)
   fsi::DevBuf<uint16_t> epnbr;               // [C][10][4]  index of vertex b among vertex-neighbours of node a
   fsi::DevBuf<int32_t> cell_rank;            // [C][10] rank of the local nodes
+  fsi::DevBuf<int32_t> cell_prow;            // [C][4] pressure dofs (solver layout): with cell_rank, 56 bytes per cell give the 64 local dofs
 
   // node graph + CSR structure
   std::vector<int64_t> h_nadj_ptr;           // [N2+1]

@@ -56,6 +56,7 @@ struct ElemArrays {
   const int32_t* cell_kind;    // [C]
   const int32_t* cell_region;  // [C]
   const int32_t* cell_rank;    // [C][10]
+  const int32_t* cell_prow;    // [C][4] solver-layout dofs of the four pressure unknowns of a cell
   const uint16_t* enbr;        // [C][10][10]
   const uint16_t* epnbr;       // [C][10][4]
 };
