@@ -3046,7 +3046,7 @@ int fsi_probe(FsiCtx* ctx, int64_t n, const int32_t* cells, const double* bary, 
 int fsi_flow_stats(FsiCtx* ctx, double* out) {
   if (!ctx || !out) return FSI_ERR_INVALID;
   HIPCHK(hipSetDevice(ctx->device));
-  if (!ctx->cellvals.p) HIPCHK(ctx->cellvals.alloc(2 * ctx->C + 8));
+  if (!ctx->cellvals.p) HIPCHK(ctx->cellvals.alloc(2 * ctx->C + 8 + 4 * STAT_PARTS));
   double* res = ctx->cellvals.p + 2 * ctx->C;
   // partitioned: the cells this rank owns (they come first); the host combines the ranks with the owned-cell counts
   const int64_t nc = ctx->part ? ctx->C_owned : ctx->C;

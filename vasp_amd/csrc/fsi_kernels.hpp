@@ -72,6 +72,7 @@ hipError_t upload_tables();
 void launch_geometry(hipStream_t st, int64_t C, const double* coords, const int32_t* tet_vertices, double* geom);
 void launch_residual(hipStream_t st, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
                      const double* U1, double* F);
+constexpr int STAT_PARTS = 256;      // stage-1 workgroups of the cell-statistics reduction: cellvals needs 2 C + 8 + 4 * STAT_PARTS doubles
 void launch_cell_stats(hipStream_t st, int64_t C, const ElemArrays& ea, const double* X, double* cellvals, double* out);
 void launch_probe(hipStream_t st, int64_t n, const ElemArrays& ea, const int32_t* cells, const double* bary, const double* X,
                   double* out);
