@@ -250,8 +250,13 @@ def main():
                   + ndof_rank * 16.0 + (ndof_rank + 1) * 8.0) if tm["spmv_compact"] else
                  nnz * (8.0 - 4.0 * op32 / max(tm["spmv_calls"], 1) + (4.0 / 6.0 if not generic else 4.0))
                  + ndof_rank * 16.0 + (ndof_rank + 1) * 8.0),
-            "k_residual (element residual + scatter-add)": (tm["residual_ms"], tm["residual_calls"], C_rank * 1676.0),
-            "k_jacobian<nonlinear> (element Jacobian + scatter-add)": (tm["jacobian_ms"], tm["jacobian_calls"], C_rank * 33420.0),
+            # 1 676 B per tet (the scatter counted once; the element-vector round trip of the reproducible
+            # gather form - 2 x 512 B per tet - is overhead, not algorithmic)
+            "k_residual + k_residual_gather (element residual; per-dof sum of the element vectors in a fixed order)":
+                (tm["residual_ms"], tm["residual_calls"], C_rank * 1676.0),
+            # F_nonlinear has no d-equation rows: 34 x 64 entries per tet are produced (the 30 x 64 others live in A_pre)
+            "k_jacobian<nonlinear> (element Jacobian of F_nonlinear, rows v and p; one launch per colour of the cell colouring)":
+                (tm["jacobian_ms"], tm["jacobian_calls"], C_rank * (652.0 + 34 * 64 * 8.0)),
         }
         table = {}
         for name, (ms, calls, nbytes) in kernels.items():
@@ -274,7 +279,7 @@ def main():
                   "k_sweep_tiled_f32<1>": ["k_sweep_tiled_f32<1>"], "k_sweep_tiled_f32<3>": ["k_sweep_tiled_f32<3>"],
                   "k_sweep_tiled_h<1>": ["k_sweep_tiled_h<1>"], "k_sweep_tiled_h<3>": ["k_sweep_tiled_h<3>"], "k_sweep_sb_h": ["k_sweep_sb_h"],
                   "k_sweep_sb_b3<0>": ["k_sweep_sb_b3<0>"], "Schur": ["k_sweep_schur_tiled", "k_sweep_csr_mixed", "k_sweep_csr_f32", "k_spmv<2,"],
-                  "k_residual": ["k_residual"], "k_jacobian": ["k_jacobian<2>"]}
+                  "k_residual": ["k_residual<", "k_residual_gather"], "k_jacobian": ["k_jacobian<2,"]}
         if pmc.exists():
             with contextlib.suppress(Exception):
                 pj = json.loads(pmc.read_text())
@@ -311,7 +316,11 @@ def main():
                                    f"per step: pre_solve, Newton solve, shift, post_solve (no file output)",
                        "tets": C, "dofs": ndof, "matrix_nnz": nnz, "parallelism": (f"element partition over {world} ranks (node slabs, ghost-layer cells {C_all / C - 1:.1%}), "
                                        f"halo + all-reduce over {dist.get_backend()}") if partitioned else "1 GPU",
-                       "rank0_matrix_nnz": nnz, "krylov_storage": f"Q FP{8 * qb}, directions FP64, capacity {tm['krylov_cap']}",
+                       "rank0_matrix_nnz": nnz,
+                       "assembly": (f"bitwise reproducible: residual summed per dof over its cells in a fixed order, Jacobian in "
+                                    f"{int(tm['assembly_colours'])} launches (cell colours)" if tm["assembly_colours"] > 0
+                                    else "unordered atomics (FSI_ASSEMBLY=atomic)"),
+                       "krylov_storage": f"Q FP{8 * qb}, directions FP64, capacity {tm['krylov_cap']}",
                        "storage_precisions": ("state, residual, Jacobian and every accumulation FP64; Krylov basis "
                                               f"FP{8 * qb}" + (" with an FP64 window of 32 columns" if qb == 4 else "")
                                               + f"; {op32} of {int(tm['spmv_calls'])} outer products on an FP32 copy of the Jacobian values, "

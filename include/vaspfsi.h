@@ -258,6 +258,9 @@ typedef struct FsiTimers {
                                                         (FP64 basis: one per Gram-Schmidt pass; FP32 basis: two per pass
                                                         + one for its FP64 window; + one when an iteration looks
                                                         converged)                                                    */
+  int64_t assembly_colours;                          /* colours of the assembly colouring (one launch of the residual /
+                                                        Jacobian kernel each: bitwise reproducible scatter-adds); 0: one
+                                                        launch over all cells with unordered atomics (FSI_ASSEMBLY=atomic) */
 } FsiTimers;
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
 /* Measurement aid: streams `bytes` of the (idle) Krylov store once per kernel with 4-, 8-, 16- and 32-byte loads and

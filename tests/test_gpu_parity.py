@@ -716,3 +716,77 @@ def test_compact_rows_product_matches_oracle(cylinder_case, monkeypatch):
     x = np.random.default_rng(10).standard_normal(o.ndof)
     assert np.abs(hb.spmv(x) - A_ref @ x).max() <= 1e-11 * np.abs(A_ref @ x).max()
     hb.close()
+
+
+def _three_steps(case, recompute_tstep=2):
+    """Three time steps of the production policy in a fresh context; returns (residual vector of the first assembly, product
+    of the first Jacobian with a fixed vector, state after every step, Krylov iterations)."""
+    from vasp_amd.capi import HipBackend
+    hb = HipBackend(case[1])
+    x = np.random.default_rng(7).standard_normal(hb.ndof)
+    states, its = [], []
+    b0 = ax0 = None
+    for k in range(3):
+        g, P = boundary_data(case, 1e-3 * (k + 1))
+        hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+        if k == 0:
+            hb.assemble_residual()
+            b0 = hb.get_state("b")
+            hb.assemble_jacobian()
+            ax0 = hb.spmv(x)
+        hist = hb.newton_solve(counter=k, first_step_num=0, atol=1e-6, rtol=1e-6, max_it=20, lmbda=1.0, recompute=20,
+                               recompute_tstep=recompute_tstep)
+        its.append([h[3] for h in hist])
+        hb.shift()
+        states.append(hb.get_state("n"))
+    hb.close()
+    return b0, ax0, states, its
+
+
+def test_time_steps_are_bitwise_reproducible(tmp_path):
+    """`north_star`: segmented scatter-add into the global vector / CSR matrix.  Here the residual's segmented reduction runs
+    on the owner's side (element vectors stored per cell, every dof sums the cells around its node in ascending order); for
+    the Jacobian the cells are coloured (no two cells of a colour share a node) and every colour is one launch, so no entry
+    of A receives two adds whose order could vary; the small facet scatters are merged on the host, the norms and the coarse
+    operators of the preconditioner are summed in fixed orders.  Two fresh contexts therefore produce THE SAME BITS -
+    residual, Jacobian, Krylov iteration counts and the state after three steps with two Jacobian refreshes - on a mesh
+    large enough (50 k tets, 4 000 workgroups in flight) for unordered atomics to show."""
+    from vasp_amd.meshgen import write_mesh
+    write_mesh(tmp_path / "s.h5", 50000)
+    case = prepare_case("offset_stenosis", tmp_path / "s.h5", tmp_path / "run", dt="0.001", T="0.002")
+    b_a, ax_a, st_a, it_a = _three_steps(case)
+    b_b, ax_b, st_b, it_b = _three_steps(case)
+    assert np.array_equal(b_a, b_b)
+    assert np.array_equal(ax_a, ax_b)
+    assert it_a == it_b
+    for u, w in zip(st_a, st_b):
+        assert np.array_equal(u, w)
+
+
+def test_reproducible_assembly_equals_the_atomic_one_to_roundoff(tmp_path, monkeypatch):
+    """FSI_ASSEMBLY=atomic (one launch over all cells, unordered atomics) against the default (gathered residual, coloured
+    Jacobian): the same sums in another order - residual and Jacobian product agree to round-off, not to the bit."""
+    from vasp_amd.capi import HipBackend
+    from vasp_amd.meshgen import write_mesh
+    write_mesh(tmp_path / "s.h5", 50000)
+    case = prepare_case("offset_stenosis", tmp_path / "s.h5", tmp_path / "run", dt="0.001", T="0.002")
+    mesh = case[0]["mesh"]
+    out = {}
+    for mode in ("default", "atomic"):
+        if mode == "atomic":
+            monkeypatch.setenv("FSI_ASSEMBLY", "atomic")
+        else:
+            monkeypatch.delenv("FSI_ASSEMBLY", raising=False)
+        hb = HipBackend(case[1])
+        assert (hb.timers()["assembly_colours"] > 0) == (mode == "default")
+        U, U1 = random_state(mesh, hb.ndof, seed=3)
+        g, P = boundary_data(case, 1e-3)
+        hb.set_state("n", U); hb.set_state("n-1", U1)
+        hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+        hb.assemble_residual()
+        b = hb.get_state("b")
+        hb.assemble_jacobian()
+        out[mode] = (b, hb.spmv(np.random.default_rng(5).standard_normal(hb.ndof)))
+        hb.close()
+    for k in range(2):
+        assert np.abs(out["default"][k] - out["atomic"][k]).max() <= 1e-13 * np.abs(out["atomic"][k]).max()

@@ -66,7 +66,8 @@ class FsiTimers(C.Structure):
                 ("krylov_dirs", C.c_int64), ("krylov_cap", C.c_int64), ("schur_nnz", C.c_int64), ("schur_rows", C.c_int64),
                 ("flush_ms", C.c_double), ("flush_calls", C.c_int64), ("schur_ms", C.c_double), ("schur_calls", C.c_int64),
                 ("schur_elem_bytes", C.c_int64), ("spmv_compact", C.c_int64), ("node_pairs", C.c_int64),
-                ("node_vertex_pairs", C.c_int64), ("spmv_fp32_calls", C.c_int64), ("sweep_flags", C.c_int64), ("part_allreduces", C.c_int64)]
+                ("node_vertex_pairs", C.c_int64), ("spmv_fp32_calls", C.c_int64), ("sweep_flags", C.c_int64), ("part_allreduces", C.c_int64),
+                ("assembly_colours", C.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

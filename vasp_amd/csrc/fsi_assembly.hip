@@ -163,9 +163,15 @@ __device__ inline void interpolate2(const double* __restrict__ sU, const double*
 // lanes.  Workgroups are persistent (a grid-stride loop over the cell pairs) and hold the basis tables in LDS: read from
 // constant memory with a lane-dependent index they are vector loads, 96 per cell in the contraction alone, and each costs
 // address-unit cycles that an LDS read does not.
+// Re != nullptr (the default, FSI_ASSEMBLY unset): the element vector of cell c is STORED to Re[c][64] - a node's six
+// entries side by side, [node a][d_x d_y d_z v_x v_y v_z], then the four pressure entries - and k_residual_gather adds, per
+// dof, the entries of the cells around the node in ascending cell order: the segmented reduction behind the scatter-add of an
+// assembly, done on the owner's side, with sums that are bitwise the same in every run.  Re == nullptr (FSI_ASSEMBLY=atomic):
+// scatter-add into F with atomics whose order varies from run to run.
 template <int WAVES>      // waves per SIMD the register budget is set for (2: no spills; 3: 56 VGPRs spilled, measured slower)
 __global__ __launch_bounds__(64, WAVES) void k_residual(ElemArrays ea, ElemParams ep, const double* __restrict__ U,
-                                                        const double* __restrict__ U1, double* __restrict__ F, int64_t C) {
+                                                        const double* __restrict__ U1, double* __restrict__ F, int64_t C,
+                                                        double* __restrict__ Re) {
   const int lane = threadIdx.x;
   __shared__ __attribute__((aligned(32))) double4 sT[NQ][10];        // (N, dN/dxi) per point and node
   __shared__ double sL[NQ][4], sW[NQ];
@@ -229,21 +235,57 @@ __global__ __launch_bounds__(64, WAVES) void k_residual(ElemArrays ea, ElemParam
         const int a = lane - 60;
         for (int k = 0; k < NQ; ++k) r += sS[t][k][24] * sL[k][a];
       }
-      unsafeAtomicAdd(&F[dof[t]], r);
+      if (Re) Re[(c0 + t) * NLOC + (lane < 60 ? 6 * (lane % 10) + 3 * (lane / 30) + (lane % 30) / 10 : lane)] = r;
+      else unsafeAtomicAdd(&F[dof[t]], r);
     }
   }
 }
-
+// F[dof] = sum over the cells around the dof's node of that cell's entry, in ascending cell order (fixed by the host).
+// One thread per dof; the six threads of a node read six neighbouring doubles of every incident cell's vector.
+// inc[k] = 16 * cell + local node of the k-th incidence of a node (ranks, inc_ptr) / of a pressure row (pinc_ptr, pinc).
+__global__ __launch_bounds__(256) void k_residual_gather(int64_t N2, int64_t V, const int64_t* __restrict__ inc_ptr,
+                                                         const int32_t* __restrict__ inc, const int64_t* __restrict__ pinc_ptr,
+                                                         const int32_t* __restrict__ pinc, const double* __restrict__ Re,
+                                                         double* __restrict__ F) {
+  // A vertex has ~24 incident cells, an edge node ~5, and a wave holds both: with one dependent pair of loads (incidence ->
+  // entry) per loop trip the wave would wait 24 memory latencies in a row.  Eight incidences per trip: eight independent
+  // index loads, then eight independent entry loads, then the eight adds in ascending order (the order - and so the sum - is
+  // the same whatever the grouping).
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= 6 * N2 + V) return;
+  const bool node = i < 6 * N2;
+  const int64_t r = node ? i / 6 : i - 6 * N2;
+  const int off = node ? (int)(i - 6 * r) : 60;
+  const int mul = node ? 6 : 1;
+  const int64_t* ptr = node ? inc_ptr : pinc_ptr;
+  const int32_t* lst = node ? inc : pinc;
+  const int64_t k1 = ptr[r + 1];
+  double s = 0.0;
+  for (int64_t k = ptr[r]; k < k1; k += 8) {
+    int32_t e[8];
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = k + j < k1 ? lst[k + j] : -1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = e[j] >= 0 ? Re[(int64_t)(e[j] >> 4) * NLOC + mul * (e[j] & 15) + off] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  F[i] = s;
+}
 // ---------------------------------------------------------------------------------------------------------
 // L2(Omega) norm of a mixed function: out += int |d|^2 + |v|^2 + p^2 dx over the cells  (`norm(dvp_res, 'l2')` of the
 // reference's newtonsolver is DOLFIN's *function* norm; see oracle/fsi_oracle.py:function_norm)
 // ---------------------------------------------------------------------------------------------------------
-// One wave per cell, waves stride over the cells and keep their sum in a register (one atomic per wave at the end:
-// a million same-address atomics cost more than the whole integration).  Values only - no gradients are needed.
-__global__ __launch_bounds__(256) void k_l2norm(ElemArrays ea, const double* __restrict__ X, int64_t C, double* __restrict__ out) {
+// One wave per cell, waves stride over the cells and keep their sum in a register; a workgroup's four sums go to
+// part[blockIdx.x] and one further workgroup adds the partials in a fixed order (k_sum_parts): the same cells meet the same
+// partial sums in every run, so the norm is bitwise reproducible (atomics on one address were neither that nor cheap: a
+// million same-address atomics cost more than the whole integration).  Values only - no gradients are needed.
+__global__ __launch_bounds__(256) void k_l2norm(ElemArrays ea, const double* __restrict__ X, int64_t C, double* __restrict__ part) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t wave = blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
   __shared__ double sU[4][NLOC];
+  __shared__ double sAcc[4];
   double acc = 0.0;
   for (int64_t c = wave; c < C; c += nwaves) {
     sU[w][lane] = X[ea.cell_dofs[c * NLOC + lane]];
@@ -263,7 +305,22 @@ __global__ __launch_bounds__(256) void k_l2norm(ElemArrays ea, const double* __r
     __builtin_amdgcn_wave_barrier();
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-  if (lane == 0 && acc != 0.0) unsafeAtomicAdd(out, acc);
+  if (lane == 0) sAcc[w] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sAcc[0] + sAcc[1]) + (sAcc[2] + sAcc[3]);
+}
+// out[0] = sum of part[0 .. n) in a fixed order (one workgroup)
+__global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ part, int n, double* __restrict__ out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
 }
 // ---------------------------------------------------------------------------------------------------------
 // per-step diagnostics of post_solve [REF src/vasp/simulations/simulation_common.py:253-348]: per cell the DG0
@@ -375,19 +432,28 @@ void launch_probe(hipStream_t st, int64_t n, const ElemArrays& ea, const int32_t
                   double* out) {
   hipLaunchKernelGGL(k_probe, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, ea, cells, bary, X, out);
 }
-void launch_l2norm(hipStream_t st, int64_t C, const ElemArrays& ea, const double* X, double* out) {
+// part: room for 4096 partial sums; out[0] is overwritten (not accumulated)
+void launch_l2norm(hipStream_t st, int64_t C, const ElemArrays& ea, const double* X, double* part, double* out) {
   const int64_t blocks = std::min<int64_t>((C + 3) / 4, 4096);
-  hipLaunchKernelGGL(k_l2norm, dim3((unsigned)blocks), dim3(256), 0, st, ea, X, C, out);
+  hipLaunchKernelGGL(k_l2norm, dim3((unsigned)blocks), dim3(256), 0, st, ea, X, C, part);
+  hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, st, part, (int)blocks, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // Jacobian: vals += d(element vector)/d(local dofs), PART selects F_linear (A_pre) or F_nonlinear
 // ---------------------------------------------------------------------------------------------------------
-template <int PART>
-__global__ __launch_bounds__(64) void k_jacobian(ElemArrays ea, ElemParams ep, const double* __restrict__ U,
+// Rows that a part cannot touch are not carried: F_nonlinear has no d-equation terms (the Laplace lifting and the solid's
+// displacement equation are linear: they live in A_pre), so the refresh kernel accumulates and scatters rows 30..63 only
+// (34 instead of 64 accumulators per lane, half the contraction); on a solid cell F_nonlinear = theta0 (P(d), grad psi)
+// depends on d alone, so only the 30 d-columns (lanes 0..29) do any work.  `list` as for k_residual: the cells of one colour.
+template <int PART, int WAVES>     // WAVES: waves per SIMD the register budget is set for
+__global__ __launch_bounds__(64, WAVES) void k_jacobian(ElemArrays ea, ElemParams ep, const double* __restrict__ U,
                                                  const double* __restrict__ U1, const int64_t* __restrict__ rowptr,
-                                                 const int64_t* __restrict__ nadj_ptr, double* __restrict__ vals) {
-  const int64_t c = blockIdx.x;
+                                                 const int64_t* __restrict__ nadj_ptr, double* __restrict__ vals,
+                                                 const int32_t* __restrict__ list) {
+  constexpr int R0 = (PART == PART_NONLINEAR) ? 30 : 0;      // first local row this part can produce
+  constexpr int NR = NLOC - R0;
+  const int64_t c = list ? (int64_t)list[blockIdx.x] : (int64_t)blockIdx.x;
   const int lane = threadIdx.x;
   __shared__ double sU[NLOC], sU1[NLOC], sJ[10];
   __shared__ double sG[NQ][10][3];       // physical gradients of the P2 basis at the quadrature points
@@ -430,9 +496,10 @@ __global__ __launch_bounds__(64) void k_jacobian(ElemArrays ea, ElemParams ep, c
   const int jf = lane < 60 ? lane / 30 : 2;          // 0 d, 1 v, 2 p
   const int jc = lane < 60 ? (lane % 30) / 10 : 0;
   const int jb = lane < 60 ? lane % 10 : lane - 60;
-  double acc[NLOC];
+  if (PART == PART_NONLINEAR && kind == 1 && jf != 0) return;    // no barrier below
+  double acc[NR];
 #pragma unroll
-  for (int i = 0; i < NLOC; ++i) acc[i] = 0.0;
+  for (int i = 0; i < NR; ++i) acc[i] = 0.0;
   for (int q = 0; q < NQ; ++q) {
     Kin<Dual> s;
     Kin<double> o;
@@ -459,53 +526,71 @@ __global__ __launch_bounds__(64) void k_jacobian(ElemArrays ea, ElemParams ep, c
     const double w = sJ[9] * c_qw[q];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const double dv = w * out.dval[i].e, vv = w * out.vval[i].e;
-      const double d0 = w * out.dgrd[i][0].e, d1 = w * out.dgrd[i][1].e, d2 = w * out.dgrd[i][2].e;
+      const double vv = w * out.vval[i].e;
       const double v0 = w * out.vgrd[i][0].e, v1 = w * out.vgrd[i][1].e, v2 = w * out.vgrd[i][2].e;
+      if (R0 == 0) {
+        const double dv = w * out.dval[i].e;
+        const double d0 = w * out.dgrd[i][0].e, d1 = w * out.dgrd[i][1].e, d2 = w * out.dgrd[i][2].e;
 #pragma unroll
-      for (int a = 0; a < 10; ++a) {
-        const double N = c_N[q][a], g0 = sG[q][a][0], g1 = sG[q][a][1], g2 = sG[q][a][2];
-        acc[i * 10 + a] += dv * N + d0 * g0 + d1 * g1 + d2 * g2;
-        acc[30 + i * 10 + a] += vv * N + v0 * g0 + v1 * g1 + v2 * g2;
+        for (int a = 0; a < 10; ++a)
+          acc[i * 10 + a] += dv * c_N[q][a] + d0 * sG[q][a][0] + d1 * sG[q][a][1] + d2 * sG[q][a][2];
       }
+#pragma unroll
+      for (int a = 0; a < 10; ++a)
+        acc[30 - R0 + i * 10 + a] += vv * c_N[q][a] + v0 * sG[q][a][0] + v1 * sG[q][a][1] + v2 * sG[q][a][2];
     }
     const double pv = w * out.pval.e;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) acc[60 + a] += pv * c_L[q][a];
+    for (int a = 0; a < 4; ++a) acc[60 - R0 + a] += pv * c_L[q][a];
   }
   // scatter column `lane` of the element matrix
   const uint16_t* nb = ea.enbr + c * 100;
   const uint16_t* pb = ea.epnbr + c * 40;
 #pragma unroll
-  for (int i = 0; i < NLOC; ++i) {
+  for (int k = 0; k < NR; ++k) {
+    const int i = R0 + k;
     const int ra = i < 60 ? i % 10 : i - 60;
     int64_t pos;
     if (jf < 2) pos = sRow[i] + 6 * (int64_t)nb[ra * 10 + jb] + 3 * jf + jc;
     else pos = sRow[i] + sDeg6[ra] + pb[ra * 4 + jb];
-    if (acc[i] != 0.0) unsafeAtomicAdd(&vals[pos], acc[i]);
+    if (acc[k] != 0.0) unsafeAtomicAdd(&vals[pos], acc[k]);
   }
 }
 
-template __global__ void k_jacobian<PART_LINEAR>(ElemArrays, ElemParams, const double*, const double*, const int64_t*,
-                                                 const int64_t*, double*);
-template __global__ void k_jacobian<PART_NONLINEAR>(ElemArrays, ElemParams, const double*, const double*,
-                                                    const int64_t*, const int64_t*, double*);
 
 void launch_geometry(hipStream_t st, int64_t C, const double* coords, const int32_t* tet_vertices, double* geom) {
   const int bs = 256;
   hipLaunchKernelGGL(k_geometry, dim3((unsigned)((C + bs - 1) / bs)), dim3(bs), 0, st, C, coords, tet_vertices, geom);
 }
+// gather form (Re and the incidence lists given): every entry of F is written, no memset needed; otherwise F += with atomics
 void launch_residual(hipStream_t st, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
-                     const double* U1, double* F) {
+                     const double* U1, double* F, const ResidualGather& rg) {
   const int64_t grid = std::min<int64_t>((C + 1) / 2, 256 * 8 * 4);      // persistent: a few rounds of the resident workgroups
-  hipLaunchKernelGGL(k_residual<2>, dim3((unsigned)grid), dim3(64), 0, st, ea, ep, U, U1, F, C);
+  hipLaunchKernelGGL(k_residual<2>, dim3((unsigned)grid), dim3(64), 0, st, ea, ep, U, U1, F, C, rg.Re);
+  if (rg.Re) {
+    const int64_t n = 6 * rg.N2 + rg.V;
+    hipLaunchKernelGGL(k_residual_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rg.N2, rg.V, rg.inc_ptr, rg.inc,
+                       rg.pinc_ptr, rg.pinc, rg.Re, F);
+  }
 }
+// `cc`: the assembly colouring (cells sorted by colour; colour k = cells[ptr[k] .. ptr[k+1])), or ncolours == 0 for one launch
+// over all cells with atomics whose order varies from run to run.
 void launch_jacobian(hipStream_t st, int part, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
-                     const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals) {
-  if (part == PART_LINEAR)
-    hipLaunchKernelGGL(k_jacobian<PART_LINEAR>, dim3((unsigned)C), dim3(64), 0, st, ea, ep, U, U1, rowptr, nadj_ptr, vals);
-  else
-    hipLaunchKernelGGL(k_jacobian<PART_NONLINEAR>, dim3((unsigned)C), dim3(64), 0, st, ea, ep, U, U1, rowptr, nadj_ptr, vals);
+                     const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals, const CellColours& cc) {
+  // two waves per SIMD with 94 spilled VGPRs beat one wave without (70 against 99 ms per refresh at 1.12 M tets)
+  static const int jac_waves = getenv("FSI_JAC_WAVES") ? atoi(getenv("FSI_JAC_WAVES")) : 2;
+  const int rounds = cc.ncolours == 0 ? 1 : cc.ncolours;
+  for (int k = 0; k < rounds; ++k) {
+    const int64_t n = cc.ncolours == 0 ? C : cc.ptr[k + 1] - cc.ptr[k];
+    const int32_t* list = cc.ncolours == 0 ? nullptr : cc.cells + cc.ptr[k];
+    if (n <= 0) continue;
+    if (part == PART_LINEAR)
+      hipLaunchKernelGGL((k_jacobian<PART_LINEAR, 1>), dim3((unsigned)n), dim3(64), 0, st, ea, ep, U, U1, rowptr, nadj_ptr, vals, list);
+    else if (jac_waves == 2)
+      hipLaunchKernelGGL((k_jacobian<PART_NONLINEAR, 2>), dim3((unsigned)n), dim3(64), 0, st, ea, ep, U, U1, rowptr, nadj_ptr, vals, list);
+    else
+      hipLaunchKernelGGL((k_jacobian<PART_NONLINEAR, 1>), dim3((unsigned)n), dim3(64), 0, st, ea, ep, U, U1, rowptr, nadj_ptr, vals, list);
+  }
 }
 
 }  // namespace fsi

@@ -1073,36 +1073,48 @@ __global__ void k_mg_d0(int64_t N2, const int64_t* __restrict__ nadj_ptr, const 
     d0[r] = (float)d;
   }
 }
-__global__ __launch_bounds__(256) void k_mg_rap(int64_t N2, const int64_t* __restrict__ nadj_ptr,
+// One wave per COARSE row i, lane l owns entry cptr[i] + l of that row and walks, like every other lane of the wave, over
+// the row's contributions in one fixed order - children a of i, fine neighbours b of a, parents j of b - keeping what falls
+// on its column.  Nothing is scattered: the sums are bitwise reproducible (the fine-row form added with atomics in whatever
+// order the waves arrived, and a coarse operator that differs in its last bit moves the eigenvalue estimate, the Chebyshev
+// interval and with them every iterate of the outer solver at the level of its tolerance).
+__global__ __launch_bounds__(256) void k_mg_rap(int64_t nc, const int64_t* __restrict__ chptr, const int32_t* __restrict__ child,
+                                                const float* __restrict__ chw, const int64_t* __restrict__ nadj_ptr,
                                                 const int32_t* __restrict__ nadj, const double* __restrict__ db,
                                                 const double* __restrict__ rowscale, const uint8_t* __restrict__ rowflag,
                                                 const int32_t* __restrict__ par, const float* __restrict__ pw,
                                                 const int64_t* __restrict__ cptr, const int32_t* __restrict__ ccol,
                                                 double* __restrict__ Ac, int32_t* __restrict__ flags) {
-  const int sub = threadIdx.x & 15;
-  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
-  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
-  for (int64_t a = grp; a < N2; a += ngrp) {
-    if (rowflag[3 * a]) continue;
-    const double inv_sc = 1.0 / rowscale[6 * a];
-    for (int64_t e = nadj_ptr[a] + sub; e < nadj_ptr[a + 1]; e += 16) {
-      const int32_t b = nadj[e];
-      if (rowflag[3 * (int64_t)b]) continue;
-      const double aab = db[3 * e] * inv_sc;
-      for (int pi = 0; pi < 2; ++pi) {
-        const float wi = pw[2 * a + pi];
-        if (wi == 0.f) continue;
-        const int32_t i = par[2 * a + pi];
-        for (int pj = 0; pj < 2; ++pj) {
-          const float wj = pw[2 * (int64_t)b + pj];
-          if (wj == 0.f) continue;
-          const int32_t j = par[2 * (int64_t)b + pj];
-          int64_t lo = cptr[i], hi = cptr[i + 1];
-          while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ccol[mid] < j) lo = mid + 1; else hi = mid; }
-          if (lo < cptr[i + 1] && ccol[lo] == j) unsafeAtomicAdd(&Ac[lo], (double)(wi * wj) * aab);
-          else atomicOr(&flags[1], 64);                            // the vertex graph misses a pair: structure bug
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = wave; i < nc; i += nwaves) {
+    const int64_t c0 = cptr[i], c1 = cptr[i + 1];
+    for (int64_t e0 = c0; e0 < c1; e0 += 64) {
+      const int64_t e = e0 + lane;
+      const int32_t mycol = e < c1 ? ccol[e] : -1;
+      double acc = 0.0;
+      bool missed = false;
+      for (int64_t k = chptr[i]; k < chptr[i + 1]; ++k) {
+        const int64_t a = child[k];
+        if (rowflag[3 * a]) continue;
+        const float wi = chw[k];
+        const double inv_sc = 1.0 / rowscale[6 * a];
+        for (int64_t ee = nadj_ptr[a]; ee < nadj_ptr[a + 1]; ++ee) {
+          const int64_t b = nadj[ee];
+          if (rowflag[3 * b]) continue;
+          const double aab = db[3 * ee] * inv_sc;
+          for (int pj = 0; pj < 2; ++pj) {
+            const float wj = pw[2 * b + pj];
+            if (wj == 0.f) continue;
+            const int32_t j = par[2 * b + pj];
+            if (j == mycol) acc += (double)(wi * wj) * aab;
+            if (c1 - c0 <= 64 && !__any(j == mycol)) missed = true;     // the vertex graph misses a pair: structure bug
+          }
         }
       }
+      if (e < c1) Ac[e] = acc;
+      if (missed && lane == 0) atomicOr(&flags[1], 64);
     }
   }
 }
@@ -1168,13 +1180,14 @@ void launch_mg_d0(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int
                   const double* rowscale, const uint8_t* rowflag, float* d0, int32_t* flags) {
   hipLaunchKernelGGL(k_mg_d0, dim3(gridn(N2)), dim3(256), 0, st, N2, nadj_ptr, nadj, db, rowscale, rowflag, d0, flags);
 }
-void launch_mg_rap(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
-                   const double* rowscale, const uint8_t* rowflag, const int32_t* par, const float* pw, const int64_t* cptr,
-                   const int32_t* ccol, double* Ac, int32_t* flags) {
-  int64_t blocks = (N2 + 15) / 16;
+void launch_mg_rap(hipStream_t st, int64_t nc, const int64_t* chptr, const int32_t* child, const float* chw,
+                   const int64_t* nadj_ptr, const int32_t* nadj, const double* db, const double* rowscale,
+                   const uint8_t* rowflag, const int32_t* par, const float* pw, const int64_t* cptr, const int32_t* ccol,
+                   double* Ac, int32_t* flags) {
+  int64_t blocks = (nc + 3) / 4;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(k_mg_rap, dim3((unsigned)blocks), dim3(256), 0, st, N2, nadj_ptr, nadj, db, rowscale, rowflag, par, pw,
-                     cptr, ccol, Ac, flags);
+  hipLaunchKernelGGL(k_mg_rap, dim3((unsigned)blocks), dim3(256), 0, st, nc, chptr, child, chw, nadj_ptr, nadj, db, rowscale,
+                     rowflag, par, pw, cptr, ccol, Ac, flags);
 }
 void launch_mg_coarse_finish(hipStream_t st, int64_t nc, const int64_t* cptr, const int32_t* ccol, const double* Ac,
                              const int32_t* cfine, const uint8_t* rowflag, float* cc, uint8_t* cflag, float* dcinv4,
@@ -1382,39 +1395,53 @@ __global__ void k_sbmg_flags(int64_t nS, const int64_t* __restrict__ sb_ptr, con
     flag[i] = (off[0] && off[1] && off[2]) ? 0 : 1;
   }
 }
-__global__ __launch_bounds__(256) void k_sbmg_rap(int64_t nS, const int64_t* __restrict__ sb_ptr,
+// as k_mg_rap: one wave per coarse row, lane = entry (a 3x3 block), contributions gathered in a fixed order, no atomics
+__global__ __launch_bounds__(256) void k_sbmg_rap(int64_t nc, const int64_t* __restrict__ chptr, const int32_t* __restrict__ child,
+                                                  const float* __restrict__ chw, const int64_t* __restrict__ sb_ptr,
                                                   const int32_t* __restrict__ sb_col, const float* __restrict__ vals,
                                                   const int32_t* __restrict__ snode, const double* __restrict__ rowscale,
                                                   const uint8_t* __restrict__ flag, const int32_t* __restrict__ par,
                                                   const float* __restrict__ pw, const int64_t* __restrict__ cptr,
                                                   const int32_t* __restrict__ ccol, float* __restrict__ cvals,
                                                   int32_t* __restrict__ flags) {
-  const int sub = threadIdx.x & 15;
-  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
-  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
-  for (int64_t a = grp; a < nS; a += ngrp) {
-    if (flag[a]) continue;
-    const int64_t r = snode[a];
-    const float is0 = (float)(1.0 / rowscale[6 * r + 3]), is1 = (float)(1.0 / rowscale[6 * r + 4]), is2 = (float)(1.0 / rowscale[6 * r + 5]);
-    for (int64_t e = sb_ptr[a] + sub; e < sb_ptr[a + 1]; e += 16) {
-      const int32_t b = sb_col[e];
-      if (flag[b]) continue;
-      float blk[9];
-      for (int j = 0; j < 3; ++j) { blk[j] = vals[9 * e + j] * is0; blk[3 + j] = vals[9 * e + 3 + j] * is1; blk[6 + j] = vals[9 * e + 6 + j] * is2; }
-      for (int pi = 0; pi < 2; ++pi) {
-        const float wi = pw[2 * a + pi];
-        if (wi == 0.f) continue;
-        const int32_t i = par[2 * a + pi];
-        for (int pj = 0; pj < 2; ++pj) {
-          const float wj = pw[2 * (int64_t)b + pj];
-          if (wj == 0.f) continue;
-          const int32_t j = par[2 * (int64_t)b + pj];
-          int64_t lo = cptr[i], hi = cptr[i + 1];
-          while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ccol[mid] < j) lo = mid + 1; else hi = mid; }
-          if (lo < cptr[i + 1] && ccol[lo] == j) { for (int t = 0; t < 9; ++t) unsafeAtomicAdd(&cvals[9 * lo + t], wi * wj * blk[t]); }
-          else atomicOr(&flags[1], 64);
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = wave; i < nc; i += nwaves) {
+    const int64_t c0 = cptr[i], c1 = cptr[i + 1];
+    for (int64_t e0 = c0; e0 < c1; e0 += 64) {
+      const int64_t e = e0 + lane;
+      const int32_t mycol = e < c1 ? ccol[e] : -1;
+      float acc[9];
+      for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+      bool missed = false;
+      for (int64_t k = chptr[i]; k < chptr[i + 1]; ++k) {
+        const int64_t a = child[k];
+        if (flag[a]) continue;
+        const float wi = chw[k];
+        const int64_t r = snode[a];
+        const float is0 = (float)(1.0 / rowscale[6 * r + 3]), is1 = (float)(1.0 / rowscale[6 * r + 4]), is2 = (float)(1.0 / rowscale[6 * r + 5]);
+        for (int64_t ee = sb_ptr[a]; ee < sb_ptr[a + 1]; ++ee) {
+          const int64_t b = sb_col[ee];
+          if (flag[b]) continue;
+          for (int pj = 0; pj < 2; ++pj) {
+            const float wj = pw[2 * b + pj];
+            if (wj == 0.f) continue;
+            const int32_t j = par[2 * b + pj];
+            if (j == mycol) {
+              const float ww = wi * wj;
+              for (int t = 0; t < 3; ++t) {
+                acc[t] += ww * (vals[9 * ee + t] * is0);
+                acc[3 + t] += ww * (vals[9 * ee + 3 + t] * is1);
+                acc[6 + t] += ww * (vals[9 * ee + 6 + t] * is2);
+              }
+            }
+            if (c1 - c0 <= 64 && !__any(j == mycol)) missed = true;
+          }
         }
       }
+      if (e < c1) for (int t = 0; t < 9; ++t) cvals[9 * e + t] = acc[t];
+      if (missed && lane == 0) atomicOr(&flags[1], 64);
     }
   }
 }
@@ -1491,13 +1518,14 @@ __global__ void k_sbmg_prolong(int64_t nS, const int32_t* __restrict__ par, cons
 void launch_sbmg_flags(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals, uint8_t* flag) {
   hipLaunchKernelGGL(k_sbmg_flags, dim3(gridn(nS)), dim3(256), 0, st, nS, sb_ptr, sb_col, vals, flag);
 }
-void launch_sbmg_rap(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
-                     const int32_t* snode, const double* rowscale, const uint8_t* flag, const int32_t* par, const float* pw,
-                     const int64_t* cptr, const int32_t* ccol, float* cvals, int32_t* flags) {
-  int64_t blocks = (nS + 15) / 16;
+void launch_sbmg_rap(hipStream_t st, int64_t nc, const int64_t* chptr, const int32_t* child, const float* chw,
+                     const int64_t* sb_ptr, const int32_t* sb_col, const float* vals, const int32_t* snode,
+                     const double* rowscale, const uint8_t* flag, const int32_t* par, const float* pw, const int64_t* cptr,
+                     const int32_t* ccol, float* cvals, int32_t* flags) {
+  int64_t blocks = (nc + 3) / 4;
   if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(k_sbmg_rap, dim3((unsigned)blocks), dim3(256), 0, st, nS, sb_ptr, sb_col, vals, snode, rowscale, flag, par,
-                     pw, cptr, ccol, cvals, flags);
+  hipLaunchKernelGGL(k_sbmg_rap, dim3((unsigned)blocks), dim3(256), 0, st, nc, chptr, child, chw, sb_ptr, sb_col, vals, snode,
+                     rowscale, flag, par, pw, cptr, ccol, cvals, flags);
 }
 void launch_sbmg_coarse_finish(hipStream_t st, int64_t nc, const int64_t* cptr, const int32_t* ccol, float* cvals,
                                const int32_t* cfine, const uint8_t* flag, float* cbinv12, uint8_t* cflag, int32_t* rowmax_bits) {
@@ -1876,16 +1904,24 @@ __global__ void k_f32_ripple4(int64_t n, float* __restrict__ x) {          // fl
     reinterpret_cast<float4*>(x)[i] = make_float4(a, b, c, 0.f);
   }
 }
-__global__ __launch_bounds__(256) void k_f32_sumsq(int64_t n, const float* __restrict__ x, double* __restrict__ out) {
+// one workgroup, fixed order of the partial sums: the eigenvalue estimate (and with it the Chebyshev interval of a coarse
+// level) is the same in every run; the vectors are the coarse levels' (a few 1e5 entries)
+__global__ __launch_bounds__(1024) void k_f32_sumsq(int64_t n, const float* __restrict__ x, double* __restrict__ out) {
+  __shared__ double sh[1024];
   double s = 0.0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += (double)x[i] * x[i];
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  if ((threadIdx.x & 63) == 0 && s != 0.0) unsafeAtomicAdd(out, s);
+  for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)x[i] * x[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
 }
 void launch_f32_ripple4(hipStream_t st, int64_t nnodes, float* x) {
   hipLaunchKernelGGL(k_f32_ripple4, dim3(gridn(nnodes)), dim3(256), 0, st, nnodes, x);
 }
 void launch_f32_sumsq(hipStream_t st, int64_t n, const float* x, double* out) {
-  hipLaunchKernelGGL(k_f32_sumsq, dim3(gridn(n) > 1024 ? 1024 : gridn(n)), dim3(256), 0, st, n, x, out);
+  hipLaunchKernelGGL(k_f32_sumsq, dim3(1), dim3(1024), 0, st, n, x, out);
 }
 }  // namespace fsi

@@ -113,6 +113,16 @@ struct FsiCtx {
   fsi::DevBuf<uint16_t> epnbr;               // [C][10][4]  index of vertex b among vertex-neighbours of node a
   fsi::DevBuf<int32_t> cell_rank;            // [C][10] rank of the local nodes
   fsi::DevBuf<int32_t> cell_prow;            // [C][4] pressure dofs (solver layout): with cell_rank, 56 bytes per cell give the 64 local dofs
+  // Reproducible assembly (the default; FSI_ASSEMBLY=atomic switches both off).  Residual: element vectors stored to
+  // Re[C][64] and summed per dof over the node's incident cells in ascending order (k_residual_gather).  Jacobian: the cells
+  // are coloured (cells of one colour share no node) and every colour is one launch, so no matrix entry receives two adds
+  // whose order could vary.
+  fsi::DevBuf<double> Re;                    // [C][64]
+  fsi::DevBuf<int64_t> inc_ptr, pinc_ptr;    // [N2 + 1], [V + 1]
+  fsi::DevBuf<int32_t> inc, pinc;            // 16 * cell + local node
+  int ncellcol = 0;                          // 0: single launch, unordered atomics (FSI_ASSEMBLY=atomic)
+  fsi::DevBuf<int32_t> col_cells;            // [C] cell ids sorted by colour
+  std::vector<int64_t> h_col_ptr;            // [ncellcol + 1]
 
   // node graph + CSR structure
   std::vector<int64_t> h_nadj_ptr;           // [N2+1]
@@ -153,7 +163,9 @@ struct FsiCtx {
   fsi::DevBuf<int32_t> pf_dofs;
   fsi::DevBuf<double> pf_coef;
   double P = 0.0;
-  int64_t nrobin = 0;                        // Robin COO: rows (v dofs), cols (d or v dofs), values
+  int64_t nrobin = 0;                        // Robin entries sorted by (row, col), duplicates merged: cols (d or v dofs), values
+  int64_t nrobin_rows = 0;                   // distinct rows (v dofs) rb_urow, entries of row k: rb_ptr[k] .. rb_ptr[k+1]
+  fsi::DevBuf<int32_t> rb_urow, rb_ptr;
   fsi::DevBuf<int32_t> rb_row, rb_col;
   fsi::DevBuf<double> rb_val;
   fsi::DevBuf<int64_t> rb_pos;               // position in the CSR values
@@ -303,6 +315,9 @@ struct FsiCtx {
   fsi::DevBuf<int32_t> a32_cols;             // padded index rows
   int64_t a32_ptail = 0, a32_tail_src = 0, a32_tail_nnz = 0;     // pressure rows: behind the padded node blocks, unpadded
   bool gcr_stagnated = false;                // the last cycle ended on 40 iterations without a 10 % gain
+  bool gcr_stalled = false;                  // ... on 80 iterations without a 10 % gain far from its target (truncated recurrence stuck)
+  int64_t newton_retries = 0;                // Newton iterations whose linear solve failed on a stale Jacobian and succeeded after a refresh
+  int64_t gcr_restarts = 0;                  // solves that dropped the kept directions and restarted because of that
   int debug_prec_apply = 0;
   fsi::DevBuf<float> Avp32, Apv32; bool pv32_ok = false;     // FSI_PV_FP32 (default on): FP32 copies for k_vel_correct32 / k_pres_rhs32
   fsi::DevBuf<double> vv_dinv;               // [3 N2] 1 / diag(Avv~), for the velocity correction
@@ -313,6 +328,7 @@ struct FsiCtx {
 
   float sbmg_gersh = 2.f, mg_gersh = 2.f;     // the row-sum bounds of the two coarse levels (fallback of the self-test)
   int coarse_power = 1;                      // FSI_COARSE_POWER=0: coarse levels' Chebyshev intervals end at the Gershgorin bound (round 2)
+  bool dd_same = false, dd_checksum_valid = false;   // this refresh found the displacement block unchanged / a checksum exists
   double lmax_d_cached = 0.0, dd_checksum = 0.0;   // largest eigenvalue of the (constant) displacement block, and what it was computed for
   // Compression of the kept Krylov space (FSI_KRYLOV_COMPRESS="soft:keep", off by default): when more
   // than `soft` directions are kept at the end of a solve they are replaced by `keep` combinations - the part of the space

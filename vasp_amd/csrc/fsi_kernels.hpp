@@ -61,6 +61,24 @@ struct ElemArrays {
   const uint16_t* epnbr;       // [C][10][4]
 };
 
+// Assembly colouring: cells of one colour share no node, so one launch over a colour adds at most once to any entry of the
+// global vector / matrix and the colours' launches are ordered by the stream: assembly is bitwise reproducible.
+struct CellColours {
+  int ncolours = 0;              // 0: one launch over all cells, unordered atomics
+  const int32_t* cells = nullptr;   // device: cell ids sorted by colour (ascending inside a colour)
+  const int64_t* ptr = nullptr;     // host: [ncolours + 1]
+};
+
+// Residual assembly as a gather: element vectors in Re[C][64], summed per dof over the incidences of its node (see k_residual)
+struct ResidualGather {
+  double* Re = nullptr;             // nullptr: scatter-add with atomics instead
+  int64_t N2 = 0, V = 0;
+  const int64_t* inc_ptr = nullptr;    // [N2 + 1] by node rank
+  const int32_t* inc = nullptr;        // 16 * cell + local node, ascending
+  const int64_t* pinc_ptr = nullptr;   // [V + 1] by pressure row
+  const int32_t* pinc = nullptr;       // 16 * cell + local vertex, ascending
+};
+
 struct ElemParams {
   Scheme sc;
   FluidProps fluid[MAX_REGIONS];
@@ -71,19 +89,19 @@ struct ElemParams {
 hipError_t upload_tables();
 void launch_geometry(hipStream_t st, int64_t C, const double* coords, const int32_t* tet_vertices, double* geom);
 void launch_residual(hipStream_t st, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
-                     const double* U1, double* F);
+                     const double* U1, double* F, const ResidualGather& rg);
 constexpr int STAT_PARTS = 256;      // stage-1 workgroups of the cell-statistics reduction: cellvals needs 2 C + 8 + 4 * STAT_PARTS doubles
 void launch_cell_stats(hipStream_t st, int64_t C, const ElemArrays& ea, const double* X, double* cellvals, double* out);
 void launch_probe(hipStream_t st, int64_t n, const ElemArrays& ea, const int32_t* cells, const double* bary, const double* X,
                   double* out);
-void launch_l2norm(hipStream_t st, int64_t C, const ElemArrays& ea, const double* X, double* out);
+void launch_l2norm(hipStream_t st, int64_t C, const ElemArrays& ea, const double* X, double* part, double* out);
 void launch_jacobian(hipStream_t st, int part, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
-                     const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals);
+                     const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals, const CellColours& cc);
 
 void launch_sweep_csr_f64(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const double* vals,
                           const int64_t* diagpos, double c1, double c2, const double* din, double* dout, double* x, double* r);
 void launch_f32_ripple4(hipStream_t st, int64_t nnodes, float* x);                 // pseudo-random float4 per node, pad lane 0
-void launch_f32_sumsq(hipStream_t st, int64_t n, const float* x, double* out);      // out += sum x^2 (out zeroed by the caller)
+void launch_f32_sumsq(hipStream_t st, int64_t n, const float* x, double* out);      // out[0] = sum x^2, fixed summation order
 
 // fsi_rccl.hip — collectives issued by the library on the solver stream (RCCL resolved with dlopen)
 int rccl_unique_id(void* out128, std::string* err);
@@ -125,8 +143,8 @@ void launch_bc_set(hipStream_t st, double* U, const int32_t* bc, const double* g
 // matrix finishing: A = Jn + Apre; ident_zeros; bc rows; row equilibration
 void launch_matrix_finish(hipStream_t st, int64_t n, const int64_t* rowptr, const int64_t* diagpos, double* A,
                           const double* Apre, const int32_t* bc, int64_t nbc, double* rowscale, int32_t* bcmask);
-void launch_robin_residual(hipStream_t st, int64_t n, const int32_t* row, const int32_t* col, const double* val,
-                           double th0, double th1, const double* U, const double* U1, double* F);
+void launch_robin_residual(hipStream_t st, int64_t nrows, const int32_t* urow, const int32_t* ptr, const int32_t* col,
+                           const double* val, double th0, double th1, const double* U, const double* U1, double* F);
 void launch_add_at(hipStream_t st, double* vals, const int64_t* pos, const double* v, double a, int64_t n);
 enum SpmvTag : int { SPMV_MONOLITHIC = 0, SPMV_SOLID_BLOCK = 1, SPMV_FIELD_BLOCK = 2 };
 void launch_spmv_node6_f32(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const float* vals,
@@ -241,9 +259,10 @@ void launch_block_scale_d(hipStream_t st, int64_t nS, const double* binv9, doubl
 void launch_cheb_init_b3(hipStream_t st, int64_t nS, const float* rhs, const float* binv12, float inv_theta, float* x, float* r, float* d);
 void launch_mg_d0(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
                   const double* rowscale, const uint8_t* rowflag, float* d0, int32_t* flags);
-void launch_mg_rap(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
-                   const double* rowscale, const uint8_t* rowflag, const int32_t* par, const float* pw, const int64_t* cptr,
-                   const int32_t* ccol, double* Ac, int32_t* flags);
+void launch_mg_rap(hipStream_t st, int64_t nc, const int64_t* chptr, const int32_t* child, const float* chw,
+                   const int64_t* nadj_ptr, const int32_t* nadj, const double* db, const double* rowscale,
+                   const uint8_t* rowflag, const int32_t* par, const float* pw, const int64_t* cptr, const int32_t* ccol,
+                   double* Ac, int32_t* flags);
 void launch_mg_coarse_finish(hipStream_t st, int64_t nc, const int64_t* cptr, const int32_t* ccol, const double* Ac,
                              const int32_t* cfine, const uint8_t* rowflag, float* cc, uint8_t* cflag, float* dcinv4,
                              int32_t* rowmax_bits);
@@ -278,9 +297,10 @@ void launch_sweep_schur_tiled(hipStream_t st, int64_t n, int max_nu, const int64
                               const double* din, double* dout, double* x, double* r);
 void launch_f32_to_f64(hipStream_t st, int64_t n, const float* a, double* b);
 void launch_sbmg_flags(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals, uint8_t* flag);
-void launch_sbmg_rap(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
-                     const int32_t* snode, const double* rowscale, const uint8_t* flag, const int32_t* par, const float* pw,
-                     const int64_t* cptr, const int32_t* ccol, float* cvals, int32_t* flags);
+void launch_sbmg_rap(hipStream_t st, int64_t nc, const int64_t* chptr, const int32_t* child, const float* chw,
+                     const int64_t* sb_ptr, const int32_t* sb_col, const float* vals, const int32_t* snode,
+                     const double* rowscale, const uint8_t* flag, const int32_t* par, const float* pw, const int64_t* cptr,
+                     const int32_t* ccol, float* cvals, int32_t* flags);
 void launch_sbmg_coarse_finish(hipStream_t st, int64_t nc, const int64_t* cptr, const int32_t* ccol, float* cvals,
                                const int32_t* cfine, const uint8_t* flag, float* cbinv12, uint8_t* cflag, int32_t* rowmax_bits);
 void launch_sbmg_restrict(hipStream_t st, int64_t nc, const int64_t* chptr, const int32_t* child, const float* chw,

@@ -77,8 +77,9 @@ __global__ void k_scale(double* y, double a, int64_t n) { GRID_STRIDE(i, n) y[i]
 __global__ void k_mul(double* z, const double* x, const double* y, int64_t n) { GRID_STRIDE(i, n) z[i] = x[i] * y[i]; }
 __global__ void k_gather(double* d, const double* s, const int32_t* idx, int64_t n) { GRID_STRIDE(i, n) d[i] = s[idx[i]]; }
 __global__ void k_scatter(double* d, const double* s, const int32_t* idx, int64_t n) { GRID_STRIDE(i, n) d[idx[i]] = s[i]; }
+// the targets are distinct (merged on the host): plain adds
 __global__ void k_add_indexed(double* y, const int32_t* idx, const double* coef, double a, int64_t n) {
-  GRID_STRIDE(i, n) unsafeAtomicAdd(&y[idx[i]], a * coef[i]);
+  GRID_STRIDE(i, n) y[idx[i]] += a * coef[i];
 }
 __global__ void k_negate(double* b, const double* F, int64_t n) { GRID_STRIDE(i, n) b[i] = -F[i]; }
 __global__ void k_bc_rhs(double* b, const double* U, const int32_t* bc, const double* g, int64_t n) {
@@ -87,12 +88,17 @@ __global__ void k_bc_rhs(double* b, const double* U, const int32_t* bc, const do
 __global__ void k_bc_set(double* U, const int32_t* bc, const double* g, int64_t n) { GRID_STRIDE(i, n) U[bc[i]] = g[i]; }
 __global__ void k_mark(int32_t* mask, const int32_t* idx, int64_t n) { GRID_STRIDE(i, n) mask[idx[i]] = 1; }
 __global__ void k_izero(int32_t* x, int64_t n) { GRID_STRIDE(i, n) x[i] = 0; }
-__global__ void k_robin_residual(int64_t n, const int32_t* row, const int32_t* col, const double* val, double th0,
-                                 double th1, const double* U, const double* U1, double* F) {
-  GRID_STRIDE(i, n) unsafeAtomicAdd(&F[row[i]], val[i] * (th0 * U[col[i]] + th1 * U1[col[i]]));
+// one thread per distinct row: its entries (sorted by column on the host) are added in that order
+__global__ void k_robin_residual(int64_t nrows, const int32_t* urow, const int32_t* ptr, const int32_t* col, const double* val,
+                                 double th0, double th1, const double* U, const double* U1, double* F) {
+  GRID_STRIDE(k, nrows) {
+    double s = 0.0;
+    for (int32_t i = ptr[k]; i < ptr[k + 1]; ++i) s += val[i] * (th0 * U[col[i]] + th1 * U1[col[i]]);
+    F[urow[k]] += s;
+  }
 }
-__global__ void k_add_at(double* vals, const int64_t* pos, const double* v, double a, int64_t n) {
-  GRID_STRIDE(i, n) unsafeAtomicAdd(&vals[pos[i]], a * v[i]);
+__global__ void k_add_at(double* vals, const int64_t* pos, const double* v, double a, int64_t n) {     // distinct positions
+  GRID_STRIDE(i, n) vals[pos[i]] += a * v[i];
 }
 
 static inline unsigned grid_for(int64_t n, int bs = 256) {
@@ -130,9 +136,9 @@ void launch_bc_rhs(hipStream_t st, double* b, const double* U, const int32_t* bc
 void launch_bc_set(hipStream_t st, double* U, const int32_t* bc, const double* g, int64_t n) {
   if (n > 0) LAUNCH1D(k_bc_set, st, n, U, bc, g, n);
 }
-void launch_robin_residual(hipStream_t st, int64_t n, const int32_t* row, const int32_t* col, const double* val,
-                           double th0, double th1, const double* U, const double* U1, double* F) {
-  if (n > 0) LAUNCH1D(k_robin_residual, st, n, n, row, col, val, th0, th1, U, U1, F);
+void launch_robin_residual(hipStream_t st, int64_t nrows, const int32_t* urow, const int32_t* ptr, const int32_t* col,
+                           const double* val, double th0, double th1, const double* U, const double* U1, double* F) {
+  if (nrows > 0) LAUNCH1D(k_robin_residual, st, nrows, nrows, urow, ptr, col, val, th0, th1, U, U1, F);
 }
 void launch_add_at(hipStream_t st, double* vals, const int64_t* pos, const double* v, double a, int64_t n) {
   if (n > 0) LAUNCH1D(k_add_at, st, n, vals, pos, v, a, n);
