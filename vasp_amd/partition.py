@@ -272,7 +272,13 @@ class DistBackend:
         self.world = dist.get_world_size() if world is None else world
         self.on_gpu_wire = dist.get_backend() == "nccl"                       # RCCL moves device buffers directly
         import os
-        overlap = int(os.environ.get("VASPFSI_OVERLAP", 2)) if overlap is None else overlap
+        # Overlap of the restricted Schwarz preconditioner, in node layers.  Measured on the 1.12 M-tet bench mesh (5 steps from
+        # rest, Krylov iterations; one context: 114): 2 ranks 138 / 124 / 118 with 2 / 3 / 4 layers (3.8 / 5.1 / 6.4 % ghost
+        # cells), 4 ranks 140 / 127 / 120 / 115 with 2 / 3 / 4 / 6 layers (11 / 14 / 18 / 27 %): four layers keep the count within
+        # 5 % of one context; iterations x local cells is smallest at 4 layers up to 4 ranks and flat between 3 and 4 beyond
+        # (profiles/r03_overlap_scan.txt).
+        if overlap is None:
+            overlap = int(os.environ["VASPFSI_OVERLAP"]) if "VASPFSI_OVERLAP" in os.environ else (4 if self.world <= 4 else 3)
         self.part = Partition(desc, self.rank, self.world, owner, overlap)
         self.ndof_global = 6 * self.part.N2 + self.part.V
         self.hb = HipBackend(self.part.local_desc, device=device, num_owned_cells=self.part.num_owned_cells, **kw)
