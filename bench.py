@@ -324,7 +324,9 @@ def main():
                        "storage_precisions": ("state, residual, Jacobian and every accumulation FP64; Krylov basis "
                                               f"FP{8 * qb}" + (" with an FP64 window of 32 columns" if qb == 4 else "")
                                               + f"; {op32} of {int(tm['spmv_calls'])} outer products on an FP32 copy of the Jacobian values, "
-                                              "every linear answer judged on the FP64 residual of the FP64 matrix; preconditioner "
+                                              + ("every linear answer judged on the FP64 residual of the FP64 matrix; " if qb == 4 else
+                                                 "iterations on the FP64 matrix, answers re-judged on b - A x when asked below 1e-8 or when the "
+                                                 "kept pairs are at risk (full store, long or stalled cycle, earlier mismatch); ") + "preconditioner "
                                               "sweeps: " + ("FP16" if fp16 else "FP32") + " matrix values, FP32 vectors (Schur: "
                                               + {0: "FP16", 4: "FP32", 8: "FP64"}[int(tm["schur_elem_bytes"])] + " values, FP64 vectors)")},
             "dof_updates_per_s": total_newton * ndof / elapsed,

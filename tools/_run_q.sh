@@ -1,6 +1,6 @@
-R=$GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/prof_q
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_q -- python3 $R/bench.py --no-cpu-baseline --no-fp64-line --steps 22 --warmup 1 > $R/gpurun_out/r03_bench_q_prof.json 2> $R/gpurun_out/r03_bench_q_prof.err; echo "prof rc=$?"
-cd $R
-python tools/_trace_fill.py /tmp/prof_q
+python -m pytest tests -m gpu -q -x > gpurun_out/r03_pytest_gpu_q.log 2>&1; tail -3 gpurun_out/r03_pytest_gpu_q.log
+python bench.py --no-cpu-baseline > gpurun_out/r03_bench_q.json 2>gpurun_out/r03_bench_q.err
+python tools/show_bench.py gpurun_out/r03_bench_q.json | cut -c1-330
+python -c "
+import json
+d=json.loads(open('gpurun_out/r03_bench_q.json').read().strip().splitlines()[-1]); print('fp64 storage', d.get('value_fp64_storage'))"

@@ -316,6 +316,8 @@ struct FsiCtx {
   int64_t a32_ptail = 0, a32_tail_src = 0, a32_tail_nnz = 0;     // pressure rows: behind the padded node blocks, unpadded
   bool gcr_stagnated = false;                // the last cycle ended on 40 iterations without a 10 % gain
   bool gcr_stalled = false;                  // ... on 80 iterations without a 10 % gain far from its target (truncated recurrence stuck)
+  double f32_cycle_floor = 1e-6;             // FP32 basis: a cycle reduces the residual by at most this factor before the FP64 verdict
+  bool f64_suspect = false;                  // FP64 basis: a verdict of the present store differed from its recurrence (see solve_gcr)
   int64_t newton_retries = 0;                // Newton iterations whose linear solve failed on a stale Jacobian and succeeded after a refresh
   int64_t gcr_restarts = 0;                  // solves that dropped the kept directions and restarted because of that
   int debug_prec_apply = 0;
