@@ -1237,6 +1237,12 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
     launch_gcr_update(st, f32, ctx->KQ.p, ctx->ldq, ctx->KZ.p, ctx->ldz, slot, n, w, z, 1.0 / wn, alpha, r, qd, ctx->scratch.p,
                       ctx->gcr_out.p + 4);
     src = (ctx->gcr_arnoldi && !f32) ? qd : r;
+    // A direction that left the residual where it was (alpha^2 below 1e-3 |r|^2): A M^-1 r lies in the kept space, and as r
+    // has not moved the next A M^-1 r is the same vector again - GCR proper cannot leave this point (seen on the 100 k-tet
+    // mesh: |r| constant to four digits for 40 iterations until the stagnation rule ended the cycle, and again in the next
+    // solve, which then lost the FP32 basis and the recycled space).  The next direction is made from the q just stored
+    // instead (an Arnoldi step: the Krylov space of A M^-1 keeps growing whatever r does) until the residual moves again.
+    if (alpha * alpha <= ctx->gcr_escape * rnorm * rnorm) { src = qd; ctx->gcr_arnoldi_steps += 1; }
     // coefficients of the new direction on the store:  p = (z - sum_j h_j p_j) / wn
     std::vector<double> c(cap, 0.0);
     c[slot] = 1.0;
@@ -2723,6 +2729,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   if (getenv("FSI_NEWTON_FORCING")) ctx->newton_forcing = atof(getenv("FSI_NEWTON_FORCING"));
   if (getenv("FSI_GCR_REORTH")) ctx->gcr_reorth = atof(getenv("FSI_GCR_REORTH"));
   if (getenv("FSI_F32_CYCLE_FLOOR")) ctx->f32_cycle_floor = atof(getenv("FSI_F32_CYCLE_FLOOR"));
+  if (getenv("FSI_GCR_ESCAPE")) ctx->gcr_escape = atof(getenv("FSI_GCR_ESCAPE"));      // 0: never leave the residual-based directions
   if (getenv("FSI_GCR_ARNOLDI")) ctx->gcr_arnoldi = atoi(getenv("FSI_GCR_ARNOLDI")) != 0;
   ctx->ldq = (n + 3) & ~(int64_t)3;
   ctx->ldz = (n + 1) & ~(int64_t)1;

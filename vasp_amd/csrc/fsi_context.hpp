@@ -319,6 +319,8 @@ struct FsiCtx {
   double f32_cycle_floor = 1e-6;             // FP32 basis: a cycle reduces the residual by at most this factor before the FP64 verdict
   bool f64_suspect = false;                  // FP64 basis: a verdict of the present store differed from its recurrence (see solve_gcr)
   int64_t newton_retries = 0;                // Newton iterations whose linear solve failed on a stale Jacobian and succeeded after a refresh
+  double gcr_escape = 1e-3;                  // alpha^2 <= this * |r|^2: the direction did not move the residual, next one from q
+  int64_t gcr_arnoldi_steps = 0;             // directions made from the last q because the residual had not moved (see gcr_cycle)
   int64_t gcr_restarts = 0;                  // solves that dropped the kept directions and restarted because of that
   int debug_prec_apply = 0;
   fsi::DevBuf<float> Avp32, Apv32; bool pv32_ok = false;     // FSI_PV_FP32 (default on): FP32 copies for k_vel_correct32 / k_pres_rhs32
