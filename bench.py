@@ -335,6 +335,7 @@ def main():
             "phase_calls": {k: tm[k] for k in ("residual_calls", "jacobian_calls", "factor_calls", "spmv_calls", "precond_calls",
                                                "krylov_solves", "krylov_iters", "inner_vv_iters", "inner_schur_iters", "inner_dd_iters",
                                                "ortho_q_launches", "ortho_q_cols", "ortho_z_launches", "ortho_z_cols")},
+            "solver_events": {k: int(tm[k]) for k in ("gcr_arnoldi_steps", "gcr_restarts", "newton_retries", "fp32_fallbacks")},
             "setup_s": setup_s,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": d["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,

@@ -261,6 +261,12 @@ typedef struct FsiTimers {
   int64_t assembly_colours;                          /* colours of the assembly colouring (one launch of the residual /
                                                         Jacobian kernel each: bitwise reproducible scatter-adds); 0: one
                                                         launch over all cells with unordered atomics (FSI_ASSEMBLY=atomic) */
+  /* what the linear solver had to do beyond iterating                                      */
+  int64_t gcr_arnoldi_steps;                         /* directions made from the last q because the residual had not moved   */
+  int64_t gcr_restarts;                              /* solves that dropped the kept directions (pairs lost / full store stalled) */
+  int64_t newton_retries;                            /* Newton iterations whose solve failed on a stale Jacobian and succeeded
+                                                        after a refresh                                                      */
+  int64_t fp32_fallbacks;                            /* Jacobian lifetimes that lost the FP32 basis and finished in FP64      */
 } FsiTimers;
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
 /* Measurement aid: streams `bytes` of the (idle) Krylov store once per kernel with 4-, 8-, 16- and 32-byte loads and

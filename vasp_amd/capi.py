@@ -67,7 +67,8 @@ class FsiTimers(C.Structure):
                 ("flush_ms", C.c_double), ("flush_calls", C.c_int64), ("schur_ms", C.c_double), ("schur_calls", C.c_int64),
                 ("schur_elem_bytes", C.c_int64), ("spmv_compact", C.c_int64), ("node_pairs", C.c_int64),
                 ("node_vertex_pairs", C.c_int64), ("spmv_fp32_calls", C.c_int64), ("sweep_flags", C.c_int64), ("part_allreduces", C.c_int64),
-                ("assembly_colours", C.c_int64)]
+                ("assembly_colours", C.c_int64), ("gcr_arnoldi_steps", C.c_int64), ("gcr_restarts", C.c_int64),
+                ("newton_retries", C.c_int64), ("fp32_fallbacks", C.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -1004,7 +1004,7 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
   if (ctx->gcr_reorth > 0.0) reorth = ctx->gcr_reorth;
   std::fill(ctx->hot_slots.begin(), ctx->hot_slots.end(), -1);      // FP64 window: directions of this cycle only
   ctx->hot_next = 0;
-  double rn2 = 0.0;
+  double rn2 = 0.0, r_entry = 0.0;
   {   // projection on the recycled space: r -= Q (Q^T r), x-coefficients y = Q^T r
     Phase ph(ctx, &ctx->t_ortho);
     const int m = (int)ctx->kry_hw;
@@ -1016,6 +1016,7 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
       HIPCHK(hipMemcpyAsync(ctx->hcoef.p, hh, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
     }
     rn2 = hh[m];
+    r_entry = std::sqrt(std::max(rn2, 0.0));
     if (ctx->rz_soft > 0) {
       ctx->rz_prev_slot = -1;
       for (int j = 0; j < m; ++j) if (ctx->kry_born[j] >= 0) ctx->rz_a[j] += hh[j];
@@ -1047,6 +1048,12 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
   bool rr_pending = false;     // partitioned: the last update's local |r|^2 has not been all-reduced yet (it rides with the next pass)
   while (rnorm > target && *iters < max_it) {
     if (since_gain >= 40 && (f32 || rnorm <= 100.0 * target)) { ctx->gcr_stagnated = true; break; }
+    // FP32 basis, four decades below the residual the cycle was entered with and six iterations without a 10 % gain: this is
+    // the floor of the FP32 columns, not a plateau - the new q are orthogonal to the kept ones to 1e-7 times the cancellation,
+    // r has collected that much of span(Q), and directions made orthogonal to Q cannot remove it.  Ending the cycle costs the
+    // verdict's product and a projection, which removes it at once (48 k-tet mesh: |r| crawled from 6.05e-8 to 6.01e-8 in 37
+    // iterations, and the projection that followed took it to a third of the target without a single new direction).
+    if (f32 && since_gain >= 6 && rnorm <= 1e-4 * r_entry) { ctx->gcr_stagnated = true; break; }
     // Far from the target, the store full (the oldest directions kept, a ring of 64 rotating) and no 10 % gain in two turns
     // of the ring: the TRUNCATED recurrence is stuck where the full one would sit out the plateau - seen late in a Jacobian's
     // life on the known-answer case driven to round-off, |r| flat to four digits for 3 700 iterations.  solve_gcr drops the
@@ -1420,6 +1427,7 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
       if (ctx->kry_fp32_policy == 2) {      // FP64 for the rest of this Jacobian's life; re-armed at the next refresh (twice at most)
         ctx->kry_fp32_policy = 3;
         ctx->kry_fp32_failures += 1;
+        ctx->kry_fp32_failures_total += 1;
       }
     }
     rstart = rnorm;
@@ -3371,7 +3379,8 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
                    (int64_t)((ctx->tiled && ctx->fused_sweeps ? 1 : 0) | (ctx->tiled && ctx->fused_sweeps && ctx->sweeps_fp16 ? 2 : 0) |
                              (ctx->solid_fp32 ? 4 : 0) | (ctx->solid_fp32 && ctx->solid_block_jacobi && ctx->solid_fused ? 8 : 0) |
                              (ctx->sbmg_ready ? 16 : 0) | (ctx->mg_ready ? 32 : 0) | (ctx->l3.ready ? 64 : 0)),
-                   ctx->part_allreduces, (int64_t)ctx->ncellcol};
+                   ctx->part_allreduces, (int64_t)ctx->ncellcol, ctx->gcr_arnoldi_steps, ctx->gcr_restarts, ctx->newton_retries,
+                   (int64_t)ctx->kry_fp32_failures_total};
   if (reset) {
     for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_flush, &ctx->t_sch, &ctx->t_kry, &ctx->t_ss, &ctx->t_db, &ctx->t_sc}) {
       t->ms = 0.0;
@@ -3383,6 +3392,7 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
     ctx->inner_calls = 0;
     ctx->ortho_q_cols = ctx->ortho_q_launches = ctx->ortho_z_cols = ctx->ortho_z_launches = 0;
     ctx->part_allreduces = 0;
+    ctx->gcr_arnoldi_steps = ctx->gcr_restarts = ctx->newton_retries = ctx->kry_fp32_failures_total = 0;
     ctx->sample_budget = 16;      // the sweep kernels of the next 16 preconditioner applications are sampled with events
   }
   return FSI_OK;

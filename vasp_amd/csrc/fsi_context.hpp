@@ -320,6 +320,7 @@ struct FsiCtx {
   bool f64_suspect = false;                  // FP64 basis: a verdict of the present store differed from its recurrence (see solve_gcr)
   int64_t newton_retries = 0;                // Newton iterations whose linear solve failed on a stale Jacobian and succeeded after a refresh
   double gcr_escape = 1e-3;                  // alpha^2 <= this * |r|^2: the direction did not move the residual, next one from q
+  int64_t kry_fp32_failures_total = 0;       // fall-backs from the FP32 basis since the timers were reset
   int64_t gcr_arnoldi_steps = 0;             // directions made from the last q because the residual had not moved (see gcr_cycle)
   int64_t gcr_restarts = 0;                  // solves that dropped the kept directions and restarted because of that
   int debug_prec_apply = 0;
