@@ -5,8 +5,10 @@ set -o pipefail
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final3
 mkdir -p $O
+if [ -z "$SKIP_PMC" ]; then
 bash tools/gpu_pmc_r3.sh 2>&1 | cut -c1-200
 cp gpurun_out/pmc/pmc_traffic.json profiles/r03_pmc_traffic.json
+fi
 VASPFSI_DIST_BACKEND=gloo VASPFSI_ONE_GPU=1 VASPFSI_LIN_MAX_IT=600 timeout -k 10 400 python bench.py --gpus 2 --steps 3 --warmup 1 --tets 100000 --no-cpu-baseline > $O/launch2.json 2> $O/launch2.err; echo "launch2 rc=$?"
 python tools/show_bench.py $O/launch2.json | cut -c1-400
 VASPFSI_FORCE_PARTITION=1 VASPFSI_RCCL=1 FSI_DEBUG=1 timeout -k 10 300 python bench.py --steps 3 --warmup 1 --tets 100000 --no-cpu-baseline > $O/rccl_library_one_rank.json 2> $O/rccl_library_one_rank.err; echo "library rccl one rank rc=$?"

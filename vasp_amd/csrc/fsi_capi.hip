@@ -1422,6 +1422,9 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
         *relres = rnorm / bnorm;
         return FSI_ERR_LINEAR;
       }
+      // (Tried in round 3: dropping the kept pairs once and staying FP32 before giving FP32 up - on a full store late in a
+      // Jacobian's life the solves that follow then need 200+ iterations each and the 100-step run loses a third: the FP64
+      // basis for the rest of the lifetime is the cheaper answer.)
       gcr_reset(ctx);
       ctx->kry_fp32 = 0;
       if (ctx->kry_fp32_policy == 2) {      // FP64 for the rest of this Jacobian's life; re-armed at the next refresh (twice at most)
@@ -2743,7 +2746,10 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   ctx->ldz = (n + 1) & ~(int64_t)1;
   const double per_dir = (double)ctx->ldz * 8.0 + (double)ctx->ldq * (ctx->kry_fp32_policy == 1 ? 4.0 : 8.0);
   int64_t cap = (int64_t)((double)free_b * 0.5 / per_dir);
-  cap = std::max<int64_t>(8, std::min<int64_t>(cap, getenv("FSI_KRYLOV_CAP") ? atoi(getenv("FSI_KRYLOV_CAP")) : 400));
+  // 600 kept directions (round 2: 400): a Jacobian's life of 20 steps makes ~380 early in a run and ~550 once the ramp is up
+  // (4.6 Newton iterations per step); a full store rotates, and the 100-step run is 5 % faster without that (12.0 against
+  // 11.4 Newton-it/s); the 20-step bench does not notice.  Half of the free HBM remains the upper limit.
+  cap = std::max<int64_t>(8, std::min<int64_t>(cap, getenv("FSI_KRYLOV_CAP") ? atoi(getenv("FSI_KRYLOV_CAP")) : 600));
   ctx->kry_cap = cap;
   HIPCHK(ctx->KZ.alloc((size_t)cap * ctx->ldz));
   HIPCHK(ctx->KQ.alloc((size_t)cap * ctx->ldq * (ctx->kry_fp32_policy == 1 ? 4 : 8)));      // FP64-sized unless FP32 is forced
