@@ -1001,6 +1001,7 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
   // FP32 storage: a cycle never has to reach below 1e-5 of its start, and the restart from the true residual absorbs
   // what a single pass leaves behind, so only a cancellation beyond 100x asks for the second pass
   double reorth = ctx->kry_fp32 ? 0.01 : std::min(0.5, std::max(0.01, 1.0 / (rtol_floor * 9e10)));
+  if (ctx->part && !ctx->kry_fp32) reorth = std::max(reorth, 0.1);      // partitioned FP64 basis: |w'|^2 is not measured in the first pass (see below)
   if (ctx->gcr_reorth > 0.0) reorth = ctx->gcr_reorth;
   std::fill(ctx->hot_slots.begin(), ctx->hot_slots.end(), -1);      // FP64 window: directions of this cycle only
   ctx->hot_next = 0;
@@ -1095,7 +1096,7 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
       HIPCHK(hipMemsetAsync(ctx->KQ.p + (size_t)slot * ctx->ldq * qbytes(ctx), 0, (size_t)ctx->ldq * qbytes(ctx), st));
     const int m = (int)ctx->kry_hw;
     std::vector<double> htot(m, 0.0);
-    double wn = 0.0, wr = 0.0, w0 = 0.0;
+    double wn = 0.0, wr = 0.0, w0 = 0.0, w_first = 0.0;
     {
       // classical Gram-Schmidt; a second pass when the first one cancelled w by more than 1 / reorth.  With recycled
       // directions w = A M^-1 r lies mostly IN the kept space, so the usual 2x criterion fires on most iterations; the
@@ -1210,6 +1211,7 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
           hot_pending = false;
         }
         if (pass == 0 && w0 == 0.0) w0 = std::sqrt(std::max(hh[m], 0.0));
+        if (pass == 0) w_first = w0;
         for (int j = 0; j < m; ++j) htot[j] += hh[j];
         if (ctx->debug_gcr) {
           const double wref = std::sqrt(std::max(hh[m], 0.0));
@@ -1224,7 +1226,25 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
         ctx->ortho_q_cols += 2 * (int64_t)m; ctx->ortho_q_launches += 2;
         wn = std::sqrt(std::max(h2[0], 0.0));
         wr = h2[1];
-        if (wn > reorth * w0) break;
+        // What one pass leaves of span(Q) in w' is (non-orthonormality of Q) x (cancellation |w| / |w'|), and that is the new
+        // column's own error against the kept ones: with cancellations of 10 - 200 on most iterations a loose criterion lets
+        // Q^T Q - I grow by that factor per column (measured on the avf problem, FP64 basis, second pass only beyond 100x:
+        // 1.5e-4, 4e-3, then q_217 . q_221 = 1.0 - duplicate columns, |r| flat for 40 iterations at a time).  The pass itself
+        // tells: |w'|^2 measured by the update kernel against |w|^2 - |h|^2, which differ by h^T (Q^T Q - I) h; their relative
+        // difference over the cancellation estimates the error the new column would carry, and a second pass is made when
+        // that exceeds the floor of the basis (FP64: 1e-9; FP32 columns are orthonormal to 6e-8 by storage: 3e-7 - scanned on the
+        // 100-step run of the bench problem: 1e-5 and 1e-6 leave two fall-backs from the FP32 basis late in a Jacobian's life,
+        // 3e-7 none, 13.1 against 12.2 - 12.35 Newton-it/s; the 20-step bench pays 0.6 %).
+        bool lost = false;
+        if (pass == 0 && (!ctx->part || f32) && h2[0] > 0.0 && hh[m] > 0.0) {
+          double hsq2 = 0.0;
+          for (int j = 0; j < m; ++j) hsq2 += hh[j] * hh[j];
+          const double disc = std::fabs(h2[0] - (hh[m] - hsq2)) / h2[0];
+          const double canc = std::sqrt(hh[m] / h2[0]);
+          lost = disc / canc > (f32 ? ctx->orth_floor32 : ctx->orth_floor64);
+          if (lost) ctx->gcr_reorth_forced += 1;
+        }
+        if (wn > reorth * w0 && !lost) break;
         w0 = wn;
       }
     }
@@ -1293,6 +1313,8 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
       FSICHK(gcr_read(ctx, ctx->gcr_out.p + 4, 1, hh));
       rnorm = std::sqrt(std::max(hh[0], 0.0));
     }
+    if (ctx->debug_gcr && getenv("FSI_DEBUG_GCR_ALL"))
+      fprintf(stderr, "[gcr]     it %d: |w'|/|w| %.2e alpha/|r| %.2e |r| %.4e%s\n", *iters, wn / std::max(w_first, 1e-300), alpha / std::max(rnorm, 1e-300), rnorm, src == r ? "" : " (next from q)");
     if (ctx->debug_gcr && (*iters % 10 == 0)) {
       fprintf(stderr, "[gcr] it %d |r| %.3e target %.3e m %d  |h_j| > 1e-6/1e-9/1e-12 |w|: %.2f %.2f %.2f of the columns\n", *iters, rnorm, target, m,
               (double)ctx->dbg_sig6 / std::max<int64_t>(1, ctx->dbg_cols), (double)ctx->dbg_sig9 / std::max<int64_t>(1, ctx->dbg_cols),
@@ -1457,6 +1479,21 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
         if (rel > 1e-9) fprintf(stderr, "[gcr]     slot %lld born %lld: |A p - q|/|q| %.3e |q| %.6f\n", (long long)k, (long long)ctx->kry_born[k], rel, std::sqrt(qn));
       }
       fprintf(stderr, "[gcr]   worst pair: slot %lld |A p - q|/|q| %.3e (|q| %.6f)\n", (long long)wk, worst, std::sqrt(qn_w));
+      // orthonormality of the kept columns: rows of Q^T Q for the last few slots
+      const int mm = (int)ctx->kry_hw;
+      double worst_o = 0.0; int wi = -1, wj = -1;
+      for (int j = std::max(0, mm - 6); j < mm; ++j) {
+        if (ctx->kry_born[j] < 0) continue;
+        const double* qj = reinterpret_cast<const double*>(ctx->KQ.p) + (size_t)j * ctx->ldq;
+        launch_gcr_dots(st, false, ctx->KQ.p, ctx->ldq, n, mm, qj, nullptr, ctx->scratch.p, ctx->hcoef.p);
+        FSICHK(gcr_read(ctx, ctx->hcoef.p, mm + 2, ctx->gcr_host));
+        for (int i = 0; i < mm; ++i) {
+          if (ctx->kry_born[i] < 0) continue;
+          const double dev = std::fabs(ctx->gcr_host[i] - (i == j ? 1.0 : 0.0));
+          if (dev > worst_o) { worst_o = dev; wi = i; wj = j; }
+        }
+      }
+      fprintf(stderr, "[gcr]   orthonormality of the last columns: max |q_i . q_j - delta| = %.3e (i %d, j %d)\n", worst_o, wi, wj);
     }
   }
   if (ctx->rz_soft > 0) {
@@ -2740,6 +2777,8 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   if (getenv("FSI_NEWTON_FORCING")) ctx->newton_forcing = atof(getenv("FSI_NEWTON_FORCING"));
   if (getenv("FSI_GCR_REORTH")) ctx->gcr_reorth = atof(getenv("FSI_GCR_REORTH"));
   if (getenv("FSI_F32_CYCLE_FLOOR")) ctx->f32_cycle_floor = atof(getenv("FSI_F32_CYCLE_FLOOR"));
+  if (getenv("FSI_ORTH_FLOOR32")) ctx->orth_floor32 = atof(getenv("FSI_ORTH_FLOOR32"));
+  if (getenv("FSI_ORTH_FLOOR64")) ctx->orth_floor64 = atof(getenv("FSI_ORTH_FLOOR64"));
   if (getenv("FSI_GCR_ESCAPE")) ctx->gcr_escape = atof(getenv("FSI_GCR_ESCAPE"));      // 0: never leave the residual-based directions
   if (getenv("FSI_GCR_ARNOLDI")) ctx->gcr_arnoldi = atoi(getenv("FSI_GCR_ARNOLDI")) != 0;
   ctx->ldq = (n + 3) & ~(int64_t)3;

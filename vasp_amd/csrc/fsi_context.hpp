@@ -319,6 +319,8 @@ struct FsiCtx {
   double f32_cycle_floor = 1e-6;             // FP32 basis: a cycle reduces the residual by at most this factor before the FP64 verdict
   bool f64_suspect = false;                  // FP64 basis: a verdict of the present store differed from its recurrence (see solve_gcr)
   int64_t newton_retries = 0;                // Newton iterations whose linear solve failed on a stale Jacobian and succeeded after a refresh
+  double orth_floor32 = 3e-7, orth_floor64 = 1e-9;   // estimated orthogonality error of a new column above which a second Gram-Schmidt pass is made
+  int64_t gcr_reorth_forced = 0;
   double gcr_escape = 1e-3;                  // alpha^2 <= this * |r|^2: the direction did not move the residual, next one from q
   int64_t kry_fp32_failures_total = 0;       // fall-backs from the FP32 basis since the timers were reset
   int64_t gcr_arnoldi_steps = 0;             // directions made from the last q because the residual had not moved (see gcr_cycle)
