@@ -18,3 +18,7 @@ VASPFSI_FORCE_PARTITION=1 timeout -k 10 300 python bench.py --steps 3 --warmup 1
 python tools/show_bench.py $O/nccl_one_rank.json | cut -c1-300
 timeout -k 10 300 python bench.py --steps 3 --warmup 1 --tets 100000 --no-cpu-baseline --no-fp64-line > $O/single_100k.json 2> $O/single_100k.err; echo "single 100k rc=$?"
 python tools/show_bench.py $O/single_100k.json | cut -c1-300
+timeout -k 10 600 python bench.py --no-cpu-baseline --no-fp64-line --steps 100 --warmup 5 > $O/bench_100_steps.json 2> $O/bench_100_steps.err; echo "100 steps rc=$?"
+python tools/show_bench.py $O/bench_100_steps.json | cut -c1-200
+python tools/gpu_avf_case.py 50000 25 > $O/avf_50k_25steps.txt 2>&1; tail -1 $O/avf_50k_25steps.txt | cut -c1-250
+python tools/gpu_avf_case.py 300000 12 > $O/avf_300k_12steps.txt 2>&1; tail -1 $O/avf_300k_12steps.txt | cut -c1-250
