@@ -324,7 +324,9 @@ def main():
                        "storage_precisions": ("state, residual, Jacobian and every accumulation FP64; Krylov basis "
                                               f"FP{8 * qb}" + (" with an FP64 window of 32 columns" if qb == 4 else "")
                                               + f"; {op32} of {int(tm['spmv_calls'])} outer products on an FP32 copy of the Jacobian values, "
-                                              + ("every linear answer judged on the FP64 residual of the FP64 matrix; " if qb == 4 else
+                                              + ("every linear answer asked for below 1e-3 judged on the FP64 residual of the FP64 matrix, looser ones "
+                                                 "too unless the last verified cycle had recurrence and truth within 1 % of the request "
+                                                 f"({int(tm['verdicts_skipped'])} of {int(tm['krylov_solves'])} solves) - Newton's FP64 residual follows; " if qb == 4 else
                                                  "iterations on the FP64 matrix, answers re-judged on b - A x when asked below 1e-8 or when the "
                                                  "kept pairs are at risk (full store, long or stalled cycle, earlier mismatch); ") + "preconditioner "
                                               "sweeps: " + ("FP16" if fp16 else "FP32") + " matrix values, FP32 vectors (Schur: "
@@ -335,7 +337,8 @@ def main():
             "phase_calls": {k: tm[k] for k in ("residual_calls", "jacobian_calls", "factor_calls", "spmv_calls", "precond_calls",
                                                "krylov_solves", "krylov_iters", "inner_vv_iters", "inner_schur_iters", "inner_dd_iters",
                                                "ortho_q_launches", "ortho_q_cols", "ortho_z_launches", "ortho_z_cols")},
-            "solver_events": {k: int(tm[k]) for k in ("gcr_arnoldi_steps", "gcr_restarts", "newton_retries", "fp32_fallbacks")},
+            "solver_events": {k: int(tm[k]) for k in ("gcr_arnoldi_steps", "gcr_restarts", "newton_retries", "fp32_fallbacks", "verdicts_skipped",
+                                                        "reorth_forced")},
             "setup_s": setup_s,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": d["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,

@@ -267,6 +267,9 @@ typedef struct FsiTimers {
   int64_t newton_retries;                            /* Newton iterations whose solve failed on a stale Jacobian and succeeded
                                                         after a refresh                                                      */
   int64_t fp32_fallbacks;                            /* Jacobian lifetimes that lost the FP32 basis and finished in FP64      */
+  int64_t verdicts_skipped;                          /* FP32 basis: loose answers (>= 1e-3) returned on the recurrence residual */
+  int64_t reorth_forced;                             /* second Gram-Schmidt passes made because the first one showed the kept
+                                                        columns non-orthonormal                                              */
 } FsiTimers;
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
 /* Measurement aid: streams `bytes` of the (idle) Krylov store once per kernel with 4-, 8-, 16- and 32-byte loads and

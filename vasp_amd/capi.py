@@ -68,7 +68,8 @@ class FsiTimers(C.Structure):
                 ("schur_elem_bytes", C.c_int64), ("spmv_compact", C.c_int64), ("node_pairs", C.c_int64),
                 ("node_vertex_pairs", C.c_int64), ("spmv_fp32_calls", C.c_int64), ("sweep_flags", C.c_int64), ("part_allreduces", C.c_int64),
                 ("assembly_colours", C.c_int64), ("gcr_arnoldi_steps", C.c_int64), ("gcr_restarts", C.c_int64),
-                ("newton_retries", C.c_int64), ("fp32_fallbacks", C.c_int64)]
+                ("newton_retries", C.c_int64), ("fp32_fallbacks", C.c_int64), ("verdicts_skipped", C.c_int64),
+                ("reorth_forced", C.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

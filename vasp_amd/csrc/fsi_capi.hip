@@ -744,6 +744,7 @@ int spmv(FsiCtx* ctx, const double* x, double* y, bool working = false) {
 // coefficients and the update, fsi_gcr.hip) and the host reads two small results; P is touched once per solve.
 void gcr_reset(FsiCtx* ctx) {
   ctx->gs_rtol = 0.0;
+  ctx->f32_last_drift = -1.0;                // no verified cycle yet on this store
   ctx->f64_suspect = false;                  // the pairs that were suspected are gone
   std::fill(ctx->hot_slots.begin(), ctx->hot_slots.end(), -1);
   ctx->hot_next = 0;
@@ -1421,13 +1422,21 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
     }
     const bool final_cycle = target <= rtol * bnorm * (1.0 + 1e-12);
     if (final_cycle && rtol >= 1e-4 && !ctx->op32_ok) break;
-    // Not skipped for loose answers either (measured, round 3): on the bench workload a solve asked for 1e-3 .. 1e-2 has
-    // recurrence and truth equal to four digits and the verdict's FP64 product is 2 % of a step - but the kept pairs are
-    // A p = q only to the accuracy of the FP32 operator they were made with, (A - A32) p, and a direction whose image is tiny
-    // has a huge p: on the avf problem at dt = 1e-4 a solve that reported 1e-2 had a true residual of 1.7 |b|, right after a
-    // verified solve whose recurrence and truth agreed to 3e-10.  The verdict is what makes the FP32 copies safe.
+    // A loose answer (the later Newton iterations of a step ask for 1e-3 .. 1e-2; 38 of the bench's 58 solves, 2.65 ms of FP64
+    // product each): recurrence and truth agree to three digits and better there (every FP32 cycle of the bench and of the avf
+    // runs, once the kept columns stay orthonormal - the first attempt at this skip met a solve that reported 1e-2 with a
+    // true residual of 1.7 |b|: duplicate columns, see the orthogonality criterion in gcr_cycle), and the next thing that
+    // happens is Newton's assembly of the FP64 residual from the updated state, the judge of the step either way.  Skipped
+    // only while the LAST VERIFIED cycle on this store found recurrence and truth closer than 1 % of what is asked now, the
+    // new directions all sat in the exact FP64 window and nothing stagnated.
+    if (final_cycle && rtol >= ctx->f32_verdict_skip_rtol && rnorm <= rtol * bnorm && *iters - its0 <= 32 && !ctx->gcr_stagnated &&
+        ctx->f32_last_drift >= 0.0 && ctx->f32_last_drift <= 0.01 * rtol) {
+      ctx->verdicts_skipped += 1;
+      break;
+    }
     const double rec32 = rnorm;
     FSICHK(true_residual());
+    ctx->f32_last_drift = std::fabs(rnorm - rec32) / bnorm;
     if (getenv("FSI_DEBUG_TRUERES"))
       fprintf(stderr, "[gcr]   fp32 cycle %d: recurrence |r|/|b| %.3e (target %.3e), true %.3e, rtol %.1e, its %d\n", cyc, rec32 / bnorm, target / bnorm, rnorm / bnorm, rtol, *iters);
     if (rnorm <= rtol * bnorm) break;
@@ -2777,6 +2786,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   if (getenv("FSI_NEWTON_FORCING")) ctx->newton_forcing = atof(getenv("FSI_NEWTON_FORCING"));
   if (getenv("FSI_GCR_REORTH")) ctx->gcr_reorth = atof(getenv("FSI_GCR_REORTH"));
   if (getenv("FSI_F32_CYCLE_FLOOR")) ctx->f32_cycle_floor = atof(getenv("FSI_F32_CYCLE_FLOOR"));
+  if (getenv("FSI_F32_VERDICT_SKIP")) ctx->f32_verdict_skip_rtol = atof(getenv("FSI_F32_VERDICT_SKIP"));      // 1: never skip
   if (getenv("FSI_ORTH_FLOOR32")) ctx->orth_floor32 = atof(getenv("FSI_ORTH_FLOOR32"));
   if (getenv("FSI_ORTH_FLOOR64")) ctx->orth_floor64 = atof(getenv("FSI_ORTH_FLOOR64"));
   if (getenv("FSI_GCR_ESCAPE")) ctx->gcr_escape = atof(getenv("FSI_GCR_ESCAPE"));      // 0: never leave the residual-based directions
@@ -3425,7 +3435,7 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
                              (ctx->solid_fp32 ? 4 : 0) | (ctx->solid_fp32 && ctx->solid_block_jacobi && ctx->solid_fused ? 8 : 0) |
                              (ctx->sbmg_ready ? 16 : 0) | (ctx->mg_ready ? 32 : 0) | (ctx->l3.ready ? 64 : 0)),
                    ctx->part_allreduces, (int64_t)ctx->ncellcol, ctx->gcr_arnoldi_steps, ctx->gcr_restarts, ctx->newton_retries,
-                   (int64_t)ctx->kry_fp32_failures_total};
+                   (int64_t)ctx->kry_fp32_failures_total, ctx->verdicts_skipped, ctx->gcr_reorth_forced};
   if (reset) {
     for (PhaseTimer* t : {&ctx->t_res, &ctx->t_jac, &ctx->t_fac, &ctx->t_spmv, &ctx->t_prec, &ctx->t_ortho, &ctx->t_flush, &ctx->t_sch, &ctx->t_kry, &ctx->t_ss, &ctx->t_db, &ctx->t_sc}) {
       t->ms = 0.0;
@@ -3438,6 +3448,7 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
     ctx->ortho_q_cols = ctx->ortho_q_launches = ctx->ortho_z_cols = ctx->ortho_z_launches = 0;
     ctx->part_allreduces = 0;
     ctx->gcr_arnoldi_steps = ctx->gcr_restarts = ctx->newton_retries = ctx->kry_fp32_failures_total = 0;
+    ctx->verdicts_skipped = ctx->gcr_reorth_forced = 0;
     ctx->sample_budget = 16;      // the sweep kernels of the next 16 preconditioner applications are sampled with events
   }
   return FSI_OK;

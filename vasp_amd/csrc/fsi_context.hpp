@@ -317,6 +317,9 @@ struct FsiCtx {
   bool gcr_stagnated = false;                // the last cycle ended on 40 iterations without a 10 % gain
   bool gcr_stalled = false;                  // ... on 80 iterations without a 10 % gain far from its target (truncated recurrence stuck)
   double f32_cycle_floor = 1e-6;             // FP32 basis: a cycle reduces the residual by at most this factor before the FP64 verdict
+  double f32_verdict_skip_rtol = 1e-3;       // FP32 basis: answers asked for at or above this may skip the FP64 verdict (see solve_gcr)
+  double f32_last_drift = -1.0;              // |true - recurrence residual| / |b| of the last verified FP32 cycle on the present store
+  int64_t verdicts_skipped = 0;
   bool f64_suspect = false;                  // FP64 basis: a verdict of the present store differed from its recurrence (see solve_gcr)
   int64_t newton_retries = 0;                // Newton iterations whose linear solve failed on a stale Jacobian and succeeded after a refresh
   double orth_floor32 = 3e-7, orth_floor64 = 1e-9;   // estimated orthogonality error of a new column above which a second Gram-Schmidt pass is made
