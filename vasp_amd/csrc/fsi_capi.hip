@@ -346,7 +346,13 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         // two-level cycle (see the displacement block): smoothing on [lmax/alpha, lmax], coarse solve on the solid vertices
         const double slmin = lmax / ctx->sbmg_alpha, sth = 0.5 * (lmax + slmin), sde = 0.5 * (lmax - slmin), ssig = sth / sde;
         double srho = 1.0 / ssig;
-        launch_cheb_init_b3(st, ctx->nS, frhs, ctx->sb_binv12.p, (float)(1.0 / sth), fx, fr, fd);
+        // FSI_CHEB4 bit 0: the smoothing sweeps as Chebyshev polynomials of the 4th kind (Lottes 2022: the smoother that
+        // minimises the two-level bound for a given degree; needs lmax only):  d_0 = 4/(3 lmax) B^-1 r,
+        // d_i = (2i-1)/(2i+3) d_{i-1} + (8i+4)/((2i+3) lmax) B^-1 r_i
+        const bool s4 = (ctx->cheb4 & 1) != 0;
+        const double sinit = s4 ? 4.0 / (3.0 * lmax) : 1.0 / sth;
+        auto s4c = [&](int i, float* c1, float* c2) { *c1 = (float)((2.0 * i - 1.0) / (2.0 * i + 3.0)); *c2 = (float)((8.0 * i + 4.0) / ((2.0 * i + 3.0) * lmax)); };
+        launch_cheb_init_b3(st, ctx->nS, frhs, ctx->sb_binv12.p, (float)sinit, fx, fr, fd);
         auto sweep = [&](float c1, float c2, int sample) {
           const bool timed = ctx->sample_budget > 0 && sample >= 0 && sample < 8 && ctx->ss_ev0[0];
           if (timed) (void)hipEventRecord(ctx->ss_ev0[sample], st);
@@ -358,6 +364,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
           std::swap(dcur, dnext);
         };
         for (int k = 0; k < ctx->sbmg_pre; ++k) {
+          if (s4) { float c1, c2; s4c(k + 1, &c1, &c2); sweep(c1, c2, k); continue; }
           const double rn = 1.0 / (2.0 * ssig - srho);
           sweep((float)(rn * srho), (float)(2.0 * rn / sde), k);
           srho = rn;
@@ -411,9 +418,10 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
           }
         }
         launch_sbmg_prolong(st, ctx->nS, ctx->sbmg_par.p, ctx->sbmg_pw.p, ctx->sbmg_flag.p, cx, dcur);   // correction as the next direction
-        sweep(0.f, (float)(1.0 / sth), -1);                    // x += P x_c, r -= A P x_c, restart the recurrence
+        sweep(0.f, (float)sinit, -1);                          // x += P x_c, r -= A P x_c, restart the recurrence
         srho = 1.0 / ssig;
         for (int k = 0; k < ctx->sbmg_post; ++k) {
+          if (s4) { float c1, c2; s4c(k + 1, &c1, &c2); sweep(c1, c2, -1); continue; }
           const double rn = 1.0 / (2.0 * ssig - srho);
           sweep((float)(rn * srho), (float)(2.0 * rn / sde), -1);
           srho = rn;
@@ -598,8 +606,12 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         // two-level cycle: Chebyshev smoothing on [lmax/alpha, lmax], coarse solve on the vertex graph, smoothing again
         const double slmin = lmax / ctx->mg_alpha, sth = 0.5 * (lmax + slmin), sde = 0.5 * (lmax - slmin), ssig = sth / sde;
         double srho = 1.0 / ssig;
-        launch_cheb_init_f32(st, n, frhs, ctx->ones32.p, (float)(1.0 / sth), fx, fr, fd);
+        const bool d4 = (ctx->cheb4 & 2) != 0;                 // FSI_CHEB4 bit 1: 4th-kind smoothing sweeps (see the solid block)
+        const double dinit = d4 ? 4.0 / (3.0 * lmax) : 1.0 / sth;
+        auto d4c = [&](int i, float* c1, float* c2) { *c1 = (float)((2.0 * i - 1.0) / (2.0 * i + 3.0)); *c2 = (float)((8.0 * i + 4.0) / ((2.0 * i + 3.0) * lmax)); };
+        launch_cheb_init_f32(st, n, frhs, ctx->ones32.p, (float)dinit, fx, fr, fd);
         for (int k = 0; k < ctx->mg_pre; ++k) {
+          if (d4) { float c1, c2; d4c(k + 1, &c1, &c2); fine_sweep(c1, c2, k); continue; }
           const double rn = 1.0 / (2.0 * ssig - srho);
           fine_sweep((float)(rn * srho), (float)(2.0 * rn / sde), k);
           srho = rn;
@@ -626,9 +638,10 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
           }
         }
         launch_mg_prolong(st, N2, ctx->mg_par.p, ctx->mg_pw.p, ctx->mg_d0.p, cx, dcur);   // correction as the next direction
-        fine_sweep(0.f, (float)(1.0 / sth), -1);                                       // x += P x_c, r -= C P x_c, restart
+        fine_sweep(0.f, (float)dinit, -1);                                             // x += P x_c, r -= C P x_c, restart
         srho = 1.0 / ssig;
         for (int k = 0; k < ctx->mg_post; ++k) {
+          if (d4) { float c1, c2; d4c(k + 1, &c1, &c2); fine_sweep(c1, c2, -1); continue; }
           const double rn = 1.0 / (2.0 * ssig - srho);
           fine_sweep((float)(rn * srho), (float)(2.0 * rn / sde), -1);
           srho = rn;
@@ -2785,6 +2798,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   ctx->debug_prec_apply = (getenv("FSI_DEBUG_PRECOND") && atoi(getenv("FSI_DEBUG_PRECOND")) >= 2) ? 12 : 0;
   if (getenv("FSI_NEWTON_FORCING")) ctx->newton_forcing = atof(getenv("FSI_NEWTON_FORCING"));
   if (getenv("FSI_GCR_REORTH")) ctx->gcr_reorth = atof(getenv("FSI_GCR_REORTH"));
+  if (getenv("FSI_CHEB4")) ctx->cheb4 = atoi(getenv("FSI_CHEB4"));
   if (getenv("FSI_F32_CYCLE_FLOOR")) ctx->f32_cycle_floor = atof(getenv("FSI_F32_CYCLE_FLOOR"));
   if (getenv("FSI_F32_VERDICT_SKIP")) ctx->f32_verdict_skip_rtol = atof(getenv("FSI_F32_VERDICT_SKIP"));      // 1: never skip
   if (getenv("FSI_ORTH_FLOOR32")) ctx->orth_floor32 = atof(getenv("FSI_ORTH_FLOOR32"));

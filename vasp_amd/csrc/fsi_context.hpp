@@ -324,6 +324,8 @@ struct FsiCtx {
   int64_t newton_retries = 0;                // Newton iterations whose linear solve failed on a stale Jacobian and succeeded after a refresh
   double orth_floor32 = 3e-7, orth_floor64 = 1e-9;   // estimated orthogonality error of a new column above which a second Gram-Schmidt pass is made
   int64_t gcr_reorth_forced = 0;
+  int cheb4 = 1;                             // bit 0 / 1: 4th-kind Chebyshev smoothing sweeps in the solid / displacement two-level cycle
+                                             // (scan in DESIGN.md section 5: solid -1.4 % of a step at the same 16 + 16 sweeps, displacement worse)
   double gcr_escape = 1e-3;                  // alpha^2 <= this * |r|^2: the direction did not move the residual, next one from q
   int64_t kry_fp32_failures_total = 0;       // fall-backs from the FP32 basis since the timers were reset
   int64_t gcr_arnoldi_steps = 0;             // directions made from the last q because the residual had not moved (see gcr_cycle)
