@@ -790,3 +790,28 @@ def test_reproducible_assembly_equals_the_atomic_one_to_roundoff(tmp_path, monke
         hb.close()
     for k in range(2):
         assert np.abs(out["default"][k] - out["atomic"][k]).max() <= 1e-13 * np.abs(out["atomic"][k]).max()
+
+
+def test_kept_basis_stays_orthonormal_on_the_avf_problem(tmp_path):
+    """Regression for the loss of orthogonality of the recycled Krylov basis: 25 steps of the avf
+    problem file (dt = 1e-4, two Jacobian lifetimes and a half) with the production tolerances.  With the second
+    Gram-Schmidt pass decided by the tolerance alone (round 2) this run needed 807 Krylov iterations, 117 Arnoldi steps out
+    of stagnant residuals and lost the FP32 basis once; with the criterion the pass itself supplies: 605, none, none."""
+    from conftest import make_avf_case
+    from vasp_amd.capi import HipBackend
+    case = make_avf_case(tmp_path)
+    ns, desc = case[0], case[1]
+    hb = HipBackend(desc)
+    krylov = 0
+    for k in range(25):
+        g, P = boundary_data(case, 1e-4 * (k + 1))
+        hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+        hist = hb.newton_solve(counter=k, first_step_num=0, atol=ns["atol"], rtol=ns["rtol"], max_it=50, lmbda=1.0,
+                               recompute=ns["recompute"], recompute_tstep=ns["recompute_tstep"])
+        assert hist[-1][0] < ns["atol"] or hist[-1][1] < ns["rtol"]
+        krylov += sum(h[3] for h in hist)
+        hb.shift()
+    tm = hb.timers()
+    hb.close()
+    assert tm["fp32_fallbacks"] == 0 and tm["gcr_restarts"] == 0 and tm["newton_retries"] == 0
+    assert tm["gcr_arnoldi_steps"] <= 10 and krylov <= 700, (tm["gcr_arnoldi_steps"], krylov)
