@@ -95,6 +95,8 @@ def main():
                     help="fp64: every storage-precision choice off (FP64 Krylov basis, FP64 Jacobian in every product, FP64 "
                          "Schur sweeps, FP32 instead of FP16 sweep matrices) - BASELINE.json configs[1] read literally")
     ap.add_argument("--no-fp64-line", action="store_true", help="skip the second run that fills value_fp64_storage")
+    ap.add_argument("--profile-host", action="store_true", help="wall time of pre_solve / boundary data / Newton solve / shift / "
+                                                                "post_solve per step in the JSON line (host_ms_per_step)")
     args = ap.parse_args()
     if args.storage == "fp64":           # read by fsi_create (getenv), so set before the library is touched
         os.environ.update(FP64_STORAGE_ENV)
@@ -155,6 +157,8 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    if args.profile_host:
+        ns["_profile"] = {}
     hb.timers(reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -340,6 +344,7 @@ def main():
             "solver_events": {k: int(tm[k]) for k in ("gcr_arnoldi_steps", "gcr_restarts", "newton_retries", "fp32_fallbacks", "verdicts_skipped",
                                                         "reorth_forced")},
             "setup_s": setup_s,
+            "host_ms_per_step": ({k: 1e3 * v / args.steps for k, v in ns["_profile"].items()} if args.profile_host else None),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": d["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
                          "launches": d["launches"],

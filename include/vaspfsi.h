@@ -162,13 +162,17 @@ int fsi_set_partition(FsiCtx* ctx, int64_t num_owned_cells, int64_t n_ghost, con
                       int64_t n_identity, const int64_t* identity_dofs, int64_t n_send, const int64_t* send_dofs,
                       double* sendbuf_dev, double* recvbuf_dev, const FsiComm* comm);
 
-/* Collectives issued by the library itself (VASPFSI_RCCL=1 in vasp_amd/partition.py): after fsi_set_partition, hand the
+/* Collectives issued by the library itself (the default of vasp_amd/partition.py on the nccl backend with more than one
+ * rank; VASPFSI_RCCL=0 keeps the callbacks): after fsi_set_partition, hand the
  * library an RCCL communicator and it queues ncclAllReduce (Krylov coefficient vectors in device memory) and grouped
  * ncclSend / ncclRecv (halo) on its solver stream; the FsiComm callbacks are then no longer called.  Counterpart of the MPI
  * reductions inside the reference's solver run [REF docs/simulation.md:14-32; simulation_common.py:217-220].
  * fsi_rccl_unique_id: 128 bytes from ncclGetUniqueId, made by one rank and broadcast by the caller.  send_counts[p] /
  * recv_counts[p]: doubles exchanged with rank p, in the order of the partition's send / ghost lists (peers ascending).
- * RCCL is resolved with dlopen at the first call; FSI_ERR_DEVICE if it is not available. */
+ * RCCL is resolved with dlopen at the first call; FSI_ERR_DEVICE if it is not available.  id128 == NULL: destroy the
+ * library's communicator and return to the FsiComm callbacks (what the caller does when any rank failed to set it up).
+ * A RCCL call that fails later aborts the communicator (ncclCommAbort) and every further collective of the context returns
+ * FSI_ERR_DEVICE at once, so that no rank waits for one that has left. */
 int fsi_rccl_unique_id(void* id128);
 int fsi_set_rccl(FsiCtx* ctx, const void* id128, int32_t rank, int32_t world, const int64_t* send_counts,
                  const int64_t* recv_counts);
@@ -270,6 +274,9 @@ typedef struct FsiTimers {
   int64_t verdicts_skipped;                          /* FP32 basis: loose answers (>= 1e-3) returned on the recurrence residual */
   int64_t reorth_forced;                             /* second Gram-Schmidt passes made because the first one showed the kept
                                                         columns non-orthonormal                                              */
+  int64_t dd_cache_hits;                             /* Jacobian refreshes that found the displacement block unchanged (three
+                                                        checksums) and kept its coarse operator and eigenvalue estimate      */
+  int64_t newton_late_solves;                        /* Newton iterations solved with the late (tighter) forcing term        */
 } FsiTimers;
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
 /* Measurement aid: streams `bytes` of the (idle) Krylov store once per kernel with 4-, 8-, 16- and 32-byte loads and

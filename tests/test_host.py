@@ -303,6 +303,29 @@ def test_host_state_is_fetched_only_when_a_hook_reads_it(tmp_path):
     assert calls.count("n") <= 1 and "n-1" not in calls          # only the checkpoint / frame of step 0 reads the vector
 
 
+def test_solver_events_show_up_in_the_product_log(tmp_path):
+    """a refresh-and-retry after a failed linear solve (a policy the reference does not have) must be
+    visible to a user of `python -m vasp_amd.monolithic`, not only in bench.py: the driver prints the library's event
+    counters whenever one of them has grown during a step - and nothing when they stay at zero."""
+    from vasp_amd import monolithic
+
+    class Eventful(_StubBackend):
+        def timers(self, reset=False):
+            return dict(newton_retries=1 if self.steps >= 2 else 0, fp32_fallbacks=0, gcr_restarts=0, krylov_iters=7)
+
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ns = monolithic.run(["-p", "cylinder", "-dt", "0.001", "-T", "0.003", "--theta", "0.51", "--folder", str(tmp_path), "--sub-folder",
+                             "1", "--new-arguments", f"mesh_path={GOLDEN / 'cylinder' / 'cylinder.h5'}"],
+                            backend_factory=Eventful, out=print)
+    out = buf.getvalue()
+    assert out.count("Linear solver events so far: newton_retries = 1, fp32_fallbacks = 0, gcr_restarts = 0") == 1
+    assert out.index("Linear solver events") > out.index("Solved for timestep 1,")          # raised in step 2, reported once
+    assert ns["solver_events"]["newton_retries"] == 1
+    _, quiet = _run_cylinder(tmp_path / "q", T="0.002")                                        # a backend without timers: no line
+    assert "Linear solver events" not in quiet
+
+
 def test_config_file_is_read_and_the_command_line_wins(tmp_path):
     """`turtleFSI -p problem -c my_config.config` [REF docs/simulation.md:19-31]: `key = value` lines, option names without
     their dashes or problem-file parameters; precedence file < command line, as ConfigArgParse gives turtleFSI."""
@@ -315,3 +338,11 @@ def test_config_file_is_read_and_the_command_line_wins(tmp_path):
     assert a["mesh_path"] == "some/mesh.h5" and a["fsi_region"] == [0.0, 1.0, 2.0, 3.5] and "config" not in a
     b = parse(["-p", "cylinder", "-c", str(cfg), "-dt", "0.01", "--new-arguments", "mesh_path=other.h5"])
     assert b["dt"] == 0.01 and b["T"] == 0.5 and b["mesh_path"] == "other.h5"
+    # the file may name the problem (the command line's -p wins, its absence does not), and a `#` / `;` inside a
+    # value - a path - belongs to the value
+    cfg2 = tmp_path / "p.config"
+    cfg2.write_text("problem = aneurysm\nmesh_path = /data/run#3/mesh;v2.h5  # trailing comment\n; another comment\n")
+    c = parse(["-c", str(cfg2)])
+    assert c["problem"] == "aneurysm" and c["mesh_path"] == "/data/run#3/mesh;v2.h5"
+    assert parse(["-c", str(cfg2), "-p", "avf"])["problem"] == "avf"
+    assert parse([])["problem"] == "offset_stenosis"

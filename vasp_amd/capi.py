@@ -69,7 +69,7 @@ class FsiTimers(C.Structure):
                 ("node_vertex_pairs", C.c_int64), ("spmv_fp32_calls", C.c_int64), ("sweep_flags", C.c_int64), ("part_allreduces", C.c_int64),
                 ("assembly_colours", C.c_int64), ("gcr_arnoldi_steps", C.c_int64), ("gcr_restarts", C.c_int64),
                 ("newton_retries", C.c_int64), ("fp32_fallbacks", C.c_int64), ("verdicts_skipped", C.c_int64),
-                ("reorth_forced", C.c_int64)]
+                ("reorth_forced", C.c_int64), ("dd_cache_hits", C.c_int64), ("newton_late_solves", C.c_int64)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -129,6 +129,8 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_flow_stats.argtypes = [vp, vp]
     lib.fsi_set_chebyshev.argtypes = [vp, i32, dbl, i32, dbl, i32, dbl, i32, dbl]
     lib.fsi_set_partition.argtypes = [vp, i64, i64, vp, i64, vp, i64, vp, vp, vp, vp]
+    lib.fsi_rccl_unique_id.argtypes = [vp]
+    lib.fsi_set_rccl.argtypes = [vp, C.c_char_p, i32, i32, vp, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("fsi_last_error", "fsi_num_dofs", "fsi_matrix_nnz"):

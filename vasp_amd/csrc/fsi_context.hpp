@@ -183,6 +183,7 @@ struct FsiCtx {
   int64_t halo_calls = 0, allreduce_calls = 0;
   // library-side RCCL transport (fsi_set_rccl, fsi_rccl.hip): communicator, per-peer halo counts (doubles), staging buffer
   bool rccl = false;
+  bool rccl_dead = false;                    // a RCCL call failed and the communicator was aborted: every later collective fails at once
   void* rccl_comm = nullptr;
   int rccl_rank = 0, rccl_world = 1;
   std::vector<int64_t> rccl_send, rccl_recv;
@@ -320,6 +321,7 @@ struct FsiCtx {
   double f32_verdict_skip_rtol = 1e-3;       // FP32 basis: answers asked for at or above this may skip the FP64 verdict (see solve_gcr)
   double f32_last_drift = -1.0;              // |true - recurrence residual| / |b| of the last verified FP32 cycle on the present store
   int64_t verdicts_skipped = 0;
+  bool in_newton = false;                    // the running fsi_solve was called by fsi_newton_solve (an FP64 Newton residual follows)
   bool f64_suspect = false;                  // FP64 basis: a verdict of the present store differed from its recurrence (see solve_gcr)
   int64_t newton_retries = 0;                // Newton iterations whose linear solve failed on a stale Jacobian and succeeded after a refresh
   double orth_floor32 = 3e-7, orth_floor64 = 1e-9;   // estimated orthogonality error of a new column above which a second Gram-Schmidt pass is made
@@ -341,7 +343,8 @@ struct FsiCtx {
   float sbmg_gersh = 2.f, mg_gersh = 2.f;     // the row-sum bounds of the two coarse levels (fallback of the self-test)
   int coarse_power = 1;                      // FSI_COARSE_POWER=0: coarse levels' Chebyshev intervals end at the Gershgorin bound (round 2)
   bool dd_same = false, dd_checksum_valid = false;   // this refresh found the displacement block unchanged / a checksum exists
-  double lmax_d_cached = 0.0, dd_checksum = 0.0;   // largest eigenvalue of the (constant) displacement block, and what it was computed for
+  int64_t dd_cache_hits = 0;                 // refreshes that kept the displacement block's coarse operator and eigenvalue estimate
+  double lmax_d_cached = 0.0, dd_checksum[3] = {0.0, 0.0, 0.0};   // largest eigenvalue of the (constant) displacement block, and what it was computed for
   // Compression of the kept Krylov space (FSI_KRYLOV_COMPRESS="soft:keep", off by default): when more
   // than `soft` directions are kept at the end of a solve they are replaced by `keep` combinations - the part of the space
   // on which the preconditioned operator B = A M^-1 deviates most from the identity (dominant right singular vectors of
@@ -359,6 +362,10 @@ struct FsiCtx {
   int kry_fp32_failures = 0;                 // cycles that lost the system in FP32 storage (policy 2 -> 3); two of them pin FP64
   double tol_hint = 0.0, bnorm_max = 0.0;     // fsi_newton_solve -> solve_gcr: lowest linear tolerance to expect; largest |b| seen
   double gcr_reorth = 0.0;                   // FSI_GCR_REORTH: second Gram-Schmidt pass when |w'| < reorth |w| (0: automatic)
+  double newton_forcing_late = 0.0;          // > 0 and < newton_forcing: forcing term of late Newton iterations (see fsi_newton_solve)
+  double newton_late_factor = 10.0;          // "late": the previous update norm (or |b|) is within this factor of its tolerance
+  int64_t newton_late_solves = 0;
+  int vel_jacobi = 0;                        // FSI_VEL_JACOBI=1: no solid -> fluid coupling inside the velocity predictor (measurement)
   double newton_forcing = 1e-2;              // inexact Newton: linear tolerance = forcing * atol / |b| (FSI_NEWTON_FORCING; 1e-2: same Newton counts as 1e-3 on the bench, 18 % fewer Krylov iterations)
 
   // timers

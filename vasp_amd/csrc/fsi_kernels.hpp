@@ -159,6 +159,7 @@ void launch_spmv(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t
                  const double* x, double* y, int tag = SPMV_FIELD_BLOCK);
 // reductions: out[0] = x.y (deterministic two-stage); scratch must hold >= 4096 doubles
 void launch_dot(hipStream_t st, const double* x, const double* y, int64_t n, double* scratch, double* out);
+void launch_hashed_sum(hipStream_t st, const double* x, int64_t first, int64_t stride, int64_t n, double* scratch, double* out);
 // known-byte read / write streams (4, 8, 16, 32 bytes per lane) over buf[0, bytes): PMC counter calibration
 void launch_calibration(hipStream_t st, void* buf, int64_t bytes, double* out);
 // fsi_gcr.hip — orthogonalisation against the kept directions of the recycled GCR (Q in FP32 or FP64, see there)

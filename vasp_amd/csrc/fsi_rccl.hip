@@ -32,6 +32,7 @@ struct Api {
   NcclResult (*GetUniqueId)(NcclUniqueId*) = nullptr;
   NcclResult (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
   NcclResult (*CommDestroy)(NcclComm) = nullptr;
+  NcclResult (*CommAbort)(NcclComm) = nullptr;
   NcclResult (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
   NcclResult (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
   NcclResult (*Recv)(void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
@@ -62,6 +63,7 @@ Api& api() {
   a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
   a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
   a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+  a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(sym("ncclCommAbort"));
   a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
   a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
   a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
@@ -72,9 +74,20 @@ Api& api() {
   return a;
 }
 
+// A failed call leaves this rank outside a collective its peers may already be inside.  Returning alone would let them wait
+// for ever, so the communicator is aborted: ncclCommAbort tears the rank's connections down, which the peers'
+// pending operations see as a remote error instead of a silent stall, and every later call on this context fails at once
+// (ctx->rccl_dead) - the run ends with FSI_ERR_DEVICE on every rank rather than hanging on some.
 int fail(FsiCtx* ctx, const char* what, NcclResult r) {
   Api& a = api();
-  ctx->err = std::string("RCCL: ") + what + ": " + (a.GetErrorString ? a.GetErrorString(r) : "error") + " (code " + std::to_string(r) + ")";
+  ctx->err = std::string("RCCL: ") + what + ": " + (a.GetErrorString ? a.GetErrorString(r) : "error") + " (code " + std::to_string(r) +
+             "); the communicator was aborted";
+  if (ctx->rccl_comm && a.CommAbort) { (void)a.CommAbort(ctx->rccl_comm); ctx->rccl_comm = nullptr; }
+  ctx->rccl_dead = true;
+  return FSI_ERR_DEVICE;
+}
+int dead(FsiCtx* ctx) {
+  if (ctx->err.empty()) ctx->err = "RCCL: the communicator of this context was aborted after an earlier error";
   return FSI_ERR_DEVICE;
 }
 
@@ -119,17 +132,19 @@ int rccl_init(FsiCtx* ctx, const void* id128, int rank, int world, const int64_t
 }
 
 void rccl_destroy(FsiCtx* ctx) {
-  if (ctx->rccl_comm) {
+  if (ctx->rccl_comm && !ctx->rccl_dead) {
     (void)hipStreamSynchronize(ctx->stream);
     api().CommDestroy(ctx->rccl_comm);
   }
   ctx->rccl_comm = nullptr;
   ctx->rccl = false;
+  ctx->rccl_dead = false;
   ctx->rccl_red.release();
 }
 
 // in place, on the solver stream; n doubles in device memory
 int rccl_allreduce_dev(FsiCtx* ctx, double* dptr, int64_t n) {
+  if (ctx->rccl_dead) return dead(ctx);
   const NcclResult r = api().AllReduce(dptr, dptr, (size_t)n, kNcclFloat64, kNcclSum, ctx->rccl_comm, ctx->stream);
   if (r != 0) return fail(ctx, "ncclAllReduce", r);
   ctx->rccl_allreduces += 1;
@@ -151,12 +166,13 @@ int rccl_allreduce_host(FsiCtx* ctx, double* v, int n) {
 // over xGMI every neighbour pair has its own link, so the exchanges run side by side
 int rccl_halo(FsiCtx* ctx) {
   Api& a = api();
+  if (ctx->rccl_dead) return dead(ctx);
   NcclResult r = a.GroupStart();
   if (r != 0) return fail(ctx, "ncclGroupStart", r);
   int64_t so = 0, ro = 0;
   for (int p = 0; p < ctx->rccl_world; ++p) {
-    if (ctx->rccl_send[p] > 0) { r = a.Send(ctx->sendbuf + so, (size_t)ctx->rccl_send[p], kNcclFloat64, p, ctx->rccl_comm, ctx->stream); if (r != 0) { a.GroupEnd(); return fail(ctx, "ncclSend", r); } }
-    if (ctx->rccl_recv[p] > 0) { r = a.Recv(ctx->recvbuf + ro, (size_t)ctx->rccl_recv[p], kNcclFloat64, p, ctx->rccl_comm, ctx->stream); if (r != 0) { a.GroupEnd(); return fail(ctx, "ncclRecv", r); } }
+    if (ctx->rccl_send[p] > 0) { r = a.Send(ctx->sendbuf + so, (size_t)ctx->rccl_send[p], kNcclFloat64, p, ctx->rccl_comm, ctx->stream); if (r != 0) { (void)a.GroupEnd(); return fail(ctx, "ncclSend", r); } }
+    if (ctx->rccl_recv[p] > 0) { r = a.Recv(ctx->recvbuf + ro, (size_t)ctx->rccl_recv[p], kNcclFloat64, p, ctx->rccl_comm, ctx->stream); if (r != 0) { (void)a.GroupEnd(); return fail(ctx, "ncclRecv", r); } }
     so += ctx->rccl_send[p];
     ro += ctx->rccl_recv[p];
   }

@@ -539,6 +539,24 @@ __global__ __launch_bounds__(256) void k_sum_final(const double* __restrict__ pa
   s = block_sum(s);
   if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
+// sum_i x[first + i * stride] * w(i) with an index-dependent weight in [1, 2) (a multiplicative hash of i): unlike a sum
+// of squares this sees sign changes, permuted entries and, through the weights, which entry a change sits in
+__global__ __launch_bounds__(256) void k_hashed_sum_partial(const double* __restrict__ x, int64_t first, int64_t stride, int64_t n,
+                                                            double* __restrict__ part) {
+  double s = 0.0;
+  GRID_STRIDE(i, n) {
+    const uint32_t h = (uint32_t)((uint64_t)i * 0x9E3779B97F4A7C15ull >> 40);      // 24 bits
+    s += x[first + i * stride] * (1.0 + (double)h * (1.0 / 16777216.0));
+  }
+  s = block_sum(s);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+void launch_hashed_sum(hipStream_t st, const double* x, int64_t first, int64_t stride, int64_t n, double* scratch, double* out) {
+  int np = (int)grid_for(n);
+  if (np > 1024) np = 1024;
+  hipLaunchKernelGGL(k_hashed_sum_partial, dim3(np), dim3(256), 0, st, x, first, stride, n, scratch);
+  hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, st, scratch, np, np, out);
+}
 void launch_dot(hipStream_t st, const double* x, const double* y, int64_t n, double* scratch, double* out) {
   int np = (int)grid_for(n);
   if (np > 1024) np = 1024;

@@ -14,6 +14,7 @@ import ast
 import importlib
 import importlib.util
 import json
+import re
 import sys
 import time as _time
 from pathlib import Path
@@ -45,7 +46,7 @@ def _coerce(text: str):
 def parse(argv: Optional[List[str]] = None) -> Dict[str, object]:
     ap = argparse.ArgumentParser(prog="vaspfsi", description="MI355X-native monolithic ALE-FSI solver "
                                  "behind the turtleFSI problem-file API")
-    ap.add_argument("-p", "--problem", default="offset_stenosis")
+    ap.add_argument("-p", "--problem", default=None)       # "offset_stenosis" unless the command line or the -c file names one
     ap.add_argument("-dt", "--time-step", dest="dt", type=float, default=None)
     ap.add_argument("-T", "--end-time", dest="T", type=float, default=None)
     ap.add_argument("-t", "--theta", dest="theta", type=float, default=None)
@@ -73,7 +74,9 @@ def parse(argv: Optional[List[str]] = None) -> Dict[str, object]:
         names = {o.lstrip("-"): a.dest for a in ap._actions for o in a.option_strings}
         types = {a.dest: a.type for a in ap._actions}
         for raw in Path(ns.config).read_text().splitlines():
-            line = raw.split("#", 1)[0].split(";", 1)[0].strip()
+            # comments: a line that starts with # or ;, or the rest of a line after whitespace + # / ; (a `#` or `;` inside a
+            # value - a path, say - belongs to the value, as in ConfigArgParse)
+            line = re.sub(r"(^|\s)[#;].*$", "", raw).strip()
             if not line or line.startswith("["):
                 continue
             for sep in ("=", ":", None):
@@ -94,6 +97,7 @@ def parse(argv: Optional[List[str]] = None) -> Dict[str, object]:
             raise SystemExit(f"--new-arguments expects key=value, got {kv!r}")
         k, v = kv.split("=", 1)
         out[k] = _coerce(v)
+    out.setdefault("problem", "offset_stenosis")
     return out
 
 
@@ -279,19 +283,30 @@ def advance(ns, backend, bc_values, pressure, hook, first_step_num: int, out=pri
     """One time step of the reference's loop body: ``t += dt``; ``pre_solve``; Dirichlet data and
     interface pressure to the device; the quasi-Newton solve behind the C-ABI; state shift; ``post_solve``.  File output
     and the step counter stay with the caller.  ``bench.py`` times exactly this function."""
+    prof = ns.get("_profile")             # bench.py --profile-host: wall time of the five parts of a step
+    tick = _time.perf_counter
+    t0 = tick()
     ns["t"] = ns["t"] + float(ns["dt"])
     upd = hook("pre_solve")(**ns)
     ns.update(upd or {})
+    t1 = tick()
     backend.set_dirichlet_values(bc_values())
     backend.set_interface_pressure(float(pressure.P) if pressure is not None else 0.0)
+    t2 = tick()
     hist = backend.newton_solve(counter=ns["counter"], first_step_num=first_step_num,
                                 log=out if ns["verbose"] else None,
                                 **{k: ns[k] for k in ("atol", "rtol", "max_it", "lmbda", "recompute", "recompute_tstep")})
+    t3 = tick()
     backend.shift()                       # dvp_["n-1"] <- dvp_["n"]
     for fn in ns["dvp_"].values():        # the host copies are refreshed only if somebody reads them
         fn.mark_stale()
+    t4 = tick()
     upd = hook("post_solve")(**ns)
     ns.update(upd or {})
+    if prof is not None:
+        for key, dt_ in (("pre_solve", t1 - t0), ("boundary_data", t2 - t1), ("newton_solve", t3 - t2), ("shift", t4 - t3),
+                         ("post_solve", tick() - t4)):
+            prof[key] = prof.get(key, 0.0) + dt_
     return hist
 
 
@@ -322,6 +337,22 @@ def stop_controls(results: Path, killtime, t_loop: float, agree=None, rank0: boo
     while agree([(results / "pauseturtle").exists()])[0]:
         _time.sleep(poll_s)
     return stop
+
+
+SOLVER_EVENT_KEYS = ("newton_retries", "fp32_fallbacks", "gcr_restarts")
+
+
+def solver_events(backend) -> Dict[str, int]:
+    """What the linear solver had to do beyond iterating, as the library counts it (FsiTimers): Newton iterations whose
+    solve failed on a stale Jacobian and succeeded after a refresh the reference's policy would not have made
+    (`newton_retries` - such an iteration is logged as "Compute Jacobian matrix"), Jacobian lifetimes that lost the FP32
+    Krylov basis (`fp32_fallbacks`), solves that dropped the recycled directions (`gcr_restarts`).  Empty for a backend
+    without timers (the oracle backend of the CPU tests)."""
+    timers = getattr(backend, "timers", None)
+    if timers is None:
+        return {}
+    tm = timers()
+    return {k: int(tm[k]) for k in SOLVER_EVENT_KEYS if k in tm}
 
 
 def _rank() -> int:
@@ -368,6 +399,7 @@ def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_ba
     results = Path(ns["results_folder"])
     total_newton = 0
     stop = False
+    events_seen: Dict[str, int] = {}
     t_loop = _time.perf_counter()
     while ns["t"] <= T + dt / 10 and not stop:
         t0 = _time.perf_counter()
@@ -387,11 +419,16 @@ def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_ba
         elif ns.get("save_step") and ns["counter"] % int(ns["save_step"]) == 0:
             ns["dvp_"]["n"].vector()              # partitioned: every rank takes part in the gather
         ns["counter"] += 1
+        ev = solver_events(backend)          # the silent refresh-and-retry is visible in the product log
+        if any(ev.get(k, 0) > events_seen.get(k, 0) for k in ev):
+            out("Linear solver events so far: " + ", ".join(f"{k} = {v}" for k, v in ev.items()))
+        events_seen = ev
         out("Solved for timestep %d, t = %.4f in %.1f s" % (ns["counter"], t, _time.perf_counter() - t0))
     if viz is not None:
         viz.close()
     ns["time_loop_seconds"] = _time.perf_counter() - t_loop
     ns["newton_iterations"] = total_newton
+    ns["solver_events"] = events_seen
     with quiet:
         hook("finished")(**ns)
     return ns

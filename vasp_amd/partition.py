@@ -305,24 +305,54 @@ class DistBackend:
                                                   C.c_void_p(self.sendbuf.data_ptr()), C.c_void_p(self.recvbuf.data_ptr()),
                                                   C.byref(self._comm)))
         self.history = self.hb.history
-        # VASPFSI_RCCL=1: the library issues the collectives itself on its solver stream (fsi_set_rccl): no callback, no
-        # host staging, no device synchronise per exchange.  Needs one rank per GPU (RCCL refuses two ranks on one device);
-        # the torch.distributed transport above stays the default.
+        # The library issues the collectives itself on its solver stream (fsi_set_rccl): no callback, no host staging, no
+        # device synchronise per exchange.  Default on the nccl backend with more than one rank (one rank per GPU: RCCL
+        # refuses two ranks on one device); VASPFSI_RCCL=0 keeps the torch.distributed callbacks above, =1 asks for the
+        # library's transport whatever the world size and raises if it cannot be had.  Every step of the set-up is agreed
+        # across the ranks (a rank that cannot load RCCL or fails in ncclCommInitRank takes all ranks back to the callbacks).
         self.library_rccl = False
-        if os.environ.get("VASPFSI_RCCL", "0") == "1":
-            if not self.on_gpu_wire:
-                raise RuntimeError("VASPFSI_RCCL=1 needs the nccl backend (one rank per GPU)")
-            ident = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if self.rank == 0:
-                buf = (C.c_char * 128)()
-                self.hb._check(self.lib.fsi_rccl_unique_id(buf))
+        want = os.environ.get("VASPFSI_RCCL", "auto")
+        if want == "1" and not self.on_gpu_wire:
+            raise RuntimeError("VASPFSI_RCCL=1 needs the nccl backend (one rank per GPU)")
+        if want == "1" or (want not in ("0", "off") and self.on_gpu_wire and self.world > 1):
+            self.library_rccl, why = self._setup_library_rccl()
+            if not self.library_rccl:
+                if want == "1":
+                    raise RuntimeError(f"VASPFSI_RCCL=1: {why}")
+                if self.rank == 0:
+                    print(f"vasp_amd.partition: library-side RCCL not available ({why}); collectives go through torch.distributed",
+                          flush=True)
+
+    def _setup_library_rccl(self):
+        """fsi_rccl_unique_id on rank 0 -> broadcast -> fsi_set_rccl on every rank, each step agreed over the process group.
+        Returns (ok, reason).  On any rank's failure every rank calls fsi_set_rccl(ctx, NULL, ...) and keeps the callbacks."""
+        from .capi import _ptr
+        torch, dist, p, dev = self.torch, self.dist, self.part, self.dev
+
+        def all_ok(flag: bool) -> bool:
+            t = torch.tensor([0.0 if flag else 1.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t)
+            return float(t.item()) == 0.0
+
+        ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+        ok = True
+        if self.rank == 0:
+            buf = (C.c_char * 128)()
+            ok = self.lib.fsi_rccl_unique_id(buf) == 0
+            if ok:
                 ident.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
-            dist.broadcast(ident, src=0)
-            raw = bytes(ident.cpu().numpy().tobytes())
-            sc = np.ascontiguousarray(p.send_counts, dtype=np.int64)
-            rc = np.ascontiguousarray(p.recv_counts, dtype=np.int64)
-            self.hb._check(self.lib.fsi_set_rccl(self.ctx, C.c_char_p(raw), self.rank, self.world, _ptr(sc), _ptr(rc)))
-            self.library_rccl = True
+        if not all_ok(ok):
+            return False, "librccl could not be loaded by the library (dlopen)"
+        dist.broadcast(ident, src=0)
+        raw = bytes(ident.cpu().numpy().tobytes())
+        sc = np.ascontiguousarray(p.send_counts, dtype=np.int64)
+        rc = np.ascontiguousarray(p.recv_counts, dtype=np.int64)
+        rcode = self.lib.fsi_set_rccl(self.ctx, C.c_char_p(raw), self.rank, self.world, _ptr(sc), _ptr(rc))
+        msg = self.lib.fsi_last_error(self.ctx).decode() if rcode != 0 else ""
+        if not all_ok(rcode == 0):
+            self.lib.fsi_set_rccl(self.ctx, None, self.rank, self.world, _ptr(sc), _ptr(rc))
+            return False, msg or "fsi_set_rccl failed on another rank"
+        return True, ""
 
     # ---- transport (called back from inside fsi_solve / fsi_newton_solve) ------------------------------------------
     def _allreduce(self, _user, vals, n):
