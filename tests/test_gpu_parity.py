@@ -127,7 +127,12 @@ def test_bicgstab_and_ilu0_solve_match_sparse_lu(cylinder_case, monkeypatch, lin
     hb.assemble_jacobian()
     o.solver_setup(np.zeros(o.ndof), np.zeros(o.ndof))
     A_ref, b_ref = o.jacobian(U, U1), o.rhs(U, U1, P, g)
-    it, rr = hb.solve(lin_rtol=1e-10, lin_max_it=3000)
+    from vasp_amd.capi import FsiError
+    try:
+        it, rr = hb.solve(lin_rtol=1e-10, lin_max_it=20000)
+    except FsiError as e:
+        hb.close()
+        pytest.fail(f"lin_solver {lin_solver} precond {precond}: {e}")
     print(f"lin_solver {lin_solver} precond {precond}: {it} iterations, relres {rr:.2e}")
     assert rr <= 1e-10
     du_ref = spla.splu(A_ref.tocsc()).solve(b_ref)

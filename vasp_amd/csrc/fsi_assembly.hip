@@ -557,6 +557,167 @@ __global__ __launch_bounds__(64, WAVES) void k_jacobian(ElemArrays ea, ElemParam
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Jacobian of F_nonlinear with the element contraction on the matrix pipe (BASELINE north_star: "MFMA only for the dense
+// per-element contractions").
+//
+// The v-equation rows of the element matrix are, per component i,  D_i[a][j] = sum_q sum_s T_q[a][s] S_q,i[s][j]:
+// test node a (10), trial column j (64), s = (value, 3 gradient slots), T_q[a] = (N_a, grad N_a) at point q and S the
+// weighted tangent of the flux along column j - a [10 x 96] x [96 x 64] product per component, 75 % of the flops of the
+// 64-row kernel of round 2 and 35 % of this one (rows 30..63 only).  On v_mfma_f64_16x16x4_f64 tiles: M = test nodes (10
+// of 16 rows), N = 16 columns per tile (four tiles), K = the four slots of one point: 12 MFMAs per point, 288 per cell, the
+// accumulators (12 tiles x 4 doubles per lane) live in the MFMA's own result registers.
+//   A operand: lane l holds T_q[a = l & 15][s = l >> 4]: one LDS read per point from sA[q][s][a] (the table the flux phase
+//              also takes its tangent seeds from).
+//   B operand of tile t: lane l needs S[s = l >> 4][column 16 t + (l & 15)], while the flux phase leaves column l's four
+//              slots in four registers of lane l: a 4 x 4 transpose between registers and the wave's four 16-lane rows,
+//              done in registers with gfx950's v_permlane32_swap / v_permlane16_swap (4 swaps per 32-bit half; no LDS).
+//   D: lane l holds rows (l >> 4) + 4 r, r = 0..3, of column 16 t + (l & 15): the scatter walks those.
+// The four pressure rows (one slot, K = 24) stay on the vector pipe.  tools/mfma_layout_check.hip checks both register maps
+// on the device; the parity tests compare the assembled matrix with the oracle's complex-step Jacobian entry by entry.
+// ---------------------------------------------------------------------------------------------------------
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+__device__ inline void lane_swap32(double& x, double& y) {      // rows 2, 3 of x <-> rows 0, 1 of y
+  const unsigned xl = __double2loint(x), xh = __double2hiint(x), yl = __double2loint(y), yh = __double2hiint(y);
+  const v2u_t lo = __builtin_amdgcn_permlane32_swap(xl, yl, false, false), hi = __builtin_amdgcn_permlane32_swap(xh, yh, false, false);
+  x = __hiloint2double(hi[0], lo[0]); y = __hiloint2double(hi[1], lo[1]);
+}
+__device__ inline void lane_swap16(double& x, double& y) {      // rows 1, 3 of x <-> rows 0, 2 of y
+  const unsigned xl = __double2loint(x), xh = __double2hiint(x), yl = __double2loint(y), yh = __double2hiint(y);
+  const v2u_t lo = __builtin_amdgcn_permlane16_swap(xl, yl, false, false), hi = __builtin_amdgcn_permlane16_swap(xh, yh, false, false);
+  x = __hiloint2double(hi[0], lo[0]); y = __hiloint2double(hi[1], lo[1]);
+}
+template <int WAVES>
+__global__ __launch_bounds__(64, WAVES) void k_jacobian_mfma(ElemArrays ea, ElemParams ep, const double* __restrict__ U,
+                                                             const double* __restrict__ U1, const int64_t* __restrict__ rowptr,
+                                                             const int64_t* __restrict__ nadj_ptr, double* __restrict__ vals,
+                                                             const int32_t* __restrict__ list) {
+  const int64_t c = list ? (int64_t)list[blockIdx.x] : (int64_t)blockIdx.x;
+  const int lane = threadIdx.x;
+  __shared__ double sU[NLOC], sU1[NLOC], sJ[10];
+  __shared__ double sA[NQ][4][10];       // (N, physical gradient) of the P2 basis at the quadrature points: [q][slot][node]
+  __shared__ double sB[NQ][25];          // base state at n: gd(9) gv(9) d(3) v(3) p
+  __shared__ double sO[NQ][25];          // state at n-1
+  __shared__ int64_t sRow[NLOC];
+  __shared__ int32_t sDeg6[10];
+  const int32_t dof = ea.cell_dofs[c * NLOC + lane];
+  sU[lane] = U[dof];
+  sU1[lane] = U1[dof];
+  sRow[lane] = rowptr[dof];
+  if (lane < 10) {
+    sJ[lane] = ea.geom[c * 10 + lane];
+    const int32_t rk = ea.cell_rank[c * 10 + lane];
+    sDeg6[lane] = 6 * (int32_t)(nadj_ptr[rk + 1] - nadj_ptr[rk]);
+  }
+  __syncthreads();
+  for (int t = lane; t < NQ * 10; t += 64) {
+    const int q = t / 10, a = t % 10;
+    sA[q][0][a] = c_N[q][a];
+    for (int j = 0; j < 3; ++j)
+      sA[q][1 + j][a] = c_dN[q][a][0] * sJ[j] + c_dN[q][a][1] * sJ[3 + j] + c_dN[q][a][2] * sJ[6 + j];
+  }
+  if (lane < NQ) {
+    Kin<double> s, o;
+    interpolate(sU, sJ, lane, s);
+    interpolate(sU1, sJ, lane, o);
+    double* B = sB[lane];
+    double* O = sO[lane];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        B[3 * i + j] = s.gd[i][j]; B[9 + 3 * i + j] = s.gv[i][j];
+        O[3 * i + j] = o.gd[i][j]; O[9 + 3 * i + j] = o.gv[i][j];
+      }
+    for (int i = 0; i < 3; ++i) { B[18 + i] = s.d[i]; B[21 + i] = s.v[i]; O[18 + i] = o.d[i]; O[21 + i] = o.v[i]; }
+    B[24] = s.p; O[24] = o.p;
+  }
+  __syncthreads();
+  const int kind = ea.cell_kind[c], region = ea.cell_region[c];
+  const int jf = lane < 60 ? lane / 30 : 2;          // trial dof of this lane: 0 d, 1 v, 2 p
+  const int jc = lane < 60 ? (lane % 30) / 10 : 0;
+  const int jb = lane < 60 ? lane % 10 : lane - 60;
+  // a solid cell's F_nonlinear depends on d alone: the other columns carry zeros through the product (the wave stays whole
+  // for the MFMAs) and are skipped by the scatter
+  const bool live = !(kind == 1 && jf != 0);
+  const int am = lane & 15, ak = lane >> 4;          // this lane's element of the A operand: node am, slot ak
+  v4d_t acc[3][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[i][t] = v4d_t{0.0, 0.0, 0.0, 0.0};
+  double accp[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int q = 0; q < NQ; ++q) {
+    Kin<Dual> s;
+    Kin<double> o;
+    const double* B = sB[q];
+    const double* O = sO[q];
+    const double seedN = sA[q][0][jb];
+    double seedG[3];
+    for (int j = 0; j < 3; ++j) seedG[j] = sA[q][1 + j][jb];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        s.gd[i][j] = Dual(B[3 * i + j], (jf == 0 && jc == i) ? seedG[j] : 0.0);
+        s.gv[i][j] = Dual(B[9 + 3 * i + j], (jf == 1 && jc == i) ? seedG[j] : 0.0);
+        o.gd[i][j] = O[3 * i + j];
+        o.gv[i][j] = O[9 + 3 * i + j];
+      }
+    for (int i = 0; i < 3; ++i) {
+      s.d[i] = Dual(B[18 + i], (jf == 0 && jc == i) ? seedN : 0.0);
+      s.v[i] = Dual(B[21 + i], (jf == 1 && jc == i) ? seedN : 0.0);
+      o.d[i] = O[18 + i];
+      o.v[i] = O[21 + i];
+    }
+    s.p = Dual(B[24], jf == 2 ? c_L[q][jb] : 0.0);
+    o.p = O[24];
+    Slots<Dual> out;
+    if (kind == 0) fluid_flux<Dual, PART_NONLINEAR>(ep.fluid[region], ep.sc, s, o, out);
+    else solid_flux<Dual, PART_NONLINEAR>(ep.solid[region], ep.sc, s, o, out);
+    const double w = live ? sJ[9] * c_qw[q] : 0.0;
+    const double aop = am < 10 ? sA[q][ak][am] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double b0 = w * out.vval[i].e, b1 = w * out.vgrd[i][0].e, b2 = w * out.vgrd[i][1].e, b3 = w * out.vgrd[i][2].e;
+      // registers <-> 16-lane rows: afterwards b_t of lane (row g, n) = slot g of column 16 t + n
+      lane_swap32(b0, b2); lane_swap32(b1, b3); lane_swap16(b0, b1); lane_swap16(b2, b3);
+      acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, b0, acc[i][0], 0, 0, 0);
+      acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, b1, acc[i][1], 0, 0, 0);
+      acc[i][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, b2, acc[i][2], 0, 0, 0);
+      acc[i][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, b3, acc[i][3], 0, 0, 0);
+    }
+    const double pv = w * out.pval.e;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) accp[a] += pv * c_L[q][a];
+  }
+  const uint16_t* nb = ea.enbr + c * 100;
+  const uint16_t* pb = ea.epnbr + c * 40;
+  // v rows: tile t holds columns 16 t + (lane & 15); this lane's four results are test nodes (lane >> 4) + 4 r
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int col = 16 * t + am;
+    const int cf = col < 60 ? col / 30 : 2, cc = col < 60 ? (col % 30) / 10 : 0, cb = col < 60 ? col % 10 : col - 60;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ra = ak + 4 * r;
+      if (ra >= 10) continue;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double v = acc[i][t][r];
+        if (v == 0.0) continue;
+        const int row = 30 + 10 * i + ra;
+        const int64_t pos = cf < 2 ? sRow[row] + 6 * (int64_t)nb[ra * 10 + cb] + 3 * cf + cc : sRow[row] + sDeg6[ra] + pb[ra * 4 + cb];
+        unsafeAtomicAdd(&vals[pos], v);
+      }
+    }
+  }
+  // p rows: column `lane`
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    if (accp[a] == 0.0) continue;
+    const int row = 60 + a;
+    const int64_t pos = jf < 2 ? sRow[row] + 6 * (int64_t)nb[a * 10 + jb] + 3 * jf + jc : sRow[row] + sDeg6[a] + pb[a * 4 + jb];
+    unsafeAtomicAdd(&vals[pos], accp[a]);
+  }
+}
 
 void launch_geometry(hipStream_t st, int64_t C, const double* coords, const int32_t* tet_vertices, double* geom) {
   const int bs = 256;
@@ -578,7 +739,8 @@ void launch_residual(hipStream_t st, int64_t C, const ElemArrays& ea, const Elem
 void launch_jacobian(hipStream_t st, int part, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
                      const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals, const CellColours& cc) {
   // two waves per SIMD with 94 spilled VGPRs beat one wave without (70 against 99 ms per refresh at 1.12 M tets)
-  static const int jac_waves = getenv("FSI_JAC_WAVES") ? atoi(getenv("FSI_JAC_WAVES")) : 2;
+  const int jac_waves = getenv("FSI_JAC_WAVES") ? atoi(getenv("FSI_JAC_WAVES")) : 2;
+  const int jac_mfma = getenv("FSI_JAC_MFMA") ? atoi(getenv("FSI_JAC_MFMA")) : 0;      // k_jacobian_mfma for the refresh kernel
   const int rounds = cc.ncolours == 0 ? 1 : cc.ncolours;
   for (int k = 0; k < rounds; ++k) {
     const int64_t n = cc.ncolours == 0 ? C : cc.ptr[k + 1] - cc.ptr[k];
@@ -586,6 +748,10 @@ void launch_jacobian(hipStream_t st, int part, int64_t C, const ElemArrays& ea, 
     if (n <= 0) continue;
     if (part == PART_LINEAR)
       hipLaunchKernelGGL((k_jacobian<PART_LINEAR, 1>), dim3((unsigned)n), dim3(64), 0, st, ea, ep, U, U1, rowptr, nadj_ptr, vals, list);
+    else if (jac_mfma && jac_waves == 2)
+      hipLaunchKernelGGL((k_jacobian_mfma<2>), dim3((unsigned)n), dim3(64), 0, st, ea, ep, U, U1, rowptr, nadj_ptr, vals, list);
+    else if (jac_mfma)
+      hipLaunchKernelGGL((k_jacobian_mfma<1>), dim3((unsigned)n), dim3(64), 0, st, ea, ep, U, U1, rowptr, nadj_ptr, vals, list);
     else if (jac_waves == 2)
       hipLaunchKernelGGL((k_jacobian<PART_NONLINEAR, 2>), dim3((unsigned)n), dim3(64), 0, st, ea, ep, U, U1, rowptr, nadj_ptr, vals, list);
     else

@@ -565,7 +565,9 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   else
     launch_vel_correct(st, n3, ctx->rowptr_vp.p, ctx->cols_vp.p, ctx->Avp.p, dp, ctx->diagpos3.p, ctx->Mvv.vals.p, vs, dv, ctx->vv_dinv.p);
   if (ctx->adv_is_db) {
-    launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->adv_db.p, dv, w3, ctx->adv_rowmask.p);
+    // dd_early (measurement): the displacement block sees the solid PREDICTOR instead of the corrected velocity - what it would
+    // have if its chain ran beside the pressure step instead of after it
+    launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->adv_db.p, ctx->dd_early ? IW + 4 * n3 : dv, w3, ctx->adv_rowmask.p);
     launch_axpby(st, td, 1.0, rd, -1.0, w3, n3);
   } else {
     launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Adv.p, dv, rd, td);
@@ -2824,6 +2826,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   if (getenv("FSI_NEWTON_FORCING_LATE")) ctx->newton_forcing_late = atof(getenv("FSI_NEWTON_FORCING_LATE"));
   if (getenv("FSI_NEWTON_LATE_FACTOR")) ctx->newton_late_factor = atof(getenv("FSI_NEWTON_LATE_FACTOR"));
   if (getenv("FSI_VEL_JACOBI")) ctx->vel_jacobi = atoi(getenv("FSI_VEL_JACOBI"));
+  if (getenv("FSI_DD_EARLY")) ctx->dd_early = atoi(getenv("FSI_DD_EARLY"));
   if (getenv("FSI_GCR_REORTH")) ctx->gcr_reorth = atof(getenv("FSI_GCR_REORTH"));
   if (getenv("FSI_CHEB4")) ctx->cheb4 = atoi(getenv("FSI_CHEB4"));
   if (getenv("FSI_F32_CYCLE_FLOOR")) ctx->f32_cycle_floor = atof(getenv("FSI_F32_CYCLE_FLOOR"));
