@@ -140,7 +140,10 @@ def test_partitioned_steps_match_single_context(world, transport, which, tmp_pat
     assert comm["library_rccl"] == (transport == "library-rccl")
     # measured: 267 reductions for 188 iterations in 14 solves (2 ranks): these runs ask for 1e-12, where every other iteration
     # repeats its Gram-Schmidt pass; round 2's count for the same run would have been 3 per pass-pair + 1 = ~750
-    assert comm["q_bytes"] == 8 and comm["allreduces"] <= 1.6 * comm["krylov"] + 2 * comm["solves"], comm
+    # (the aneurysm and avf systems cancel w more often: up to two passes per iteration + the confirming reduction; measured
+    # on MI355X: 831 for 444 iterations, 2050 for 715)
+    per_it = 1.6 if which == "cylinder" else 3.0
+    assert comm["q_bytes"] == 8 and comm["allreduces"] <= per_it * comm["krylov"] + 2 * comm["solves"], comm
     print("krylov iterations per Newton iteration:", world, "ranks", [it[3] for h in hist_part for it in h], "single",
           [it[3] for h in hist_one for it in h])
 

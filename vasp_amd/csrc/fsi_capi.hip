@@ -273,9 +273,9 @@ void schur_apply(FsiCtx* ctx, const double* in, double* out, double* w3) {
 
 // FP32 Chebyshev sweeps on a component-diagonal node-block matrix; dinv carries the Jacobi scaling and the mask
 void cheb_db_f32(FsiCtx* ctx, const float* db, const float* dinv, const double* rhs, double* x, double* W, int its,
-                 double lmax, double kappa) {
+                 double lmax, double kappa, hipStream_t st = nullptr) {
   const int64_t n = 4 * ctx->N2;                 // float4 per node
-  hipStream_t st = ctx->stream;
+  if (!st) st = ctx->stream;
   float* F = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(W) + 15) & ~uintptr_t(15));   // float4 loads
   float *fr = F, *fd = F + n, *ft = F + 2 * n, *fx = F + 3 * n, *frhs = F + 4 * n;
   launch_pad_to_f32(st, ctx->N2, rhs, nullptr, frhs);
@@ -324,11 +324,27 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   double* W = ctx->blk.p;
   double *rd = W, *rv = W + n3, *rp = W + 2 * n3, *vs = W + 3 * n3, *tp = W + 4 * n3, *dp = W + 5 * n3, *dv = W + 6 * n3,
          *td = W + 7 * n3, *dd = W + 8 * n3, *IW = W + 9 * n3, *w3 = W + 19 * n3;     // IW: 10 vectors; its first 4 hold the (FP32, float4-padded) sweep work
+  // Two chains side by side (prec_streams; default configuration only: FP32 solid cycle, FP32 fluid sweeps, FP16 / FP32 Schur
+  // sweeps with FP64 vectors, scalar displacement block).  The application is a chain of ~215 dependent launches, most of them
+  // short of filling the chip (latency- and issue-bound sweeps on 0.1 - 0.6 GB of data), and its dependences are fewer than
+  // its order: the fluid predictor does not need the solid one (block Jacobi instead of Gauss-Seidel between the two parts:
+  // same Krylov counts, measured), and the displacement block needs the velocity on the SOLID rows only, where the pressure
+  // correction is small (dd_early: measured).  Stream A (the solver stream): split, solid predictor, displacement block,
+  // merge.  Stream B: fluid predictor, then - once the solid predictor is there - pressure right-hand side, Schur sweeps,
+  // velocity correction.  Work vectors of the two chains are disjoint: the solid and displacement sweeps use IW[0, 4 n3),
+  // the fluid sweeps IW[6 n3, 10 n3), the Schur sweeps the unused tail of rp (V of its n3 entries carry r_p).
+  const bool conc = ctx->prec_streams && ctx->stream2 && ctx->solid_fp32 && ctx->solid_block_jacobi && ctx->solid_fused && ctx->sbmg_ready &&
+                    ctx->sweeps_fp32 && ctx->tiled && ctx->fused_sweeps && ctx->cheb_its_p > 0 && ctx->schur_fp32 == 1 && ctx->s_vals32.p &&
+                    ctx->pv32_ok && ctx->adv_is_db && ctx->cheb_its_d > 0 && ctx->dd_is_scalar && 4 * V <= n3 && ctx->debug_prec_apply == 0;
+  hipStream_t sA = ctx->stream, sB = conc ? ctx->stream2 : ctx->stream;
   launch_split(st, N2, V, r, rd, rv, rp);
+  if (conc) { HIPCHK(hipEventRecord(ctx->ev_split, sA)); HIPCHK(hipStreamWaitEvent(sB, ctx->ev_split, 0)); }
   // velocity predictor: block Gauss-Seidel solid (elasticity-dominated, many cheap sweeps) -> fluid interior (mass-dominated)
   {
     double *xs = IW + 4 * n3, *xf = IW + 5 * n3, *rhs2 = IW + 6 * n3;
     double *cs_rhs = IW + 7 * n3, *cs_x = IW + 8 * n3;            // compact solid vectors (3 nS <= n3)
+    if (conc)      // stream B, issued first: the fluid predictor straight from r_v (no coupling to the solid predictor), work area IW[6 n3, 10 n3)
+      cheb_db_f32(ctx, ctx->vv_db32.p, ctx->vvf_dinv32.p, rv, xf, IW + 6 * n3, ctx->cheb_its_f, ctx->lmax_f, ctx->cheb_kappa_f, sB);
     if (ctx->solid_fp32) {
       const int64_t n = 4 * ctx->nS;               // float4 per solid node
       float* F = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(IW) + 15) & ~uintptr_t(15));   // float4 loads
@@ -469,12 +485,20 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
     launch_fill(st, xs, n3, 0.0);
     launch_scatter3(st, ctx->nS, ctx->snode.p, cs_x, xs);
     }
+    if (conc) {
+      // when the solid predictor is there, the rest of the pressure step follows on B while A goes on to the displacement block
+      HIPCHK(hipEventRecord(ctx->ev_solid, sA));
+      HIPCHK(hipStreamWaitEvent(sB, ctx->ev_solid, 0));
+      st = sB;
+    } else {
     // rhs of the fluid part: rv - Avv~ xs; xs lives on the solid nodes, the fluid solve masks the solid rows, so only
     // the fluid rows with solid columns differ from rv
     launch_copy(st, rhs2, rv, n3);
     if (!ctx->vel_jacobi)      // (vel_jacobi: block Jacobi instead of Gauss-Seidel between the solid and the fluid part of the predictor)
       launch_residual_rows(st, ctx->nfs, ctx->fs_rows.p, ctx->fs_ptr.p, ctx->fs_col.p, ctx->fs_src.p, ctx->Mvv.vals.p, xs, rv, rhs2);
-    if (ctx->sweeps_fp32)
+    }
+    if (conc) {}
+    else if (ctx->sweeps_fp32)
       cheb_db_f32(ctx, ctx->vv_db32.p, ctx->vvf_dinv32.p, rhs2, xf, IW, ctx->cheb_its_f, ctx->lmax_f, ctx->cheb_kappa_f);
     else
       cheb_solve_op(ctx, n3, [&](const double* in, double* out) { launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->vv_db.p, in, out); },
@@ -504,7 +528,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
       }
       launch_f32_to_f64(st, V, fx, dp);
     } else {
-      double *pr = IW, *pa = IW + V, *pb = IW + 2 * V;
+      double *pr = conc ? rp + V : IW, *pa = pr + V, *pb = pr + 2 * V;
       // FSI_CHEB4 bit 2: the Schur sweeps as the 4th-kind polynomial (needs lmax only; see the solid block)
       const bool p4 = (ctx->cheb4 & 4) != 0;
       launch_cheb_init(st, V, nullptr, tp, ctx->s_diagpos.p, ctx->s_vals.p, p4 ? 4.0 / (3.0 * lmax) : 1.0 / th, dp, pr, pa);
@@ -564,10 +588,11 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
     launch_vel_correct32(st, N2, ctx->padj_ptr.p, ctx->padj.p, ctx->Avp32.p, dp, ctx->vv_dinv.p, vs, dv);
   else
     launch_vel_correct(st, n3, ctx->rowptr_vp.p, ctx->cols_vp.p, ctx->Avp.p, dp, ctx->diagpos3.p, ctx->Mvv.vals.p, vs, dv, ctx->vv_dinv.p);
+  if (conc) { HIPCHK(hipEventRecord(ctx->ev_b, sB)); st = sA; }      // the rest (displacement block) is stream A's, behind the solid predictor
   if (ctx->adv_is_db) {
-    // dd_early (measurement): the displacement block sees the solid PREDICTOR instead of the corrected velocity - what it would
-    // have if its chain ran beside the pressure step instead of after it
-    launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->adv_db.p, ctx->dd_early ? IW + 4 * n3 : dv, w3, ctx->adv_rowmask.p);
+    // dd_early: the displacement block sees the solid PREDICTOR instead of the corrected velocity - what it has when its chain
+    // runs beside the pressure step instead of after it
+    launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->adv_db.p, (ctx->dd_early || conc) ? IW + 4 * n3 : dv, w3, ctx->adv_rowmask.p);
     launch_axpby(st, td, 1.0, rd, -1.0, w3, n3);
   } else {
     launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Adv.p, dv, rd, td);
@@ -679,6 +704,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
                           [&](const double* in, double* out) { launch_spmv(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Mdd.vals.p, in, out); },
                           td, dd, IW, ctx->inner_rtol, ctx->inner_maxit, &ctx->inner_its[2]));
   }
+  if (conc) HIPCHK(hipStreamWaitEvent(sA, ctx->ev_b, 0));
   launch_merge(st, N2, V, dd, dv, dp, z);
   if (ctx->debug_prec_apply > 0) {                 // FSI_DEBUG_PRECOND=2: non-finite entries of the parts, first applications only
     ctx->debug_prec_apply -= 1;
@@ -1999,6 +2025,8 @@ int fsi_destroy(FsiCtx* ctx) {
     for (int k = 0; k < PhaseTimer::RING; ++k) { if (t->e0[k]) (void)hipEventDestroy(t->e0[k]); if (t->e1[k]) (void)hipEventDestroy(t->e1[k]); }
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  for (hipEvent_t e : {ctx->ev_split, ctx->ev_solid, ctx->ev_b}) if (e) (void)hipEventDestroy(e);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return FSI_OK;
@@ -2038,6 +2066,8 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) { ctx->err = "fsi_create: no such HIP device"; return FSI_ERR_DEVICE; }
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreate(&ctx->stream));
+  HIPCHK(hipStreamCreate(&ctx->stream2));
+  for (hipEvent_t* e : {&ctx->ev_split, &ctx->ev_solid, &ctx->ev_b}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
   HIPCHK(hipEventCreate(&ctx->ev0));
   HIPCHK(hipEventCreate(&ctx->ev1));
   HIPCHK(upload_tables());
@@ -2827,6 +2857,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   if (getenv("FSI_NEWTON_LATE_FACTOR")) ctx->newton_late_factor = atof(getenv("FSI_NEWTON_LATE_FACTOR"));
   if (getenv("FSI_VEL_JACOBI")) ctx->vel_jacobi = atoi(getenv("FSI_VEL_JACOBI"));
   if (getenv("FSI_DD_EARLY")) ctx->dd_early = atoi(getenv("FSI_DD_EARLY"));
+  if (getenv("FSI_PREC_STREAMS")) ctx->prec_streams = atoi(getenv("FSI_PREC_STREAMS"));
   if (getenv("FSI_GCR_REORTH")) ctx->gcr_reorth = atof(getenv("FSI_GCR_REORTH"));
   if (getenv("FSI_CHEB4")) ctx->cheb4 = atoi(getenv("FSI_CHEB4"));
   if (getenv("FSI_F32_CYCLE_FLOOR")) ctx->f32_cycle_floor = atof(getenv("FSI_F32_CYCLE_FLOOR"));

@@ -365,6 +365,11 @@ struct FsiCtx {
   double newton_forcing_late = 0.0;          // > 0 and < newton_forcing: forcing term of late Newton iterations (see fsi_newton_solve)
   double newton_late_factor = 10.0;          // "late": the previous update norm (or |b|) is within this factor of its tolerance
   int64_t newton_late_solves = 0;
+  // Two chains of one preconditioner application side by side (FSI_PREC_STREAMS=1; precondition_block): stream A = solver
+  // stream: split, solid predictor, displacement block, merge; stream B: fluid predictor, pressure step, velocity correction.
+  int prec_streams = 0;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_split = nullptr, ev_solid = nullptr, ev_b = nullptr;
   int dd_early = 0;                          // FSI_DD_EARLY=1: displacement rhs from the solid predictor (measurement)
   int vel_jacobi = 0;                        // FSI_VEL_JACOBI=1: no solid -> fluid coupling inside the velocity predictor (measurement)
   double newton_forcing = 1e-2;              // inexact Newton: linear tolerance = forcing * atol / |b| (FSI_NEWTON_FORCING; 1e-2: same Newton counts as 1e-3 on the bench, 18 % fewer Krylov iterations)
