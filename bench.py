@@ -39,6 +39,18 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# Kernel groups of the `kernels` table -> the kernel names of a rocprofv3 trace that belong to them (a name that ends inside
+# its template argument list matches every instantiation).  tools/pmc_traffic.py sums the PMC counters over the same groups, so
+# that "HBM traffic per launch" and "algorithmic bytes per launch" of a group are averages over the same set of launches: the
+# orthogonalisation group holds the FP32 column kernels AND the FP64-window kernels, the outer product both value types.
+KERNEL_GROUPS = {"k_gcr_dots": ["k_gcr_dots<", "k_gcr_axpy<"],
+                 "k_gcr_flush": ["k_gcr_flush<"],
+                 "k_spmv_node6": ["k_spmv_node6<", "k_spmv_node6p<", "k_spmv<0,"],
+                 "k_spmv_tiled_f32<1>": ["k_spmv_tiled_f32<1>"], "k_spmv_tiled_f32<3>": ["k_spmv_tiled_f32<3>"],
+                 "k_sweep_tiled_f32<1>": ["k_sweep_tiled_f32<1>"], "k_sweep_tiled_f32<3>": ["k_sweep_tiled_f32<3>"],
+                 "k_sweep_tiled_h<1>": ["k_sweep_tiled_h<1>"], "k_sweep_tiled_h<3>": ["k_sweep_tiled_h<3>"], "k_sweep_sb_h": ["k_sweep_sb_h"],
+                 "k_sweep_sb_b3<0>": ["k_sweep_sb_b3<0>"], "Schur": ["k_sweep_schur_tiled", "k_sweep_csr_mixed", "k_sweep_csr_f32", "k_spmv<2,"],
+                 "k_residual": ["k_residual<", "k_residual_gather"], "k_jacobian": ["k_jacobian<2,"]}
 FP64_STORAGE_ENV = {"FSI_KRYLOV_FP32": "0", "FSI_OPERATOR_FP32": "0", "FSI_SCHUR_FP32": "0", "FSI_SWEEPS_FP16": "0"}
 
 
@@ -74,13 +86,14 @@ def fp64_storage_run(args) -> dict:
             "storage_precisions": j["config"]["storage_precisions"], "roofline": j["roofline"], "wall_s": time.perf_counter() - t0}
 
 
-def cpu_baseline(budget_s: float = 30.0):
-    """The CPU port of the same algorithm (oracle/: C element routines under OpenMP for the assembly, exact sparse LU
-    for the solve - the reference's own linear solver is a direct LU, MUMPS) timed on the host cores on a bounded sample
-    of the bench workload: the same offset-stenosis problem on a mesh of the same generator, sized so that the run takes
-    about ``budget_s``."""
-    from oracle.cpu_port import timed_newton_run
-    return timed_newton_run(budget_s)
+def cpu_baseline(budget_s: float = 25.0):
+    """The CPU port of the same algorithm (oracle/cpu_port.py) timed on the host cores on a bounded sample of the bench
+    workload: the offset-stenosis problem on a 48 000-tet mesh of the same generator ("assembly + SpMV +
+    Krylov" for config 2's CPU leg) - C element routines and the monolithic SpMV under OpenMP on all cores, the HIP path's
+    field-split preconditioner with scipy's incomplete LU as inner solver, recycled GCR; the refresh step and ``budget_s`` of
+    steady steps of one Jacobian lifetime."""
+    from oracle.cpu_port import timed_krylov_run
+    return timed_krylov_run(budget_s, tets=int(os.environ.get("VASPFSI_CPU_BASELINE_TETS", 48000)))
 
 
 def main():
@@ -164,8 +177,11 @@ def main():
     t0 = time.perf_counter()
     n_newton, n_krylov = 0, 0
     krylov_per_solve = []                    # per time step: Krylov iterations of each Newton iteration
+    step_s = []                              # wall time of each timed step (the state shift at its end waits for the device)
     for _ in range(args.steps):
+        t_step = time.perf_counter()
         hist = one_step()
+        step_s.append(time.perf_counter() - t_step)
         n_newton += len(hist)
         n_krylov += sum(h[3] for h in hist)
         krylov_per_solve.append([int(h[3]) for h in hist])
@@ -243,15 +259,10 @@ def main():
             "Schur-complement sweep (explicit two-ring pressure matrix: product + Chebyshev update; avg from sampled HIP events)":
                 (sch_avg * tm["inner_schur_iters"], int(tm["inner_schur_iters"]),
                  tm["schur_nnz"] * (tm["schur_elem_bytes"] + 4.0) + tm["schur_rows"] * 8.0 * 5),
-            ("k_spmv_compact (monolithic Jacobian, node rows: 24 of the 36 entries per node pair that the forms can fill, f64 + one "
-             "i32 per pair; + k_spmv<0> on the pressure rows)" if tm["spmv_compact"] else
-             f"k_spmv_node6 (monolithic Jacobian, one i32 column per six entries, {op32} of {int(tm['spmv_calls'])} products on the FP32 "
+            (f"k_spmv_node6 (monolithic Jacobian, one i32 column per six entries, {op32} of {int(tm['spmv_calls'])} products on the FP32 "
              "copy of the values, the rest FP64; + k_spmv<0> on the pressure rows)"
              if not generic else "k_spmv<0> (monolithic Jacobian, CSR f64 + i32)"):
                 (tm["spmv_ms"], tm["spmv_calls"],
-                 (tm["node_pairs"] * (24 * 8.0 + 4.0) + tm["node_vertex_pairs"] * (3 * 8.0 + 4.0)
-                  + (nnz - 36.0 * tm["node_pairs"] - 6.0 * tm["node_vertex_pairs"]) * 12.0       # pressure rows, full CSR
-                  + ndof_rank * 16.0 + (ndof_rank + 1) * 8.0) if tm["spmv_compact"] else
                  nnz * (8.0 - 4.0 * op32 / max(tm["spmv_calls"], 1) + (4.0 / 6.0 if not generic else 4.0))
                  + ndof_rank * 16.0 + (ndof_rank + 1) * 8.0),
             # 1 676 B per tet (the scatter counted once; the element-vector round trip of the reproducible
@@ -270,45 +281,32 @@ def main():
                            "share_of_timed_region": ms / (1e3 * elapsed)}
         dom = max(table, key=lambda k: table[k]["gpu_ms"])
         d = table[dom]
-        # HBM traffic per launch from the PMC passes of this same command (tools/gpu_pmc_r2.sh -> profiles/r02_pmc_traffic.json:
-        # 2 x FETCH_SIZE + WRITE_SIZE, the factors calibrated on known-byte streams); a group of kernels is averaged over its
-        # launches
-        traffic, traffic_source = None, None
-        pmc = next((q for q in (ROOT / "profiles" / "r03_pmc_traffic.json", ROOT / "profiles" / "r02_pmc_traffic.json") if q.exists()),
-                   ROOT / "profiles" / "r03_pmc_traffic.json")
-        groups = {"k_gcr_dots": [f"k_gcr_dots<{'double' if qb == 8 else 'float'}", f"k_gcr_axpy<{'double' if qb == 8 else 'float'}"],
-                  "k_gcr_flush": ["k_gcr_flush<"],
-                  "k_spmv_node6": ["k_spmv_node6<", "k_spmv_node6p<", "k_spmv<0,"], "k_spmv_compact": ["k_spmv_compact", "k_spmv<0,"],
-                  "k_spmv_tiled_f32<1>": ["k_spmv_tiled_f32<1>"], "k_spmv_tiled_f32<3>": ["k_spmv_tiled_f32<3>"],
-                  "k_sweep_tiled_f32<1>": ["k_sweep_tiled_f32<1>"], "k_sweep_tiled_f32<3>": ["k_sweep_tiled_f32<3>"],
-                  "k_sweep_tiled_h<1>": ["k_sweep_tiled_h<1>"], "k_sweep_tiled_h<3>": ["k_sweep_tiled_h<3>"], "k_sweep_sb_h": ["k_sweep_sb_h"],
-                  "k_sweep_sb_b3<0>": ["k_sweep_sb_b3<0>"], "Schur": ["k_sweep_schur_tiled", "k_sweep_csr_mixed", "k_sweep_csr_f32", "k_spmv<2,"],
-                  "k_residual": ["k_residual<", "k_residual_gather"], "k_jacobian": ["k_jacobian<2,"]}
-        if pmc.exists():
+        # HBM traffic per launch: tools/gpu_pmc_r4.sh runs THIS command with --warmup 0 under rocprofv3 --pmc
+        # (FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on known-byte streams) and tools/pmc_traffic.py stores, per
+        # kernel group, the PMC bytes summed over every launch of the group next to the algorithmic bytes the profiled run's own
+        # JSON line reports for the same launches (with no warm-up the library's counters cover the whole process, so the two
+        # launch sets are identical).  Their ratio is what the counters say about wasted traffic; `traffic` below is that ratio
+        # applied to this run's algorithmic bytes per launch, i.e. on the basis of `algorithmic_bytes_per_launch`.
+        traffic, traffic_source, traffic_ratio = None, None, None
+        pmc = next((q for q in (ROOT / "profiles" / "r04_pmc_traffic.json",) if q.exists()), None)
+        if pmc is not None and world == 1:
             with contextlib.suppress(Exception):
                 pj = json.loads(pmc.read_text())
-                det = pj.get("detail", {})
-                # the counters were collected on one workload: they describe this run only if it is the same one (fetch + write
-                # bytes per launch, FETCH_SIZE x 1024 x 2 and WRITE_SIZE x 1024 as calibrated in tools/gpu_pmc_r2.sh)
-                same = pj.get("tets") in (None, C) and pj.get("dofs") in (None, ndof) and world == 1
-                traffic_source = f"profiles/{pmc.name}" + ("" if pj.get("tets") else " (size not recorded: 1.12 M-tet bench mesh)")
-                if (pj.get("tets") is None and C != 1123200) or not same:
-                    det = {}
-                    traffic_source = None
-                for key, names in groups.items():
-                    if dom.startswith(key):
-                        # a name that ends inside its template argument list matches every instantiation
-                        rows = [v for k, v in det.items()
-                                if any(k == nm or ("<" in nm and not nm.endswith(">") and k.startswith(nm)) for nm in names)]
-                        if key in ("k_spmv_node6", "k_spmv_compact"):            # one product = one launch of each part
-                            traffic = 0.0
-                            for nm in names:
-                                part = [v for k, v in det.items() if k.startswith(nm) or k == nm]
-                                nl = sum(r["launches"] for r in part)
-                                traffic += sum((r["fetch_bytes"] + r["write_bytes"]) * r["launches"] for r in part) / max(nl, 1)
-                        elif rows:
-                            nl = sum(r["launches"] for r in rows)
-                            traffic = sum((r["fetch_bytes"] + r["write_bytes"]) * r["launches"] for r in rows) / max(nl, 1)
+                if pj.get("tets") == C and pj.get("dofs") == ndof:
+                    for key, g in pj.get("groups", {}).items():
+                        if dom.startswith(key) and g.get("algorithmic_bytes_per_launch"):
+                            traffic_ratio = g["pmc_bytes_per_launch"] / g["algorithmic_bytes_per_launch"]
+                            traffic = traffic_ratio * d["algorithmic_bytes_per_launch"]
+                            traffic_source = f"profiles/{pmc.name}: group {key}, {g['launches']} launches of the profiled run"
+        # the north star's own aggregate: assembly (residual + Jacobian) and the monolithic SpMV together
+        agg = [v for k, v in table.items() if k.startswith(("k_residual", "k_jacobian", "k_spmv_node6", "k_spmv<0>"))]
+        agg_bytes = sum(v["algorithmic_bytes_per_launch"] * v["launches"] for v in agg)
+        agg_ms = sum(v["gpu_ms"] for v in agg)
+        assembly_spmv = {"kernels": "k_residual + k_residual_gather, k_jacobian<nonlinear>, monolithic SpMV (north_star: assembly + SpMV >= 40 % of the HBM roofline)",
+                         "algorithmic_bytes": agg_bytes, "gpu_ms": agg_ms, "achieved_GBps": agg_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else 0.0,
+                         "peak_GBps": HBM_PEAK_GBS, "frac": (agg_bytes / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if agg_ms > 0 else 0.0,
+                         "per_kernel_frac": {k.split(" ")[0]: v["frac_of_hbm_peak"] for k, v in table.items()
+                                             if k.startswith(("k_residual", "k_jacobian", "k_spmv"))}}
         out = {
             "metric": "Newton-iterations/sec (offset_stenosis, monolithic ALE-FSI step)",
             "value": total_newton / elapsed, "unit": "Newton-iterations/s", "n_gpus": world, "steps": args.steps,
@@ -346,12 +344,20 @@ def main():
             "setup_s": setup_s,
             "host_ms_per_step": ({k: 1e3 * v / args.steps for k, v in ns["_profile"].items()} if args.profile_host else None),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": d["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
+                         "frac": d["frac_of_hbm_peak"], "traffic": traffic, "traffic_over_algorithmic": traffic_ratio,
+                         "traffic_source": traffic_source if traffic is not None else None,
                          "launches": d["launches"],
                          "avg_launch_ms": d["avg_launch_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                          "share_of_timed_region": d["share_of_timed_region"]},
+            "assembly_spmv": assembly_spmv,
             "kernels": table,
         }
+        if args.steps > 20:          # long runs: the time per step grows with the ramp (more Newton iterations per step); per Jacobian lifetime
+            life = int(ns["recompute_tstep"])
+            out["per_lifetime"] = [{"steps": f"{a}-{min(a + life, args.steps) - 1}", "ms_per_step": 1e3 * sum(step_s[a:a + life]) / len(step_s[a:a + life]),
+                                    "newton_iterations": sum(len(k) for k in krylov_per_solve[a:a + life]),
+                                    "krylov_iterations": sum(sum(k) for k in krylov_per_solve[a:a + life])}
+                                   for a in range(0, args.steps, life)]
     hb.close()                 # the context's HBM (Krylov store, matrices) is free again before anything else runs
     if rank == 0:
         out["config"]["storage"] = args.storage

@@ -249,7 +249,6 @@ typedef struct FsiTimers {
   double schur_ms;       int64_t schur_calls;        /* sampled launches of the Schur-complement sweep                */
   int64_t schur_elem_bytes;                          /* value bytes next to a 4-byte column: 8 FP64, 4 FP32; 0: FP16
                                                         value and 16-bit tile-local column packed in the 4 bytes     */
-  int64_t spmv_compact;                              /* 1: the outer product runs on the compact node rows            */
   int64_t node_pairs;    int64_t node_vertex_pairs;  /* P2 node pairs / node-vertex pairs of the matrix graph         */
   int64_t spmv_fp32_calls;                           /* outer products that ran on the FP32 copy of the matrix        */
   int64_t sweep_flags;                               /* what the preconditioner sweeps actually run as (the context's

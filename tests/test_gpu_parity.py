@@ -808,51 +808,6 @@ def test_wall_shear_stress_kernel_matches_oracle(cyl, cylinder_case):
     cyl.set_state("n", np.zeros(cyl.ndof))
 
 
-def test_compact_rows_product_matches_oracle(cylinder_case, monkeypatch):
-    """FSI_SPMV_COMPACT=1 (opt-in): the outer product on the 24-of-36 compact node rows is the same operator."""
-    from oracle.fsi_oracle import FsiOracle
-    from vasp_amd.capi import HipBackend
-    monkeypatch.setenv("FSI_SPMV_COMPACT", "1")
-    ns, desc = cylinder_case[0], cylinder_case[1]
-    o = FsiOracle(desc)
-    hb = HipBackend(desc)
-    U, U1 = random_state(ns["mesh"], o.ndof, seed=9)
-    g, P = boundary_data(cylinder_case, 0.05)
-    hb.set_state("n", U); hb.set_state("n-1", U1); hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
-    o.solver_setup(np.zeros(o.ndof), np.zeros(o.ndof))
-    A_ref = o.jacobian(U, U1)
-    hb.assemble_jacobian()
-    assert hb.timers()["spmv_compact"] == 1
-    x = np.random.default_rng(10).standard_normal(o.ndof)
-    assert np.abs(hb.spmv(x) - A_ref @ x).max() <= 1e-11 * np.abs(A_ref @ x).max()
-    hb.close()
-
-
-def _three_steps(case, recompute_tstep=2):
-    """Three time steps of the production policy in a fresh context; returns (residual vector of the first assembly, product
-    of the first Jacobian with a fixed vector, state after every step, Krylov iterations)."""
-    from vasp_amd.capi import HipBackend
-    hb = HipBackend(case[1])
-    x = np.random.default_rng(7).standard_normal(hb.ndof)
-    states, its = [], []
-    b0 = ax0 = None
-    for k in range(3):
-        g, P = boundary_data(case, 1e-3 * (k + 1))
-        hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
-        if k == 0:
-            hb.assemble_residual()
-            b0 = hb.get_state("b")
-            hb.assemble_jacobian()
-            ax0 = hb.spmv(x)
-        hist = hb.newton_solve(counter=k, first_step_num=0, atol=1e-6, rtol=1e-6, max_it=20, lmbda=1.0, recompute=20,
-                               recompute_tstep=recompute_tstep)
-        its.append([h[3] for h in hist])
-        hb.shift()
-        states.append(hb.get_state("n"))
-    hb.close()
-    return b0, ax0, states, its
-
-
 def test_time_steps_are_bitwise_reproducible(tmp_path):
     """`north_star`: segmented scatter-add into the global vector / CSR matrix.  Here the residual's segmented reduction runs
     on the owner's side (element vectors stored per cell, every dof sums the cells around its node in ascending order); for

@@ -56,7 +56,11 @@ def main():
     exact_env = {"FSI_KRYLOV_FP32": "0", "FSI_OPERATOR_FP32": "0", "FSI_SCHUR_FP32": "0", "FSI_SWEEPS_FP16": "0"}
     U_ref, its_ref, kry_ref, _ = run(exact_env, lin_rtol=1e-10, newton_forcing=0.0)
     print("exact solves: Newton", its_ref, "Krylov", kry_ref)
-    configs = [("forcing 1e-2 (round 3 default)", {}),
+    configs = [("forcing 1e-2, one stream (round 3)", {"FSI_PREC_STREAMS": "0"}),
+               ("forcing 1e-2, two streams", {}),
+               ("late 3e-3, factor 10", {"FSI_NEWTON_FORCING_LATE": "3e-3", "FSI_NEWTON_LATE_FACTOR": "10"}),
+               ("late 3e-3, factor 30", {"FSI_NEWTON_FORCING_LATE": "3e-3", "FSI_NEWTON_LATE_FACTOR": "30"}),
+               ("late 2e-3, factor 10", {"FSI_NEWTON_FORCING_LATE": "2e-3", "FSI_NEWTON_LATE_FACTOR": "10"}),
                ("late 1e-3, factor 10", {"FSI_NEWTON_FORCING_LATE": "1e-3", "FSI_NEWTON_LATE_FACTOR": "10"}),
                ("late 1e-3, factor 100", {"FSI_NEWTON_FORCING_LATE": "1e-3", "FSI_NEWTON_LATE_FACTOR": "100"}),
                ("late 1e-4, factor 10", {"FSI_NEWTON_FORCING_LATE": "1e-4", "FSI_NEWTON_LATE_FACTOR": "10"}),

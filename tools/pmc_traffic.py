@@ -57,5 +57,27 @@ for name in sorted(set(fetch) | set(write)):
     per_launch[short] = f + w
     detail[short] = {"fetch_bytes": f, "write_bytes": w, "raw_fetch_KiB": fetch.get(name, (0.0, 0))[0],
                      "raw_write_KiB": write.get(name, (0.0, 0))[0], "launches": fetch.get(name, (0, 0))[1], "widths": [rk, wk]}
-print(json.dumps({**workload, "unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, KiB counters x 1024 x calibration factor of the access width)",
+# Per kernel GROUP of bench.py's table: PMC bytes summed over every launch of the group's kernels, divided
+# by the launches the bench line of the SAME run counts for the group, next to the algorithmic bytes per launch of that line -
+# the profiled command runs with --warmup 0, so the library's counters and the trace cover the same launches.
+groups = {}
+if len(sys.argv) > 6:
+    try:
+        sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
+        from bench import KERNEL_GROUPS
+        bench_line = json.loads(open(sys.argv[6]).read().strip().splitlines()[-1])
+        for key, names in KERNEL_GROUPS.items():
+            rows = [(k, v) for k, v in detail.items() if any(k == nm or k.startswith(nm) for nm in names)]
+            bk = next((k for k in bench_line["kernels"] if k.startswith(key) or (key == "Schur" and k.startswith("Schur"))), None)
+            if not rows or bk is None or not bench_line["kernels"][bk]["launches"]:
+                continue
+            tot = sum((v["fetch_bytes"] + v["write_bytes"]) * v["launches"] for _, v in rows)
+            bl = bench_line["kernels"][bk]["launches"]
+            groups[key] = {"kernels": {k: v["launches"] for k, v in rows}, "trace_launches": sum(v["launches"] for _, v in rows),
+                           "launches": bl, "pmc_bytes_total": tot, "pmc_bytes_per_launch": tot / bl,
+                           "algorithmic_bytes_per_launch": bench_line["kernels"][bk]["algorithmic_bytes_per_launch"],
+                           "traffic_over_algorithmic": tot / bl / max(bench_line["kernels"][bk]["algorithmic_bytes_per_launch"], 1.0)}
+    except Exception as e:
+        groups = {"error": str(e)}
+print(json.dumps({**workload, "groups": groups, "unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, KiB counters x 1024 x calibration factor of the access width)",
                   "calibration_bytes": cal_bytes, "calibration_factors": cal, "per_launch_bytes": per_launch, "detail": detail}, indent=1))

@@ -65,7 +65,7 @@ class FsiTimers(C.Structure):
                 ("ortho_z_launches", C.c_int64), ("q_elem_bytes", C.c_int64), ("ldq", C.c_int64), ("ldz", C.c_int64),
                 ("krylov_dirs", C.c_int64), ("krylov_cap", C.c_int64), ("schur_nnz", C.c_int64), ("schur_rows", C.c_int64),
                 ("flush_ms", C.c_double), ("flush_calls", C.c_int64), ("schur_ms", C.c_double), ("schur_calls", C.c_int64),
-                ("schur_elem_bytes", C.c_int64), ("spmv_compact", C.c_int64), ("node_pairs", C.c_int64),
+                ("schur_elem_bytes", C.c_int64), ("node_pairs", C.c_int64),
                 ("node_vertex_pairs", C.c_int64), ("spmv_fp32_calls", C.c_int64), ("sweep_flags", C.c_int64), ("part_allreduces", C.c_int64),
                 ("assembly_colours", C.c_int64), ("gcr_arnoldi_steps", C.c_int64), ("gcr_restarts", C.c_int64),
                 ("newton_retries", C.c_int64), ("fp32_fallbacks", C.c_int64), ("verdicts_skipped", C.c_int64),

@@ -10,7 +10,6 @@
 #include <numeric>
 
 #include "fsi_kernels.hpp"
-#include "fsi_symeig.hpp"
 
 using namespace fsi;
 
@@ -390,37 +389,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         float *cr = ctx->sbmg_work.p, *cd = cr + n4c, *cd2 = cr + 2 * n4c, *cx = cr + 3 * n4c, *crhs = cr + 4 * n4c;
         launch_sbmg_restrict(st, nc, ctx->sbmg_chptr.p, ctx->sbmg_child.p, ctx->sbmg_chw.p, ctx->snode.p, ctx->rowscale.p,
                              ctx->sbmg_flag.p, ctx->sbmg_cflag.p, fr, crhs);
-        if (ctx->l3.ready) {
-          // a few two-grid cycles on the P1 level with the dense aggregate level below it (fsi_amg.hip): smoothing on
-          // [lmax / alpha, lmax], then per cycle  e = P A3^-1 P^T r  as the next direction, one sweep that applies it and
-          // restarts the recurrence, `post` smoothing sweeps
-          const L3Level& L3 = ctx->l3;
-          const double cl = ctx->sbmg_clmax;
-          const double clmin = cl / L3.alpha, cth = 0.5 * (cl + clmin), cde = 0.5 * (cl - clmin), csig = cth / cde;
-          double crho = 1.0 / csig;
-          launch_cheb_init_b3(st, nc, crhs, ctx->sbmg_cbinv12.p, (float)(1.0 / cth), cx, cr, cd);
-          HIPCHK(hipMemsetAsync(cd2, 0, n4c * sizeof(float), st));
-          float *ca = cd, *cb = cd2;
-          auto csweep = [&](float c1, float c2) {
-            launch_sweep_sb_b3(st, nc, ctx->sbmg_cptr.p, ctx->sbmg_ccol.p, ctx->sbmg_cvals.p, ctx->sbmg_cbinv12.p, c1, c2, ca, cb, cx, cr, 1);
-            std::swap(ca, cb);
-          };
-          for (int k = 0; k < L3.pre; ++k) {
-            const double rn = 1.0 / (2.0 * csig - crho);
-            csweep((float)(rn * crho), (float)(2.0 * rn / cde));
-            crho = rn;
-          }
-          for (int cyc = 0; cyc < L3.cycles; ++cyc) {
-            l3_correct(ctx, cr, ca);
-            csweep(0.f, (float)(1.0 / cth));
-            crho = 1.0 / csig;
-            for (int k = 0; k < L3.post; ++k) {
-              const double rn = 1.0 / (2.0 * csig - crho);
-              csweep((float)(rn * crho), (float)(2.0 * rn / cde));
-              crho = rn;
-            }
-          }
-        } else {
+        {
           const double cl = ctx->sbmg_clmax, clmin = cl / ctx->sbmg_ckappa, cth = 0.5 * (cl + clmin), cde = 0.5 * (cl - clmin), csig = cth / cde;
           double crho = 1.0 / csig;
           launch_cheb_init_b3(st, nc, crhs, ctx->sbmg_cbinv12.p, (float)(1.0 / cth), cx, cr, cd);
@@ -768,20 +737,9 @@ int spmv(FsiCtx* ctx, const double* x, double* y, bool working = false) {
                        ctx->a32_ptail - ctx->a32_tail_src, x, y);
     return FSI_OK;
   }
-  // FSI_SPMV_MONO=1: column-array-free variant (8.7 instead of 12 bytes per entry); measured SLOWER on MI355X (6.6 vs
-  // 5.5 ms at 1.7 G entries: the index chain nadj -> x and the t / 6 outweigh the bytes), so the CSR kernel stays
-  static const bool generic = getenv("FSI_SPMV_MONO") == nullptr;
-  static const bool node6 = getenv("FSI_SPMV_GENERIC") == nullptr;
-  if (generic && node6 && ctx->compact_ok && ctx->spmv_compact)
-    launch_spmv_compact(ctx->stream, ctx->N2, ctx->V, ctx->rowptr.p, ctx->cols.p, ctx->A.p, ctx->nadj_ptr.p, ctx->nadj.p,
-                        ctx->padj_ptr.p, ctx->padj.p, ctx->cA.p, ctx->cP.p, x, y);
-  else if (generic && node6)
-    launch_spmv_node6(ctx->stream, ctx->N2, ctx->V, ctx->rowptr.p, ctx->cols.p, ctx->A.p, x, y);
-  else if (generic)
-    launch_spmv(ctx->stream, ctx->ndof, ctx->rowptr.p, ctx->cols.p, ctx->A.p, x, y, SPMV_MONOLITHIC);
-  else
-    launch_spmv_mono(ctx->stream, ctx->ndof, ctx->N2, ctx->rowptr.p, ctx->nadj_ptr.p, ctx->nadj.p, ctx->padj_ptr.p, ctx->padj.p,
-                     ctx->vrank.p, ctx->A.p, x, y);
+  static const bool node6 = getenv("FSI_SPMV_GENERIC") == nullptr;      // FSI_SPMV_GENERIC=1: one wave per row on the plain CSR arrays
+  if (node6) launch_spmv_node6(ctx->stream, ctx->N2, ctx->V, ctx->rowptr.p, ctx->cols.p, ctx->A.p, x, y);
+  else launch_spmv(ctx->stream, ctx->ndof, ctx->rowptr.p, ctx->cols.p, ctx->A.p, x, y, SPMV_MONOLITHIC);
   return FSI_OK;
 }
 
@@ -800,15 +758,6 @@ void gcr_reset(FsiCtx* ctx) {
   ctx->kry_hw = 0;
   ctx->kry_free.clear();
   std::fill(ctx->kry_born.begin(), ctx->kry_born.end(), (int64_t)-1);
-  if (ctx->rz_soft > 0) {
-    const size_t cap = (size_t)ctx->kry_cap;
-    ctx->rz_C.assign(cap * cap, 0.0);
-    ctx->rz_known.assign(cap, 0);
-    ctx->rz_a.assign(cap, 0.0);
-    ctx->rz_prev_h.assign(cap, 0.0);
-    ctx->rz_sols.clear();
-    ctx->rz_prev_slot = -1;
-  }
 }
 
 namespace {
@@ -845,166 +794,6 @@ int gcr_retire(FsiCtx* ctx, int batch) {
     ctx->kry_born[sidx] = -1;
     ctx->kry_free.push_back(sidx);
   }
-  return FSI_OK;
-}
-
-// ---- bookkeeping of the recycled-space compression (see FsiCtx::rz_*) ----------------------------------------------------
-// w_k = B r_k = sum_j h_j q_j + wn q_k  and  r_{k+1} = r_k - alpha_k q_k  give  B q_k = (B r_k - B r_{k+1}) / alpha_k  in the
-// basis Q as soon as the NEXT iteration of the same cycle has its coefficients; the last direction of a cycle stays unknown.
-void rz_record(FsiCtx* ctx, const std::vector<double>& htot, int m, int slot, double wn, double alpha) {
-  const size_t cap = (size_t)ctx->kry_cap;
-  std::vector<double> h(cap, 0.0);
-  for (int j = 0; j < m; ++j) h[j] = htot[j];
-  h[slot] = wn;
-  if (ctx->rz_prev_slot >= 0 && ctx->rz_prev_alpha != 0.0 && std::isfinite(ctx->rz_prev_alpha)) {
-    double* col = &ctx->rz_C[cap * (size_t)ctx->rz_prev_slot];
-    const double inv = 1.0 / ctx->rz_prev_alpha;
-    for (size_t i = 0; i < cap; ++i) col[i] = (ctx->rz_prev_h[i] - h[i]) * inv;
-    ctx->rz_known[ctx->rz_prev_slot] = 1;
-  }
-  ctx->rz_prev_h.swap(h);
-  ctx->rz_prev_slot = slot;
-  ctx->rz_prev_alpha = alpha;
-  ctx->rz_a[slot] += alpha;                  // A x = Q a: the solution's coordinates, x = P a
-}
-
-// Replace the m kept directions by `rz_keep` combinations of them (P' = P Y, Q' = Q Y, Y with orthonormal columns, so Q'
-// stays orthonormal and A P' = Q'): the dominant right singular vectors of Q^T (B - I) Q and the most recent solutions.
-// Called between solves, when every direction is explicit.  Columns [0, keep) of the store afterwards.
-int gcr_compress(FsiCtx* ctx) {
-  const int64_t cap = ctx->kry_cap, n = ctx->ndof;
-  std::vector<int32_t> act;
-  for (int64_t sidx = 0; sidx < ctx->kry_hw; ++sidx)
-    if (ctx->kry_born[sidx] >= 0) act.push_back((int32_t)sidx);
-  const int m = (int)act.size();
-  if (ctx->rz_soft <= 0 || m <= ctx->rz_soft) return FSI_OK;
-  const int K = std::min(ctx->rz_keep, m - 1);
-  const int64_t hw = ctx->kry_hw;
-  if (K < 4 || hw + K > cap || hw != (int64_t)m) return FSI_OK;      // needs a compact store [0, m) and K spare columns behind it
-  hipStream_t st = ctx->stream;
-  // mode 0 (default): D = Q^T B Q, the directions kept are its right singular vectors with the SMALLEST singular values - where
-  // the preconditioned operator nearly annihilates the kept space (eigenvalues near zero are what a Krylov iteration is slow
-  // on; an over-amplified mode costs one iteration).  mode 1: D = Q^T (B - I) Q, largest singular values (deviation from the
-  // identity at both ends; measured worse: it is dominated by the large end).  Unknown columns: B q = q.
-  static const int mode = getenv("FSI_KRYLOV_COMPRESS_MODE") ? atoi(getenv("FSI_KRYLOV_COMPRESS_MODE")) : 0;
-  std::vector<double> D((size_t)m * m, 0.0), G((size_t)m * m, 0.0), V, ev;
-  for (int j = 0; j < m; ++j) {
-    const bool known = ctx->rz_known[act[j]] != 0;
-    for (int i = 0; i < m; ++i) {
-      const double cij = known ? ctx->rz_C[(size_t)cap * act[j] + act[i]] : (i == j ? 1.0 : 0.0);
-      D[(size_t)i * m + j] = cij - ((mode == 1 && i == j) ? 1.0 : 0.0);
-    }
-  }
-  for (int a = 0; a < m; ++a)
-    for (int b = a; b < m; ++b) {
-      double sum = 0.0;
-      for (int i = 0; i < m; ++i) sum += D[(size_t)i * m + a] * D[(size_t)i * m + b];
-      G[(size_t)a * m + b] = G[(size_t)b * m + a] = sum;
-    }
-  sym_eig(m, G, V, ev);                      // ascending: the last columns carry the largest singular values of D
-  // Y (m x K): first the recent solutions (they are what the next right-hand side projects on), then singular vectors from
-  // the top, orthonormalised as they come (modified Gram-Schmidt, twice)
-  std::vector<double> Y((size_t)m * K, 0.0);
-  int ny = 0;
-  auto push = [&](const std::vector<double>& v) {
-    if (ny >= K) return;
-    std::vector<double> y(v);
-    double n0 = 0.0;
-    for (double t : y) n0 += t * t;
-    if (!(n0 > 0.0)) return;
-    for (int pass = 0; pass < 2; ++pass)
-      for (int k = 0; k < ny; ++k) {
-        double d = 0.0;
-        for (int i = 0; i < m; ++i) d += Y[(size_t)i * K + k] * y[i];
-        for (int i = 0; i < m; ++i) y[i] -= d * Y[(size_t)i * K + k];
-      }
-    double n1 = 0.0;
-    for (double t : y) n1 += t * t;
-    if (!(n1 > 1e-20 * n0) || !std::isfinite(n1)) return;
-    const double sc = 1.0 / std::sqrt(n1);
-    for (int i = 0; i < m; ++i) Y[(size_t)i * K + ny] = y[i] * sc;
-    ny += 1;
-  };
-  for (auto it = ctx->rz_sols.rbegin(); it != ctx->rz_sols.rend(); ++it) {
-    std::vector<double> v(m);
-    for (int i = 0; i < m; ++i) v[i] = (*it)[act[i]];
-    push(v);
-  }
-  for (int t = 0; t < m && ny < K; ++t) {
-    const int c = mode == 1 ? m - 1 - t : t;       // ascending eigenvalues of D^T D: smallest first (mode 0), largest first (mode 1)
-    std::vector<double> v(m);
-    for (int i = 0; i < m; ++i) v[i] = V[(size_t)i * m + c];
-    push(v);
-  }
-  if (ny < K) return FSI_OK;
-  // device: the K combinations into columns [hw, hw + K) of both stores (32 per launch), then down to [0, K)
-  const size_t qb = qbytes(ctx);
-  if (ctx->rz_coef.n < (size_t)32 * cap) HIPCHK(ctx->rz_coef.alloc((size_t)32 * cap));
-  std::vector<double> coef((size_t)32 * m);
-  for (int k0 = 0; k0 < K; k0 += 32) {
-    const int kn = std::min(32, K - k0);
-    for (int k = 0; k < kn; ++k)
-      for (int j = 0; j < m; ++j) coef[(size_t)k * m + j] = Y[(size_t)j * K + k0 + k];      // inputs are columns [0, m): act[j] == j
-    HIPCHK(hipMemcpyAsync(ctx->rz_coef.p, coef.data(), (size_t)kn * m * sizeof(double), hipMemcpyHostToDevice, st));
-    launch_gcr_combine(st, 8, ctx->KZ.p, ctx->ldz, n, m, ctx->rz_coef.p, kn, hw + k0);
-    launch_gcr_combine(st, (int)qb, ctx->KQ.p, ctx->ldq, n, m, ctx->rz_coef.p, kn, hw + k0);
-    HIPCHK(hipStreamSynchronize(st));          // `coef` is pageable and reused
-  }
-  HIPCHK(hipMemcpyAsync(ctx->KZ.p, ctx->KZ.p + (size_t)hw * ctx->ldz, (size_t)K * ctx->ldz * sizeof(double), hipMemcpyDeviceToDevice, st));
-  HIPCHK(hipMemcpyAsync(ctx->KQ.p, ctx->KQ.p + (size_t)hw * ctx->ldq * qb, (size_t)K * ctx->ldq * qb, hipMemcpyDeviceToDevice, st));
-  // host state in the new basis: C' = Y^T C Y (unknown columns as identity), solutions a' = Y^T a
-  std::vector<double> Cn((size_t)m * m, 0.0), T((size_t)m * K, 0.0), Cp((size_t)K * K, 0.0);
-  for (int j = 0; j < m; ++j)
-    for (int i = 0; i < m; ++i) Cn[(size_t)i * m + j] = ctx->rz_known[act[j]] ? ctx->rz_C[(size_t)cap * act[j] + act[i]] : (i == j ? 1.0 : 0.0);
-  for (int i = 0; i < m; ++i)
-    for (int k = 0; k < K; ++k) {
-      double sum = 0.0;
-      for (int j = 0; j < m; ++j) sum += Cn[(size_t)i * m + j] * Y[(size_t)j * K + k];
-      T[(size_t)i * K + k] = sum;
-    }
-  for (int a = 0; a < K; ++a)
-    for (int b = 0; b < K; ++b) {
-      double sum = 0.0;
-      for (int i = 0; i < m; ++i) sum += Y[(size_t)i * K + a] * T[(size_t)i * K + b];
-      Cp[(size_t)a * K + b] = sum;
-    }
-  std::vector<std::vector<double>> sols;
-  for (const auto& a : ctx->rz_sols) {
-    std::vector<double> an((size_t)cap, 0.0);
-    for (int k = 0; k < K; ++k) { double sum = 0.0; for (int i = 0; i < m; ++i) sum += Y[(size_t)i * K + k] * a[act[i]]; an[k] = sum; }
-    sols.push_back(std::move(an));
-  }
-  std::fill(ctx->rz_C.begin(), ctx->rz_C.end(), 0.0);
-  std::fill(ctx->rz_known.begin(), ctx->rz_known.end(), 0);
-  for (int b = 0; b < K; ++b) {
-    for (int a = 0; a < K; ++a) ctx->rz_C[(size_t)cap * b + a] = Cp[(size_t)a * K + b];
-    ctx->rz_known[b] = 1;
-  }
-  ctx->rz_sols.swap(sols);
-  ctx->rz_prev_slot = -1;
-  std::fill(ctx->kry_born.begin(), ctx->kry_born.end(), (int64_t)-1);
-  for (int k = 0; k < K; ++k) ctx->kry_born[k] = k;
-  ctx->kry_hw = K;
-  ctx->kry_m = K;
-  ctx->kry_free.clear();
-  std::fill(ctx->hot_slots.begin(), ctx->hot_slots.end(), -1);
-  ctx->hot_next = 0;
-  ctx->rz_compressions += 1;
-  HIPCHK(hipStreamSynchronize(st));
-  if (ctx->debug_gcr && !ctx->kry_fp32) {      // consistency of the compressed pairs (FP64 basis): |A p'_k - q'_k| / |q'_k|, max |q'_0 . q'_j - delta|
-    for (int k : {0, K - 1}) {
-      FSICHK(spmv(ctx, ctx->KZ.p + (size_t)k * ctx->ldz, ctx->tmp3.p));
-      const double* qk = reinterpret_cast<const double*>(ctx->KQ.p) + (size_t)k * ctx->ldq;
-      launch_axpby(st, ctx->tmp3.p, 1.0, ctx->tmp3.p, -1.0, qk, n);
-      double e = 0.0, qn = 0.0;
-      FSICHK(dot_n(ctx, ctx->tmp3.p, ctx->tmp3.p, n, &e));
-      FSICHK(dot_n(ctx, qk, qk, n, &qn));
-      fprintf(stderr, "[gcr]   pair %d: |A p - q| / |q| = %.3e, |q| = %.6f\n", k, std::sqrt(e / std::max(qn, 1e-300)), std::sqrt(qn));
-    }
-  }
-  if (ctx->debug_gcr)
-    fprintf(stderr, "[gcr] compressed %d kept directions to %d (largest / %d-th / smallest singular value^2 of Q^T (B - I) Q: %.3e / %.3e / %.3e)\n",
-            m, K, K, ev[m - 1], ev[std::max(0, m - K)], ev[0]);
   return FSI_OK;
 }
 
@@ -1067,10 +856,6 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
     }
     rn2 = hh[m];
     r_entry = std::sqrt(std::max(rn2, 0.0));
-    if (ctx->rz_soft > 0) {
-      ctx->rz_prev_slot = -1;
-      for (int j = 0; j < m; ++j) if (ctx->kry_born[j] >= 0) ctx->rz_a[j] += hh[j];
-    }
     if (m > 0) {
       for (int j = 0; j < m; ++j) cy.y[j] = ctx->kry_born[j] >= 0 ? hh[j] : 0.0;
       launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, r, nullptr, ctx->scratch.p, ctx->gcr_out.p);
@@ -1304,7 +1089,6 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
       return FSI_ERR_LINEAR;
     }
     const double alpha = wr / wn;          // q . r with q = w / wn
-    if (ctx->rz_soft > 0) rz_record(ctx, htot, m, slot, wn, alpha);
     if (f32) {                              // the exact q goes into the FP64 window (ring of 32)
       qd = ctx->KQh.p + (size_t)ctx->hot_next * ctx->ldq;
       ctx->hot_slots[ctx->hot_next] = slot;
@@ -1555,12 +1339,6 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
       }
       fprintf(stderr, "[gcr]   orthonormality of the last columns: max |q_i . q_j - delta| = %.3e (i %d, j %d)\n", worst_o, wi, wj);
     }
-  }
-  if (ctx->rz_soft > 0) {
-    ctx->rz_sols.push_back(ctx->rz_a);
-    if (ctx->rz_sols.size() > 2) ctx->rz_sols.erase(ctx->rz_sols.begin());
-    std::fill(ctx->rz_a.begin(), ctx->rz_a.end(), 0.0);
-    if (rnorm <= rtol * bnorm) FSICHK(gcr_compress(ctx));
   }
   // stagnation within a factor 100 of a tolerance below 1e-9 (after the restarts above): the answer is as accurate as FP64 makes it on this system, and
   // the caller (Newton's own residual check) judges the step; reported through relres
@@ -1814,11 +1592,6 @@ int refresh_preconditioner(FsiCtx* ctx) {
         if (getenv("FSI_DEBUG")) fprintf(stderr, "[fsi] solid coarse level: lmax %.3f by power iteration (Gershgorin bound %.3f)\n", lam, (double)rowmax);
         ctx->sbmg_clmax = lam;
       }
-      ctx->l3.ready = false;
-      if (ctx->sbmg_ready && ctx->solid_l3) {
-        if (!ctx->l3.built) FSICHK(l3_build(ctx));
-        FSICHK(l3_refresh(ctx));
-      }
       HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
       if (getenv("FSI_DEBUG")) fprintf(stderr, "[fsi] solid two-level: %lld coarse nodes, clmax %.3f, ready %d\n", (long long)ctx->sbmg_nc, rowmax, (int)ctx->sbmg_ready);
     }
@@ -1977,7 +1750,7 @@ int fsi_destroy(FsiCtx* ctx) {
   DevBuf<double>* dbl[] = {&ctx->geom, &ctx->A_pre, &ctx->A, &ctx->LU, &ctx->rowscale, &ctx->U, &ctx->U1, &ctx->F, &ctx->b,
                            &ctx->du, &ctx->bs, &ctx->tmp1, &ctx->tmp2, &ctx->tmp3, &ctx->tmp4, &ctx->tmp5, &ctx->tmp6,
                            &ctx->tmp7, &ctx->scratch, &ctx->bc_vals, &ctx->pf_coef, &ctx->rb_val, &ctx->KZ, &ctx->hcoef,
-                           &ctx->gcr_out, &ctx->gcr_y, &ctx->gcr_cn, &ctx->KQh, &ctx->hcoef_hot, &ctx->cA, &ctx->cP};
+                           &ctx->gcr_out, &ctx->gcr_y, &ctx->gcr_cn, &ctx->KQh, &ctx->hcoef_hot};
   for (auto* b : dbl) b->release();
   ctx->KQ.release(); ctx->A32.release(); ctx->a32_ptr.release(); ctx->a32_cols.release();
   ctx->gcr_slots.release();
@@ -1993,7 +1766,6 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->sbmg_par.release(); ctx->sbmg_ccol.release(); ctx->sbmg_child.release(); ctx->sbmg_cfine.release(); ctx->sbmg_pw.release();
   ctx->sbmg_chw.release(); ctx->sbmg_cvals.release(); ctx->sbmg_cbinv12.release(); ctx->sbmg_work.release(); ctx->sbmg_cptr.release();
   ctx->sbmg_chptr.release(); ctx->sbmg_flag.release(); ctx->sbmg_cflag.release();
-  ctx->l3.release();
   rccl_destroy(ctx);
   ctx->s_vals32.release(); ctx->s_dinv32.release(); ctx->s_work32.release(); ctx->s_rec.release(); ctx->s_dinv.release();
   ctx->s_ploc.release(); ctx->s_tile_uptr.release(); ctx->s_tile_ulist.release();
@@ -2707,16 +2479,6 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
             }
             ctx->sbmg_nc = nsc;
             ctx->sbmg_nblk = (int64_t)sccol.size();
-            if (const char* e = getenv("FSI_SOLID_L3")) ctx->solid_l3 = atoi(e);
-            if (ctx->solid_l3) {                   // what the level-3 set-up (fsi_amg.hip) needs on the host
-              ctx->h_sc_ptr = scptr;
-              ctx->h_sc_col = sccol;
-              ctx->h_sc_xyz.resize(3 * (size_t)nsc);
-              for (int64_t I = 0; I < nsc; ++I) {
-                const int32_t nd = ctx->h_rank2node[ctx->h_snode[scfine[I]]];      // a vertex: nd < V
-                for (int c = 0; c < 3; ++c) ctx->h_sc_xyz[3 * (size_t)I + c] = ctx->h_coords[3 * (size_t)nd + c];
-              }
-            }
             FSICHK(upload(ctx, ctx->sbmg_par, spar));
             FSICHK(upload(ctx, ctx->sbmg_pw, spw));
             FSICHK(upload(ctx, ctx->sbmg_chptr, schptr));
@@ -2819,16 +2581,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   // Krylov space: sized from free memory (the recycled directions are what 288 GB of HBM are used for)
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
-  ctx->spmv_compact = getenv("FSI_SPMV_COMPACT") ? atoi(getenv("FSI_SPMV_COMPACT")) : 0;
-  if (ctx->spmv_compact) {
-    HIPCHK(ctx->cA.alloc((size_t)24 * ctx->h_nadj.size()));
-    HIPCHK(ctx->cP.alloc((size_t)3 * std::max<size_t>(1, ctx->h_padj.size())));
-  }
   ctx->kry_fp32_policy = getenv("FSI_KRYLOV_FP32") ? atoi(getenv("FSI_KRYLOV_FP32")) : 2;
-  if (const char* e = getenv("FSI_KRYLOV_COMPRESS")) {      // "soft:keep", e.g. 128:64
-    int a = 0, b = 0;
-    if (sscanf(e, "%d:%d", &a, &b) == 2 && a > b && b >= 4) { ctx->rz_soft = a; ctx->rz_keep = b; }
-  }
   ctx->kry_fp32 = ctx->kry_fp32_policy == 1;
   ctx->op32_policy = getenv("FSI_OPERATOR_FP32") ? atoi(getenv("FSI_OPERATOR_FP32")) : 1;
   if (ctx->op32_policy && ctx->kry_fp32_policy != 0) {
@@ -3148,17 +2901,6 @@ int fsi_assemble_jacobian(FsiCtx* ctx) {
                          ctx->nmbc, ctx->rowscale.p, ctx->iflags.p + 16);
     HIPCHK(hipGetLastError());
     if (getenv("FSI_DEBUG")) { HIPCHK(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[fsi] matrix finish done\n"); fflush(stderr); }
-    // compact copy of the node rows for the outer product; what it leaves out is checked to vanish on this Jacobian
-    ctx->compact_ok = false;
-    if (ctx->spmv_compact && ctx->cA.p) {
-      HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), ctx->stream));
-      launch_compact_rows(ctx->stream, ctx->N2, ctx->rowptr.p, ctx->nadj_ptr.p, ctx->padj_ptr.p, ctx->A.p, ctx->cA.p, ctx->cP.p, ctx->iflags.p);
-      int32_t fl[4] = {0, 0, 0, 0};
-      HIPCHK(hipMemcpyAsync(fl, ctx->iflags.p, sizeof fl, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-      ctx->compact_ok = fl[0] == 0;
-      HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), ctx->stream));
-    }
   }
   ctx->op32_ok = false;
   if (ctx->op32_policy && ctx->kry_fp32_policy != 0 && ctx->precond == 0 && ctx->A32.p) {
@@ -3523,11 +3265,11 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
                    (int64_t)(ctx->kry_fp32 ? 4 : 8), ctx->ldq, ctx->ldz, ctx->kry_hw, ctx->kry_cap,
                    (int64_t)ctx->s_cols.n, ctx->V, ctx->t_flush.ms, ctx->t_flush.calls, ctx->t_sch.ms, ctx->t_sch.calls,
                    (int64_t)((ctx->schur_fp32 && ctx->s_vals32.p) ? ((ctx->schur_tiled && ctx->sweeps_fp16 && ctx->s_rec.p) ? 0 : 4) : 8),
-                   (int64_t)(ctx->compact_ok && ctx->spmv_compact ? 1 : 0), (int64_t)ctx->h_nadj.size(), (int64_t)ctx->h_padj.size(),
+                   (int64_t)ctx->h_nadj.size(), (int64_t)ctx->h_padj.size(),
                    ctx->op32_products,
                    (int64_t)((ctx->tiled && ctx->fused_sweeps ? 1 : 0) | (ctx->tiled && ctx->fused_sweeps && ctx->sweeps_fp16 ? 2 : 0) |
                              (ctx->solid_fp32 ? 4 : 0) | (ctx->solid_fp32 && ctx->solid_block_jacobi && ctx->solid_fused ? 8 : 0) |
-                             (ctx->sbmg_ready ? 16 : 0) | (ctx->mg_ready ? 32 : 0) | (ctx->l3.ready ? 64 : 0)),
+                             (ctx->sbmg_ready ? 16 : 0) | (ctx->mg_ready ? 32 : 0)),
                    ctx->part_allreduces, (int64_t)ctx->ncellcol, ctx->gcr_arnoldi_steps, ctx->gcr_restarts, ctx->newton_retries,
                    (int64_t)ctx->kry_fp32_failures_total, ctx->verdicts_skipped, ctx->gcr_reorth_forced, ctx->dd_cache_hits,
                    ctx->newton_late_solves};

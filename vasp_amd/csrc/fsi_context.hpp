@@ -39,27 +39,6 @@ struct DevBuf {
   }
 };
 
-// Third level of the solid block's cycle: smoothed aggregation with a dense, explicitly inverted coarsest operator
-// (fsi_amg.hip).  P: frozen prolongator, 3x6 blocks, stored by vertex (pptr / pcol) and by aggregate (tptr / tvert / tblk).
-struct L3Level {
-  bool built = false, usable = false, ready = false;
-  int aggsize = 48, deg = 1, pre = 6, post = 6, cycles = 3;
-  double alpha = 30.0;                         // smoothing interval of the P1 level inside the cycle: [lmax / alpha, lmax]
-  double lmax = 0.0;                           // largest eigenvalue of B^-1 A2 (host power iteration at build time)
-  int true_lmax = 0;                           // 1: the cycle's smoothing interval ends at 1.1 lmax instead of the Gershgorin bound
-  int64_t nagg = 0, nd = 0, ndp = 0, npb = 0, ntrip = 0, npair = 0, nslot = 0;
-  DevBuf<int64_t> pptr, tptr;
-  DevBuf<int32_t> pcol, tvert, tblk, tcol, trip_e, trip_b, trip_t, pair_b, pair_t;
-  DevBuf<float> pval, T, Ainv, r3, x3;
-  DevBuf<double> A3, panelR, panelC, dinv, diag;
-  DevBuf<uint8_t> dead;
-  void release() {
-    pptr.release(); tptr.release(); pcol.release(); tvert.release(); tblk.release(); tcol.release(); trip_e.release();
-    trip_b.release(); trip_t.release(); pair_b.release(); pair_t.release(); pval.release(); T.release(); Ainv.release();
-    r3.release(); x3.release(); A3.release(); panelR.release(); panelC.release(); dinv.release(); diag.release(); dead.release();
-  }
-};
-
 // One colour of the multicolour ordering: `ngroups` groups of `group_rows` consecutive rows starting at `first_row`
 // (6 rows per P2 node for the d/v block, 1 row per vertex for the pressure block).
 struct Level {
@@ -144,9 +123,6 @@ struct FsiCtx {
   fsi::DevBuf<double> A_pre, A, LU;          // [nnz] each; A holds the row-equilibrated Jacobian after setup
   fsi::DevBuf<double> rowscale;              // [ndof]
   bool have_jacobian = false;
-  fsi::DevBuf<double> cA, cP;                // compact node rows of A for the outer product (fsi_solver.hip: k_spmv_compact)
-  bool compact_ok = false;                   // the dropped entries were verified to vanish on the current Jacobian
-  int spmv_compact = 0;                      // FSI_SPMV_COMPACT=1: outer product on the compact node rows (measured slower, see fsi_solver.hip)
 
   // vectors (solver ordering)
   fsi::DevBuf<double> U, U1, F, b, du, bs, tmp1, tmp2, tmp3, tmp4, tmp5, tmp6, tmp7;
@@ -261,11 +237,6 @@ struct FsiCtx {
   fsi::DevBuf<float> sbmg_pw, sbmg_chw, sbmg_cvals, sbmg_cbinv12, sbmg_work;
   fsi::DevBuf<int64_t> sbmg_cptr, sbmg_chptr;
   fsi::DevBuf<uint8_t> sbmg_flag, sbmg_cflag;
-  std::vector<int64_t> h_sc_ptr;             // host copies of the P1 level's pattern and vertex coordinates (level-3 set-up)
-  std::vector<int32_t> h_sc_col;
-  std::vector<double> h_sc_xyz;
-  fsi::L3Level l3;                           // FSI_SOLID_L3=1: two-grid cycles with the dense aggregate level instead of sbmg_cits plain sweeps
-  int solid_l3 = 0;                          // measured in round 3: no gain over plain sweeps on a correct interval
   int sbmg_pre = 16, sbmg_post = 16, sbmg_cits = 90;      // round 2: 200 coarse sweeps on an interval that ended at 2.2x the largest eigenvalue
   double sbmg_alpha = 200.0, sbmg_ckappa = 4000.0, sbmg_clmax = 2.0;
   int64_t nfs = 0;                           // fluid-interior velocity rows with solid columns (coupling of the predictor)
@@ -345,19 +316,6 @@ struct FsiCtx {
   bool dd_same = false, dd_checksum_valid = false;   // this refresh found the displacement block unchanged / a checksum exists
   int64_t dd_cache_hits = 0;                 // refreshes that kept the displacement block's coarse operator and eigenvalue estimate
   double lmax_d_cached = 0.0, dd_checksum[3] = {0.0, 0.0, 0.0};   // largest eigenvalue of the (constant) displacement block, and what it was computed for
-  // Compression of the kept Krylov space (FSI_KRYLOV_COMPRESS="soft:keep", off by default): when more
-  // than `soft` directions are kept at the end of a solve they are replaced by `keep` combinations - the part of the space
-  // on which the preconditioned operator B = A M^-1 deviates most from the identity (dominant right singular vectors of
-  // Q^T (B - I) Q, which the Gram-Schmidt coefficients give for free: B q_k = (B r_k - B r_{k+1}) / alpha_k) plus the last
-  // solutions.  rz_C[i + cap j] = q_i . B q_j, rz_known[j]: column j is known.
-  int rz_soft = 0, rz_keep = 0;
-  std::vector<double> rz_C, rz_prev_h, rz_a;
-  std::vector<uint8_t> rz_known;
-  std::vector<std::vector<double>> rz_sols;
-  int rz_prev_slot = -1;
-  double rz_prev_alpha = 0.0;
-  int64_t rz_compressions = 0;
-  fsi::DevBuf<double> rz_coef;
   int64_t part_allreduces = 0;               // partitioned runs: all-reduces issued inside the Krylov iterations (tests count them)
   int kry_fp32_failures = 0;                 // cycles that lost the system in FP32 storage (policy 2 -> 3); two of them pin FP64
   double tol_hint = 0.0, bnorm_max = 0.0;     // fsi_newton_solve -> solve_gcr: lowest linear tolerance to expect; largest |b| seen
@@ -367,7 +325,7 @@ struct FsiCtx {
   int64_t newton_late_solves = 0;
   // Two chains of one preconditioner application side by side (FSI_PREC_STREAMS=1; precondition_block): stream A = solver
   // stream: split, solid predictor, displacement block, merge; stream B: fluid predictor, pressure step, velocity correction.
-  int prec_streams = 0;
+  int prec_streams = 1;                      // FSI_PREC_STREAMS=0: one chain on the solver stream (rounds 1-3)
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_split = nullptr, ev_solid = nullptr, ev_b = nullptr;
   int dd_early = 0;                          // FSI_DD_EARLY=1: displacement rhs from the solid predictor (measurement)

@@ -228,29 +228,6 @@ __global__ __launch_bounds__(256) void k_gcr_flush(double* __restrict__ Z, int64
   }
 }
 
-// Compression of the kept space (solve-time bookkeeping in fsi_capi.hip: gcr_compress): KN new columns, each a combination
-// of the m old ones,  out_k = sum_j c[k * m + j] in_j  - one pass over the m input columns serves all KN outputs.  Inputs
-// and outputs are columns of the same store (outputs go to columns past the inputs, then move down).
-template <class T, int KN>
-__global__ __launch_bounds__(256) void k_gcr_combine(const T* __restrict__ S, int64_t ld, int64_t n, int m, const double* __restrict__ c,
-                                                     int knew, int64_t out0) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
-    double acc[KN];
-#pragma unroll
-    for (int k = 0; k < KN; ++k) acc[k] = 0.0;
-#pragma unroll 4
-    for (int j = 0; j < m; ++j) {
-      const double v = (double)S[(int64_t)j * ld + i];
-#pragma unroll
-      for (int k = 0; k < KN; ++k) acc[k] += c[(int64_t)k * m + j] * v;
-    }
-#pragma unroll
-    for (int k = 0; k < KN; ++k)
-      if (k < knew) const_cast<T*>(S)[(out0 + k) * ld + i] = (T)acc[k];
-  }
-}
-
 template <class QT>
 void dots_t(hipStream_t st, const void* Q, int64_t ldq, int64_t n, int m, const double* w, const double* r,
             double* scratch, double* out) {
@@ -306,14 +283,6 @@ void launch_gcr_update(hipStream_t st, bool fp32, void* Q, int64_t ldq, double* 
                        double* scratch, double* out1) {
   if (fp32) update_t<float>(st, Q, ldq, Z, ldz, slot, n, w, z, inv_wn, alpha, r, qd, scratch, out1);
   else update_t<double>(st, Q, ldq, Z, ldz, slot, n, w, z, inv_wn, alpha, r, qd, scratch, out1);
-}
-// columns [out0, out0 + knew) of the store = combinations c (knew x m, row-major) of columns [0, m); knew <= 32 per call
-void launch_gcr_combine(hipStream_t st, int elem_bytes, void* S, int64_t ld, int64_t n, int m, const double* c, int knew, int64_t out0) {
-  int64_t blocks = (n + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  const dim3 g((unsigned)blocks), b(256);
-  if (elem_bytes == 4) hipLaunchKernelGGL((k_gcr_combine<float, 32>), g, b, 0, st, static_cast<const float*>(S), ld, n, m, c, knew, out0);
-  else hipLaunchKernelGGL((k_gcr_combine<double, 32>), g, b, 0, st, static_cast<const double*>(S), ld, n, m, c, knew, out0);
 }
 int gcr_flush_width(int knew) { return knew <= 0 ? 0 : knew <= 4 ? 4 : knew <= 8 ? 8 : knew <= 16 ? 16 : 32; }
 void launch_gcr_flush(hipStream_t st, double* Z, int64_t ldz, int64_t n, int m, const double* y, const double* cn,

@@ -111,11 +111,6 @@ int rccl_allreduce_dev(FsiCtx* ctx, double* dptr, int64_t n);   // in place, dev
 int rccl_allreduce_host(FsiCtx* ctx, double* v, int n);         // host values through a staging buffer (one wait)
 int rccl_halo(FsiCtx* ctx);                                     // sendbuf -> peers' recvbuf, grouped send / recv
 
-// fsi_amg.hip — dense third level of the solid block's cycle (see there)
-int l3_build(FsiCtx* ctx);                                   // once per context: aggregates + frozen smoothed prolongator (host)
-int l3_refresh(FsiCtx* ctx);                                 // every Jacobian: Galerkin operator + explicit inverse (device)
-void l3_correct(FsiCtx* ctx, const float* r4, float* e4);    // e = P A3^-1 P^T r, three launches
-
 // fsi_post.hip — solid stress / strain and wall shear stress (cell-local DG1 projections)
 hipError_t upload_post_tables(const double* qw, const double* dN, const double* L);
 void launch_stress_strain(hipStream_t st, int64_t ncell, const ElemArrays& ea, const ElemParams& ep, const double* U,
@@ -174,7 +169,6 @@ void launch_gcr_update(hipStream_t st, bool fp32, void* Q, int64_t ldq, double* 
                        const double* w, const double* z, double inv_wn, double alpha, double* r, double* qd,
                        double* scratch, double* out1);
 // x += sum_j y[j] Z_j; Z_slots[k] = sum_j cn[k * m + j] Z_j for k < knew (<= 32); cn has gcr_flush_width(knew) columns
-void launch_gcr_combine(hipStream_t st, int elem_bytes, void* S, int64_t ld, int64_t n, int m, const double* c, int knew, int64_t out0);
 int gcr_flush_width(int knew);
 void launch_gcr_flush(hipStream_t st, double* Z, int64_t ldz, int64_t n, int m, const double* y, const double* cn,
                       const int32_t* slots, int knew, double* x);
@@ -275,15 +269,6 @@ void launch_residual_rows(hipStream_t st, int64_t nrows, const int32_t* rows, co
                           const int64_t* src, const double* vals, const double* x, const double* b, double* y);
 void launch_spmv_node6(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const double* vals,
                        const double* x, double* y);
-// compact node rows (24 of 36 entries per node pair, no pressure columns in the d-rows): built after matrix_finish
-void launch_compact_rows(hipStream_t st, int64_t N2, const int64_t* rowptr, const int64_t* nadj_ptr, const int64_t* padj_ptr,
-                         const double* A, double* cA, double* cP, int32_t* flags);
-void launch_spmv_compact(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const double* A,
-                         const int64_t* nadj_ptr, const int32_t* nadj, const int64_t* padj_ptr, const int32_t* padj,
-                         const double* cA, const double* cP, const double* x, double* y);
-void launch_spmv_mono(hipStream_t st, int64_t n, int64_t N2, const int64_t* rowptr, const int64_t* nadj_ptr,
-                      const int32_t* nadj, const int64_t* padj_ptr, const int32_t* padj, const int32_t* vrank,
-                      const double* vals, const double* x, double* y);
 void launch_sweep_csr_f32(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const float* vals,
                           const float* dinv, float c1, float c2, const float* din, float* dout, float* x, float* r);
 void launch_csr_dinv_f32(hipStream_t st, int64_t n, const int64_t* diagpos, const double* A, float* dinv);

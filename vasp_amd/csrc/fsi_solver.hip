@@ -201,33 +201,6 @@ __global__ __launch_bounds__(256) void k_spmv(int64_t n, const int64_t* __restri
     if (lane == 0) y[row] = sum;
   }
 }
-// Monolithic SpMV without the column array: a row of node r is [for every neighbour node s: columns 6s..6s+5][pressure
-// columns of r's vertex neighbours] (k_expand_cols), so the column of entry t is 6 nadj[t / 6] + t % 6 - one 4-byte index
-// per SIX entries instead of one per entry (12 -> 8.7 bytes per stored entry).
-__global__ __launch_bounds__(256) void k_spmv_mono(int64_t n, int64_t N2, const int64_t* __restrict__ rowptr,
-                                                   const int64_t* __restrict__ nadj_ptr, const int32_t* __restrict__ nadj,
-                                                   const int64_t* __restrict__ padj_ptr, const int32_t* __restrict__ padj,
-                                                   const int32_t* __restrict__ vrank, const double* __restrict__ vals,
-                                                   const double* __restrict__ x, double* __restrict__ y) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const int64_t n6 = 6 * N2;
-  for (int64_t row = wave; row < n; row += nwaves) {
-    const int32_t r = row >= n6 ? vrank[row - n6] : (int32_t)(row / 6);
-    const int64_t s = rowptr[row], a = nadj_ptr[r], pa = padj_ptr[r];
-    const int nd = 6 * (int)(nadj_ptr[r + 1] - a), np = (int)(padj_ptr[r + 1] - pa);
-    const double* v = vals + s;
-    double sum = 0.0;
-    for (int t = lane; t < nd; t += 64) {
-      const int nb = t / 6;
-      sum += v[t] * x[6 * (int64_t)nadj[a + nb] + (t - 6 * nb)];
-    }
-    for (int t = lane; t < np; t += 64) sum += v[nd + t] * x[n6 + padj[pa + t]];
-    sum = wave_sum(sum);
-    if (lane == 0) y[row] = sum;
-  }
-}
 // Monolithic SpMV, velocity / displacement rows: the six rows of a node share their column pattern (k_expand_cols), so
 // one wave takes a node, reads the column indices and gathers x ONCE and streams the six value rows against them -
 // 8 + 4/6 instead of 12 bytes per entry, a sixth of the gathers, and six independent value streams in flight per lane.
@@ -265,106 +238,6 @@ __global__ __launch_bounds__(256) void k_spmv_node6(int64_t N2, const int64_t* _
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3); a4 = wave_sum(a4); a5 = wave_sum(a5);
     if (lane == 0) { double* o = y + 6 * r; o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5; }
-  }
-}
-// Compact form of the node rows of the monolithic Jacobian.  Per node pair the 6x6 block [d;v] x [d;v] of the forms of
-// SURVEY.md A.2 has structure: the d-rows carry only a component-diagonal A_dd (solid: penalised mass; fluid: the Laplace
-// lifting) and a component-diagonal A_dv (solid: -delta rho theta M; fluid: zero), and no pressure columns; the v-rows are
-// full (shape derivatives, convection, stress).  So 24 of the 36 entries can be non-zero, and the d-rows have no pressure
-// entries: 8.9 GB instead of 15 GB per product on the 1.12 M-tet mesh.  Layout per node r with L neighbours (SoA, like
-// the six value rows of k_spmv_node6): cA[24 nadj_ptr[r] + k L + t], k = 0..2 dd_c, 3..5 dv_c, 6..14 vd[c][j], 15..23
-// vv[c][j]; cP[3 padj_ptr[r] + c np + u] the pressure columns of the three v-rows.
-// k_compact_rows verifies what it drops: flags[0] |= 1 if a dropped entry exceeds 1e-13 (rows are equilibrated to max 1).
-// Measured on MI355X (1.12 M tets, 20-step bench): 3.46 ms per product against 3.20 ms for k_spmv_node6 on the full rows,
-// with 12.7 GB of HBM traffic (PMC, calibrated) against 19 GB - fewer bytes, but 24 short (27-element) value runs per node
-// and the gathers of x leave the half-waves waiting on latency.  Kept behind FSI_SPMV_COMPACT=1; the default stays node6.
-__global__ __launch_bounds__(256) void k_compact_rows(int64_t N2, const int64_t* __restrict__ rowptr,
-                                                      const int64_t* __restrict__ nadj_ptr, const int64_t* __restrict__ padj_ptr,
-                                                      const double* __restrict__ A, double* __restrict__ cA,
-                                                      double* __restrict__ cP, int32_t* __restrict__ flags) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t r = wave; r < N2; r += nwaves) {
-    const int64_t s0 = rowptr[6 * r], Lr = rowptr[6 * r + 1] - s0;
-    const int64_t a = nadj_ptr[r], L = nadj_ptr[r + 1] - a, pa = padj_ptr[r], np = padj_ptr[r + 1] - pa;
-    double* ca = cA + 24 * a;
-    double dropped = 0.0;
-    for (int64_t t = lane; t < L; t += 64) {
-      for (int c = 0; c < 3; ++c) {
-        const double* row = A + s0 + c * Lr + 6 * t;                 // d-row c
-        for (int j = 0; j < 6; ++j) {
-          const double v = row[j];
-          if (j == c) ca[c * L + t] = v;
-          else if (j == 3 + c) ca[(3 + c) * L + t] = v;
-          else dropped = fmax(dropped, fabs(v));
-        }
-        const double* vrow = A + s0 + (3 + c) * Lr + 6 * t;           // v-row c
-        for (int j = 0; j < 3; ++j) { ca[(6 + 3 * c + j) * L + t] = vrow[j]; ca[(15 + 3 * c + j) * L + t] = vrow[3 + j]; }
-      }
-    }
-    for (int64_t u = lane; u < np; u += 64)
-      for (int c = 0; c < 3; ++c) {
-        dropped = fmax(dropped, fabs(A[s0 + c * Lr + 6 * L + u]));
-        cP[3 * pa + c * np + u] = A[s0 + (3 + c) * Lr + 6 * L + u];
-      }
-    dropped = wave_max(dropped);
-    if (lane == 0 && dropped > 1e-13) atomicOr(&flags[0], 1);
-  }
-}
-__global__ __launch_bounds__(256) void k_spmv_compact(int64_t N2, const int64_t* __restrict__ nadj_ptr,
-                                                      const int32_t* __restrict__ nadj, const int64_t* __restrict__ padj_ptr,
-                                                      const int32_t* __restrict__ padj, const double* __restrict__ cA,
-                                                      const double* __restrict__ cP, const double* __restrict__ x,
-                                                      double* __restrict__ y) {
-  // half a wave per node: a node has ~27 neighbours, a full wave would leave most lanes idle
-  const int lane = threadIdx.x & 31;
-  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 5;
-  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 5;
-  const double* xp = x + 6 * N2;
-  for (int64_t r = grp; r < N2; r += ngrp) {
-    const int64_t a = nadj_ptr[r], L = nadj_ptr[r + 1] - a;
-    const double* v = cA + 24 * a;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
-    for (int64_t t = lane; t < L; t += 32) {
-      const double2* xb = reinterpret_cast<const double2*>(x + 6 * (int64_t)nadj[a + t]);
-      const double2 x01 = xb[0], x23 = xb[1], x45 = xb[2];          // d_x d_y | d_z v_x | v_y v_z of the neighbour
-      const double d0 = x01.x, d1 = x01.y, d2 = x23.x, u0 = x23.y, u1 = x45.x, u2 = x45.y;
-      a0 += v[t] * d0 + v[3 * L + t] * u0;
-      a1 += v[L + t] * d1 + v[4 * L + t] * u1;
-      a2 += v[2 * L + t] * d2 + v[5 * L + t] * u2;
-      a3 += (v[6 * L + t] * d0 + v[7 * L + t] * d1 + v[8 * L + t] * d2) + (v[15 * L + t] * u0 + v[16 * L + t] * u1 + v[17 * L + t] * u2);
-      a4 += (v[9 * L + t] * d0 + v[10 * L + t] * d1 + v[11 * L + t] * d2) + (v[18 * L + t] * u0 + v[19 * L + t] * u1 + v[20 * L + t] * u2);
-      a5 += (v[12 * L + t] * d0 + v[13 * L + t] * d1 + v[14 * L + t] * d2) + (v[21 * L + t] * u0 + v[22 * L + t] * u1 + v[23 * L + t] * u2);
-    }
-    const int64_t pa = padj_ptr[r], np = padj_ptr[r + 1] - pa;
-    const double* w = cP + 3 * pa;
-    for (int64_t u = lane; u < np; u += 32) {
-      const double pv = xp[padj[pa + u]];
-      a3 += w[u] * pv; a4 += w[np + u] * pv; a5 += w[2 * np + u] * pv;
-    }
-    for (int off = 16; off > 0; off >>= 1) {
-      a0 += __shfl_xor(a0, off, 32); a1 += __shfl_xor(a1, off, 32); a2 += __shfl_xor(a2, off, 32);
-      a3 += __shfl_xor(a3, off, 32); a4 += __shfl_xor(a4, off, 32); a5 += __shfl_xor(a5, off, 32);
-    }
-    if (lane == 0) { double* o = y + 6 * r; o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5; }
-  }
-}
-void launch_compact_rows(hipStream_t st, int64_t N2, const int64_t* rowptr, const int64_t* nadj_ptr, const int64_t* padj_ptr,
-                         const double* A, double* cA, double* cP, int32_t* flags) {
-  int64_t blocks = (N2 + 3) / 4;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(k_compact_rows, dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, nadj_ptr, padj_ptr, A, cA, cP, flags);
-}
-void launch_spmv_compact(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const double* A,
-                         const int64_t* nadj_ptr, const int32_t* nadj, const int64_t* padj_ptr, const int32_t* padj,
-                         const double* cA, const double* cP, const double* x, double* y) {
-  int64_t blocks = (N2 + 7) / 8;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(k_spmv_compact, dim3((unsigned)blocks), dim3(256), 0, st, N2, nadj_ptr, nadj, padj_ptr, padj, cA, cP, x, y);
-  if (V > 0) {                                                  // pressure rows: the generic kernel on the tail of the full matrix
-    int64_t pb = (V + 3) / 4;
-    hipLaunchKernelGGL(k_spmv<SPMV_MONOLITHIC>, dim3((unsigned)pb), dim3(256), 0, st, V, rowptr + 6 * N2, cols, A, x, y + 6 * N2);
   }
 }
 template <class VT>
@@ -491,14 +364,6 @@ void launch_round_to_f32(hipStream_t st, int64_t n, const double* a, float* b) {
   int64_t blocks = (n + 255) / 256;
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(k_round_to_f32, dim3((unsigned)blocks), dim3(256), 0, st, n, a, b);
-}
-void launch_spmv_mono(hipStream_t st, int64_t n, int64_t N2, const int64_t* rowptr, const int64_t* nadj_ptr,
-                      const int32_t* nadj, const int64_t* padj_ptr, const int32_t* padj, const int32_t* vrank,
-                      const double* vals, const double* x, double* y) {
-  int64_t blocks = (n + 3) / 4;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(k_spmv_mono, dim3((unsigned)blocks), dim3(256), 0, st, n, N2, rowptr, nadj_ptr, nadj, padj_ptr, padj,
-                     vrank, vals, x, y);
 }
 void launch_spmv(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const double* vals,
                  const double* x, double* y, int tag) {
