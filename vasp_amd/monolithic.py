@@ -207,12 +207,14 @@ def default_backend(desc):
     if world > 1:
         import torch
         from .dist import init_from_env
-        from .partition import DistBackend
+        from .partition import DistBackend, start_driver
         rank, local_rank, world, dist = init_from_env(backend=os.environ.get("VASPFSI_DIST_BACKEND"))
         if os.environ.get("VASPFSI_ONE_GPU"):
             local_rank = 0
         torch.cuda.set_device(local_rank)
-        return DistBackend(desc, dist, device=local_rank)
+        if os.environ.get("VASPFSI_SYMMETRIC"):          # rounds 1-3: every rank read the mesh and ran the hooks
+            return DistBackend(desc, dist, device=local_rank)
+        return start_driver(desc, dist, device=local_rank)       # this is rank 0: the other ranks are in run_worker (see run)
     from .capi import HipBackend   # raises loudly if libvaspfsi.so or the GPU is missing
     return HipBackend(desc)
 
@@ -367,6 +369,22 @@ def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_ba
     import io
     import os
     rank0 = _rank() == 0
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    driver_mode = world > 1 and backend_factory is default_backend and not os.environ.get("VASPFSI_SYMMETRIC")
+    if driver_mode and not rank0:
+        # Ranks 1 .. N-1 of `python -m torch.distributed.run --nproc-per-node N -m vasp_amd.monolithic ...`: they never read the
+        # mesh, build no function space and run no hook; rank 0 sends each its part of the element partition (as DOLFIN
+        # distributes a mesh it read once [REF src/vasp/simulations/offset_stenosis.py:20-23]) and announces every collective
+        # call of the time loop (vasp_amd/partition.py: start_driver / run_worker).
+        import torch
+        from .dist import init_from_env
+        from .partition import run_worker
+        _, local_rank, _, dist = init_from_env(backend=os.environ.get("VASPFSI_DIST_BACKEND"))
+        if os.environ.get("VASPFSI_ONE_GPU"):
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        run_worker(dist, device=local_rank)
+        return {"worker": True}
     if not rank0:                                 # the reference guards its prints with MPI.rank == 0
         out = lambda *a, **k: None
     quiet = contextlib.nullcontext() if rank0 else contextlib.redirect_stdout(io.StringIO())
@@ -375,6 +393,20 @@ def run(argv: Optional[List[str]] = None, backend_factory: Callable = default_ba
     state = ns["_state"]
     backend = backend_factory(desc)
     ns["backend"] = backend
+    if driver_mode:
+        # whatever ends this function - the last time step or an exception in a hook or in the solver - the workers' serve
+        # loops must end with it
+        try:
+            return _time_loop(ns, backend, bc_values, pressure, hook, out, rank0, quiet)
+        finally:
+            with contextlib.suppress(Exception):
+                backend.close()
+    return _time_loop(ns, backend, bc_values, pressure, hook, out, rank0, quiet)
+
+
+def _time_loop(ns, backend, bc_values, pressure, hook, out, rank0, quiet):
+    """The part of ``run`` behind the backend's construction: restart, the time loop, output, ``finished``."""
+    state = ns["_state"]
     mesh = ns["mesh"]
     for which, fn in ns["dvp_"].items():          # per-step diagnostics of post_solve run on the device
         fn.backend, fn.which = backend, which
