@@ -87,10 +87,70 @@ typedef struct FsiNewtonIter {
   double lin_relres;           /* achieved ||r||/||b||                                                      */
 } FsiNewtonIter;
 
+/* ---- tuning ---------------------------------------------------------------------------------------- */
+/* Every product option of a context in one place: storage precisions, sizes, Newton / Krylov policy, the preconditioner's
+ * structure and sweep counts (DESIGN.md sections 4 - 5 give the measurement behind each default).  fsi_tuning_defaults fills
+ * the defaults; fsi_create takes the defaults with the developer overrides of the environment applied (FSI_<NAME> for the
+ * field <name>, parsed in ONE function: csrc/fsi_tuning.hip; debugging aids FSI_DEBUG* are not options and stay environment
+ * only); fsi_create_tuned takes the struct as given.  The reference has no counterpart: its linear solver is
+ * `linear_solver="mumps"` [REF src/vasp/simulations/offset_stenosis.py:45]. */
+typedef struct FsiTuning {
+  int32_t struct_size;         /* sizeof(FsiTuning) of the caller: a library built with a longer struct fills the rest with defaults */
+  /* storage precisions (all arithmetic on the Newton level and every linear-solve verdict is FP64 whatever these say) */
+  int32_t krylov_fp32;         /* Krylov basis Q: 0 FP64, 1 FP32, 2 decided per Jacobian lifetime from the tolerances asked for    */
+  int32_t operator_fp32;       /* 1: products inside Krylov iterations on an FP32 copy of the Jacobian values (with an FP32 basis) */
+  int32_t schur_fp32;          /* 1: Schur-complement sweeps on FP16 / FP32 matrix values (vectors FP64); 0: FP64 values           */
+  int32_t sweeps_fp32;         /* 1: velocity / displacement block sweeps in FP32 vectors                                          */
+  int32_t sweeps_fp16;         /* 1: fine-level sweep matrices as packed FP16 records                                              */
+  int32_t solid_fp32;          /* 1: solid velocity block as FP32 3x3 block-CSR                                                    */
+  int32_t pv_fp32;             /* 1: FP32 node-form copies of A_vp / A_pv for the two block products of the pressure step          */
+  int32_t krylov_capacity;     /* kept directions per Jacobian lifetime (bounded by half of the free HBM)                          */
+  double krylov_fp32_floor;    /* krylov_fp32 == 2: FP32 basis iff the lowest linear tolerance the lifetime can be asked for is    */
+                               /* above this.  1e-10 since round 4 (1e-7 before): with the columns kept orthonormal (round 3) the  */
+                               /* FP32 basis + restarts from the FP64 residual reach 1e-11 on the golden runs, and the aneurysm    */
+                               /* problem at its own tolerances (1e-10 / 1e-9) runs 28 % faster (profiles/r04_aneurysm_fp32.txt)   */
+  /* assembly and numbering */
+  int32_t assembly_atomic;     /* 0: bitwise reproducible assembly (per-dof gather, cell colours); 1: unordered atomics            */
+  int32_t node_order;          /* 0: Morton curve (default), 1: the mesh's order, 2: multicolour (needed by precond = 1)           */
+  int32_t tiles;               /* 1: LDS-tiled sweep kernels                                                                        */
+  int32_t jacobian_waves;      /* waves per SIMD the refresh kernel's register budget is set for (1 | 2)                           */
+  int32_t jacobian_mfma;       /* 1: element contraction of the refresh kernel on v_mfma_f64_16x16x4 (k_jacobian_mfma; measured    */
+                               /*    slower in round 4: 103 against 70 ms per refresh at 1.12 M tets)                              */
+  /* Newton / Krylov policy */
+  double newton_forcing;       /* linear tolerance = forcing * atol / |b| (0: every system to lin_rtol)                            */
+  double newton_forcing_late;  /* ... of late Newton iterations (previous update within newton_late_factor of its tolerance)       */
+  double newton_late_factor;
+  double f32_cycle_floor;      /* FP32 basis: a cycle reduces the residual by at most this factor before the FP64 verdict          */
+  double f32_verdict_skip_rtol;/* FP32 basis, inside fsi_newton_solve: answers asked for at or above this may skip the verdict     */
+  double orth_floor32, orth_floor64;   /* estimated orthogonality error of a new column that forces a second Gram-Schmidt pass     */
+  double gcr_escape;           /* alpha^2 <= this |r|^2: the next direction is made from the last q instead of r                   */
+  double gcr_reorth;           /* second Gram-Schmidt pass when |w'| < reorth |w| (0: automatic)                                   */
+  /* block preconditioner */
+  int32_t prec_streams;        /* 1: two chains of an application side by side on two HIP streams                                  */
+  int32_t cheb4;               /* bit 0 / 1 / 2: 4th-kind Chebyshev sweeps in the solid cycle / displacement cycle / Schur solve   */
+  int32_t coarse_power;        /* 1: coarse-level Chebyshev intervals from a power iteration (0: Gershgorin bound)                 */
+  int32_t solid_mg, dd_mg;     /* two-level (P2 -> P1) cycles of the solid velocity block / the displacement block                 */
+  int32_t mg_keep;             /* 1: keep the displacement block's coarse operator while three checksums say it is unchanged       */
+  int32_t solid_block_jacobi, solid_fused, fused_sweeps, scalar_dd;
+  int32_t its_solid, its_fluid, its_schur, its_disp;          /* sweeps (solid / disp: one-level fallbacks)                         */
+  double kappa_solid, kappa_fluid, kappa_schur, kappa_disp;   /* assumed condition numbers of the Chebyshev intervals              */
+  int32_t sbmg_pre, sbmg_post, sbmg_cits;                     /* solid cycle: smoothing sweeps before / after, coarse sweeps       */
+  double sbmg_alpha, sbmg_ckappa;                             /* ... smoothing interval [lmax / alpha, lmax], coarse kappa         */
+  int32_t mg_pre, mg_post, mg_cits;                           /* displacement cycle                                                */
+  double mg_alpha, mg_ckappa;
+} FsiTuning;
+void fsi_tuning_defaults(FsiTuning* t);
+/* the defaults with the FSI_<NAME> variables of the environment applied (what fsi_create uses) */
+void fsi_tuning_from_env(FsiTuning* t);
+
 /* ---- lifetime ------------------------------------------------------------------------------------ */
 /* Replaces: space / form set-up up to solver_setup() (A_pre assembled at the zero state). `device` is the
  * HIP device ordinal. */
 int fsi_create(const FsiMeshDesc* mesh, const FsiParams* params, int device, FsiCtx** out);
+/* fsi_create with an explicit FsiTuning (the environment is not consulted).  tuning == NULL: the defaults. */
+int fsi_create_tuned(const FsiMeshDesc* mesh, const FsiParams* params, int device, const FsiTuning* tuning, FsiCtx** out);
+/* the tuning the context was created with */
+int fsi_get_tuning(const FsiCtx* ctx, FsiTuning* out);
 int fsi_destroy(FsiCtx* ctx);
 const char* fsi_last_error(const FsiCtx* ctx);
 
@@ -112,11 +172,14 @@ int fsi_set_robin_facets(FsiCtx* ctx, int64_t nf, const int32_t* facet_nodes, co
  * lin_rtol) for parity runs, the default 1e-2 leaves the Newton iteration counts of the bench unchanged and saves the
  * Krylov iterations that would polish an update far below the Newton tolerance. */
 int fsi_set_newton_forcing(FsiCtx* ctx, double forcing);
-/* Replaces: `linear_solver="mumps"` [REF offset_stenosis.py:45].  precond 0 = field-split block preconditioner
- * (velocity/pressure SIMPLE split with the solid displacement eliminated, then the displacement block; inner ILU(0)
- * BiCGStab solves to `inner_rtol` within `inner_max_it` iterations), 1 = multicolour ILU(0) of the monolithic matrix.
- * Non-positive inner_rtol / inner_max_it keep the current values. */
-int fsi_set_linear_solver(FsiCtx* ctx, int32_t precond, double inner_rtol, int32_t inner_max_it);
+/* Replaces: `linear_solver="mumps"` [REF offset_stenosis.py:45].  precond 0 = field-split block preconditioner (velocity /
+ * pressure SIMPLE split with the solid displacement eliminated, then the displacement block; every inner solve a fixed number
+ * of Jacobi-Chebyshev sweeps), 1 = multicolour ILU(0) of the monolithic matrix (needs the context created with
+ * FSI_ORDER=colour).  With FsiNewtonOpts.lin_solver (0 recycled GCR, 1 BiCGStab) that makes four pairs; tested on MI355X
+ * (tests/test_gpu_parity.py::test_bicgstab_and_ilu0_solve_match_sparse_lu): GCR + field split (the default) and each option
+ * with the other's default partner converge to 1e-10; BiCGStab + ILU(0) together stagnates on the FSI Jacobian (a saddle
+ * point with 1e7 penalty rows) and is recorded there as a strict xfail. */
+int fsi_set_linear_solver(FsiCtx* ctx, int32_t precond);
 /* Sweep counts and assumed condition numbers of the Chebyshev solves inside the block preconditioner (solid and
  * fluid-interior part of the velocity block, pressure Schur complement).  Non-positive arguments keep the current value.
  * Defaults: solid 300 / 1e4 (one-level fallback; default: two-level cycle), fluid 4 / 5, Schur 40 / 1e2, displacement 60 / 1e3 (one-level fallback; the default

@@ -13,7 +13,7 @@ HEADER = (ROOT / "include" / "vaspfsi.h").read_text()
 
 
 def declared_functions():
-    return sorted(set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(fsi_\w+)\s*\(", HEADER, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|int64_t|void|const char\*)\s+(fsi_\w+)\s*\(", HEADER, flags=re.M)))
 
 
 def test_every_declared_symbol_is_exported():
@@ -33,11 +33,40 @@ def test_struct_layouts_match_header():
         return [part.strip().split()[-1].lstrip("*") for f in body.split(";") if f.strip() for part in f.split(",")]
     for name, cls in (("FsiMeshDesc", capi.FsiMeshDesc), ("FsiParams", capi.FsiParams),
                       ("FsiNewtonOpts", capi.FsiNewtonOpts), ("FsiNewtonIter", capi.FsiNewtonIter), ("FsiTimers", capi.FsiTimers),
+                      ("FsiTuning", capi.FsiTuning),
                       ("FsiStepStats", getattr(capi, "FsiStepStats", None))):
         if cls is None:
             continue
         assert [f for f, _ in cls._fields_] == fields(name), name
     assert ctypes.sizeof(capi.FsiNewtonIter) == 32
+
+
+def test_tuning_defaults_and_environment_overrides(monkeypatch):
+    """FsiTuning (round 4): one documented struct instead of ~80 getenv switches.  The library fills the
+    defaults, FSI_<NAME> overrides a field in ONE place (csrc/fsi_tuning.hip), the ctypes struct has the library's size, and
+    no product option is read from the environment anywhere else in the library's sources."""
+    lib = capi.load_library()
+    t = capi.FsiTuning()
+    lib.fsi_tuning_defaults(ctypes.byref(t))
+    assert t.struct_size == ctypes.sizeof(capi.FsiTuning)
+    d = t.as_dict()
+    assert (d["krylov_fp32"], d["krylov_capacity"], d["prec_streams"], d["its_schur"], d["newton_forcing"]) == (2, 600, 1, 30, 1e-2)
+    assert d["newton_forcing_late"] == 3e-3 and d["assembly_atomic"] == 0 and d["node_order"] == 0 and d["jacobian_mfma"] == 0
+    monkeypatch.setenv("FSI_KRYLOV_FP32", "0")
+    monkeypatch.setenv("FSI_ORDER", "colour")
+    monkeypatch.setenv("FSI_ASSEMBLY", "atomic")
+    monkeypatch.setenv("FSI_CHEB_P", "24")
+    monkeypatch.setenv("FSI_NEWTON_FORCING_LATE", "1e-3")
+    e = capi.FsiTuning()
+    lib.fsi_tuning_from_env(ctypes.byref(e))
+    assert (e.krylov_fp32, e.node_order, e.assembly_atomic, e.its_schur, e.newton_forcing_late) == (0, 2, 1, 24, 1e-3)
+    assert e.krylov_capacity == 600                                        # untouched fields keep their defaults
+    # the only getenv calls outside fsi_tuning.hip are debugging aids
+    for src in (ROOT / "vasp_amd" / "csrc").glob("*.h*"):
+        if src.name == "fsi_tuning.hip":
+            continue
+        for m in re.finditer(r'getenv\("(\w+)"\)', src.read_text()):
+            assert m.group(1).startswith("FSI_DEBUG") or m.group(1) == "FSI_RCCL_HOST_REDUCE", (src.name, m.group(1))
 
 
 def test_error_codes_match_header():

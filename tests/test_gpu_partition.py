@@ -148,8 +148,11 @@ def test_partitioned_steps_match_single_context(world, transport, which, tmp_pat
     # repeats its Gram-Schmidt pass; round 2's count for the same run would have been 3 per pass-pair + 1 = ~750
     # (the aneurysm and avf systems cancel w more often: up to two passes per iteration + the confirming reduction; measured
     # on MI355X: 831 for 444 iterations, 2050 for 715)
-    per_it = 1.6 if which == "cylinder" else 3.0
-    assert comm["q_bytes"] == 8 and comm["allreduces"] <= per_it * comm["krylov"] + 2 * comm["solves"], comm
+    # (a Jacobian refreshed at a state that is already converged to round-off sees right-hand sides of ~1e-12, for which the
+    # forcing term asks loose tolerances: that lifetime may then legitimately choose the FP32 basis - seen on the avf run -,
+    # whose passes take two reductions + the window's)
+    per_it = 1.6 if which == "cylinder" else 3.0 if comm["q_bytes"] == 8 else 5.0
+    assert (comm["q_bytes"] == 8 or which != "cylinder") and comm["allreduces"] <= per_it * comm["krylov"] + 2 * comm["solves"], comm
     print("krylov iterations per Newton iteration:", world, "ranks", [it[3] for h in hist_part for it in h], "single",
           [it[3] for h in hist_one for it in h])
 

@@ -32,24 +32,24 @@ def main():
         ns["t"] = 0.005
         hook("pre_solve")(**ns)
     os.environ["FSI_KRYLOV_CAP"] = "8"                       # no Krylov store needed here
-    hb = HipBackend(desc)
     mesh = ns["mesh"]
     rng = np.random.default_rng(0)
     N2, h = mesh.num_nodes, mesh.hmin()
-    U = np.zeros(hb.ndof)
+    U = np.zeros(mesh.num_dofs)
     U[:3 * N2] = 0.01 * h * rng.standard_normal(3 * N2)
     U[3 * N2:6 * N2] = 0.1 * rng.standard_normal(3 * N2)
     U[6 * N2:] = 10 * rng.standard_normal(mesh.num_vertices)
-    hb.set_state("n", U); hb.set_state("n-1", 0.9 * U)
-    hb.set_dirichlet_values(bc_values()); hb.set_interface_pressure(float(pressure.P))
-    x = rng.standard_normal(hb.ndof)
+    x = rng.standard_normal(mesh.num_dofs)
     ref = None
-    print(f"{mesh.num_cells} tets, {hb.ndof} dofs")
+    print(f"{mesh.num_cells} tets, {mesh.num_dofs} dofs")
     for name, env in (("k_jacobian<2,2> (vector pipe, shipped)", {"FSI_JAC_MFMA": "0", "FSI_JAC_WAVES": "2"}),
                       ("k_jacobian<2,1> (vector pipe, 1 wave/SIMD)", {"FSI_JAC_MFMA": "0", "FSI_JAC_WAVES": "1"}),
                       ("k_jacobian_mfma<2> (matrix pipe)", {"FSI_JAC_MFMA": "1", "FSI_JAC_WAVES": "2"}),
                       ("k_jacobian_mfma<1> (matrix pipe, 1 wave/SIMD)", {"FSI_JAC_MFMA": "1", "FSI_JAC_WAVES": "1"})):
-        os.environ.update(env)
+        os.environ.update(env)                               # FsiTuning.jacobian_waves / jacobian_mfma, read by fsi_create
+        hb = HipBackend(desc)
+        hb.set_state("n", U); hb.set_state("n-1", 0.9 * U)
+        hb.set_dirichlet_values(bc_values()); hb.set_interface_pressure(float(pressure.P))
         hb.assemble_jacobian()                               # warm-up
         y = hb.spmv(x)
         if ref is None:
@@ -61,7 +61,7 @@ def main():
         tm = hb.timers()
         print(f"{name:48s} {tm['jacobian_ms'] / tm['jacobian_calls']:8.2f} ms per refresh (kernel + finish), factor {tm['factor_ms'] / max(1, tm['factor_calls']):7.2f} ms, "
               f"A x vs shipped kernel: {err:.2e}", flush=True)
-    hb.close()
+        hb.close()
 
 
 if __name__ == "__main__":

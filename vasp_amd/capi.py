@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = (
     "fsi_assemble_residual", "fsi_assemble_jacobian", "fsi_solve", "fsi_newton_solve", "fsi_shift",
     "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_get_matrix", "fsi_spmv",
     "fsi_get_timers", "fsi_get_values", "fsi_stress_strain", "fsi_wall_shear_stress", "fsi_calibration_streams", "fsi_set_newton_forcing", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
-    "fsi_rccl_unique_id", "fsi_set_rccl",
+    "fsi_rccl_unique_id", "fsi_set_rccl", "fsi_create_tuned", "fsi_get_tuning", "fsi_tuning_defaults", "fsi_tuning_from_env",
 )
 
 
@@ -36,6 +36,31 @@ class FsiParams(C.Structure):
     _fields_ = [("dt", C.c_double), ("theta", C.c_double), ("num_fluid_regions", C.c_int32),
                 ("fluid_props", C.c_void_p), ("num_solid_regions", C.c_int32), ("solid_props", C.c_void_p),
                 ("solid_models", C.c_void_p), ("delta", C.c_double), ("laplace_alpha", C.c_double)]
+
+
+class FsiTuning(C.Structure):
+    """include/vaspfsi.h: every product option of a context (storage precisions, sizes, Newton / Krylov policy, the
+    preconditioner's structure and sweep counts).  ``HipBackend(desc, tuning={"krylov_fp32": 0, ...})`` starts from the
+    library's defaults with the environment's FSI_<NAME> overrides and sets the named fields."""
+    _fields_ = [("struct_size", C.c_int32), ("krylov_fp32", C.c_int32), ("operator_fp32", C.c_int32), ("schur_fp32", C.c_int32),
+                ("sweeps_fp32", C.c_int32), ("sweeps_fp16", C.c_int32), ("solid_fp32", C.c_int32), ("pv_fp32", C.c_int32),
+                ("krylov_capacity", C.c_int32), ("krylov_fp32_floor", C.c_double),
+                ("assembly_atomic", C.c_int32), ("node_order", C.c_int32), ("tiles", C.c_int32), ("jacobian_waves", C.c_int32),
+                ("jacobian_mfma", C.c_int32),
+                ("newton_forcing", C.c_double), ("newton_forcing_late", C.c_double), ("newton_late_factor", C.c_double),
+                ("f32_cycle_floor", C.c_double), ("f32_verdict_skip_rtol", C.c_double), ("orth_floor32", C.c_double),
+                ("orth_floor64", C.c_double), ("gcr_escape", C.c_double), ("gcr_reorth", C.c_double),
+                ("prec_streams", C.c_int32), ("cheb4", C.c_int32), ("coarse_power", C.c_int32), ("solid_mg", C.c_int32),
+                ("dd_mg", C.c_int32), ("mg_keep", C.c_int32), ("solid_block_jacobi", C.c_int32), ("solid_fused", C.c_int32),
+                ("fused_sweeps", C.c_int32), ("scalar_dd", C.c_int32),
+                ("its_solid", C.c_int32), ("its_fluid", C.c_int32), ("its_schur", C.c_int32), ("its_disp", C.c_int32),
+                ("kappa_solid", C.c_double), ("kappa_fluid", C.c_double), ("kappa_schur", C.c_double), ("kappa_disp", C.c_double),
+                ("sbmg_pre", C.c_int32), ("sbmg_post", C.c_int32), ("sbmg_cits", C.c_int32), ("sbmg_alpha", C.c_double),
+                ("sbmg_ckappa", C.c_double),
+                ("mg_pre", C.c_int32), ("mg_post", C.c_int32), ("mg_cits", C.c_int32), ("mg_alpha", C.c_double), ("mg_ckappa", C.c_double)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
 
 
 class FsiNewtonOpts(C.Structure):
@@ -96,6 +121,10 @@ def load_library(path: Optional[Path] = None):
     lib = C.CDLL(str(p))
     vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
     lib.fsi_create.argtypes = [C.POINTER(FsiMeshDesc), C.POINTER(FsiParams), C.c_int, C.POINTER(vp)]
+    lib.fsi_create_tuned.argtypes = [C.POINTER(FsiMeshDesc), C.POINTER(FsiParams), C.c_int, C.POINTER(FsiTuning), C.POINTER(vp)]
+    lib.fsi_get_tuning.argtypes = [vp, C.POINTER(FsiTuning)]
+    lib.fsi_tuning_defaults.argtypes = [C.POINTER(FsiTuning)]
+    lib.fsi_tuning_from_env.argtypes = [C.POINTER(FsiTuning)]
     lib.fsi_destroy.argtypes = [vp]
     lib.fsi_last_error.argtypes = [vp]
     lib.fsi_last_error.restype = C.c_char_p
@@ -124,7 +153,7 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_get_matrix.argtypes = [vp, vp, vp, vp]
     lib.fsi_spmv.argtypes = [vp, vp, vp]
     lib.fsi_get_timers.argtypes = [vp, C.POINTER(FsiTimers), C.c_int]
-    lib.fsi_set_linear_solver.argtypes = [vp, i32, dbl, i32]
+    lib.fsi_set_linear_solver.argtypes = [vp, i32]
     lib.fsi_probe.argtypes = [vp, i64, vp, vp, vp]
     lib.fsi_flow_stats.argtypes = [vp, vp]
     lib.fsi_set_chebyshev.argtypes = [vp, i32, dbl, i32, dbl, i32, dbl, i32, dbl]
@@ -133,7 +162,9 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_set_rccl.argtypes = [vp, C.c_char_p, i32, i32, vp, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("fsi_last_error", "fsi_num_dofs", "fsi_matrix_nnz"):
+        if name in ("fsi_tuning_defaults", "fsi_tuning_from_env"):
+            fn.restype = None
+        elif name not in ("fsi_last_error", "fsi_num_dofs", "fsi_matrix_nnz"):
             fn.restype = C.c_int
     if path is None:
         _lib = lib
@@ -180,8 +211,9 @@ class HipBackend:
     """One problem instance resident on one GPU; the methods are what ``monolithic.run`` calls per time step."""
 
     def __init__(self, desc: dict, device: int = 0, lin_rtol: float = 1e-10, lin_max_it: int = 4000,
-                 lin_solver: int = 0, precond: int = 0, inner_rtol: float = 1e-2, inner_max_it: int = 40,
-                 newton_forcing: Optional[float] = None, num_owned_cells: Optional[int] = None):
+                 lin_solver: int = 0, precond: int = 0,
+                 newton_forcing: Optional[float] = None, num_owned_cells: Optional[int] = None,
+                 tuning: Optional[dict] = None):
         import os
         self.lib = load_library()
         self.ctx = C.c_void_p()
@@ -208,7 +240,16 @@ class HipBackend:
                          _ptr(kind), _ptr(region))
         pr = FsiParams(float(desc["dt"]), float(desc["theta"]), len(fprops), _ptr(fprops), len(sprops), _ptr(sprops),
                        _ptr(smodels), float(desc.get("delta", 1.0e7)), float(desc.get("laplace_alpha", 1.0)))
-        rc = self.lib.fsi_create(C.byref(md), C.byref(pr), device, C.byref(self.ctx))
+        if tuning:          # named FsiTuning fields over the defaults + environment overrides; fsi_create_tuned takes the struct as given
+            t = FsiTuning()
+            self.lib.fsi_tuning_from_env(C.byref(t))
+            for k, v in tuning.items():
+                if k not in dict(FsiTuning._fields_):
+                    raise KeyError(f"FsiTuning has no field {k!r}")
+                setattr(t, k, v)
+            rc = self.lib.fsi_create_tuned(C.byref(md), C.byref(pr), device, C.byref(t), C.byref(self.ctx))
+        else:
+            rc = self.lib.fsi_create(C.byref(md), C.byref(pr), device, C.byref(self.ctx))
         if rc != FSI_OK:
             msg = self.lib.fsi_last_error(self.ctx).decode() if self.ctx else "fsi_create failed"
             if self.ctx:
@@ -216,7 +257,7 @@ class HipBackend:
                 self.ctx = C.c_void_p()
             raise FsiError(rc, msg)
         self.ndof = int(self.lib.fsi_num_dofs(self.ctx))
-        self._check(self.lib.fsi_set_linear_solver(self.ctx, int(precond), float(inner_rtol), int(inner_max_it)))
+        self._check(self.lib.fsi_set_linear_solver(self.ctx, int(precond)))
         if newton_forcing is not None:          # 0: every Newton system solved to lin_rtol, as the reference's direct LU
             self._check(self.lib.fsi_set_newton_forcing(self.ctx, float(newton_forcing)))
         bc = np.ascontiguousarray(desc.get("bc_dofs", np.zeros(0)), dtype=np.int64)
@@ -333,8 +374,8 @@ class HipBackend:
         self._check(self.lib.fsi_spmv(self.ctx, _ptr(x), _ptr(y)))
         return y
 
-    def set_linear_solver(self, precond: int = 0, inner_rtol: float = 0.0, inner_max_it: int = 0):
-        self._check(self.lib.fsi_set_linear_solver(self.ctx, int(precond), float(inner_rtol), int(inner_max_it)))
+    def set_linear_solver(self, precond: int = 0):
+        self._check(self.lib.fsi_set_linear_solver(self.ctx, int(precond)))
 
     def set_chebyshev(self, its_solid=0, kappa_solid=0.0, its_fluid=0, kappa_fluid=0.0, its_schur=0, kappa_schur=0.0,
                       its_disp=0, kappa_disp=0.0):
@@ -371,6 +412,12 @@ class HipBackend:
         out = np.empty((len(fc), 3, 3))
         self._check(self.lib.fsi_wall_shear_stress(self.ctx, len(fc), _ptr(fc), _ptr(fl), float(mu), _ptr(out)))
         return out
+
+    def tuning(self) -> dict:
+        """The FsiTuning the context was created with."""
+        t = FsiTuning()
+        self._check(self.lib.fsi_get_tuning(self.ctx, C.byref(t)))
+        return t.as_dict()
 
     def timers(self, reset=False) -> dict:
         t = FsiTimers()

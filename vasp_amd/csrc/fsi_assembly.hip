@@ -737,10 +737,10 @@ void launch_residual(hipStream_t st, int64_t C, const ElemArrays& ea, const Elem
 // `cc`: the assembly colouring (cells sorted by colour; colour k = cells[ptr[k] .. ptr[k+1])), or ncolours == 0 for one launch
 // over all cells with atomics whose order varies from run to run.
 void launch_jacobian(hipStream_t st, int part, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
-                     const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals, const CellColours& cc) {
-  // two waves per SIMD with 94 spilled VGPRs beat one wave without (70 against 99 ms per refresh at 1.12 M tets)
-  const int jac_waves = getenv("FSI_JAC_WAVES") ? atoi(getenv("FSI_JAC_WAVES")) : 2;
-  const int jac_mfma = getenv("FSI_JAC_MFMA") ? atoi(getenv("FSI_JAC_MFMA")) : 0;      // k_jacobian_mfma for the refresh kernel
+                     const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals, const CellColours& cc,
+                     int jac_waves, int jac_mfma) {
+  // jac_waves (FsiTuning.jacobian_waves): two waves per SIMD with 94 spilled VGPRs beat one wave without (70 against 99 ms per
+  // refresh at 1.12 M tets); jac_mfma (FsiTuning.jacobian_mfma): k_jacobian_mfma for the refresh kernel (103 ms: not the default)
   const int rounds = cc.ncolours == 0 ? 1 : cc.ncolours;
   for (int k = 0; k < rounds; ++k) {
     const int64_t n = cc.ncolours == 0 ? C : cc.ptr[k + 1] - cc.ptr[k];

@@ -141,61 +141,6 @@ void launch_extract_blocks(hipStream_t st, int64_t N2, int64_t V, double ktheta,
                      padj_ptr, vrank, node_solid, rowptr3, rowptr_vp, rowptr_pv, rowptr_pp, Add, Adv, Avv, Avp, Apv, App);
 }
 
-// ---- sparsified Schur complement S1 = (A_pp - Apv~ D^-1 A_vp) restricted to the vertex-neighbour pattern -------------------
-// Only used to build an ILU(0) preconditioner for the pressure solve; the solve itself applies the full operator
-// (launch_schur_apply).  One wave per pressure row q; columns = vertex neighbours of q (ascending pressure positions).
-static constexpr int MAXS = 512;
-__global__ __launch_bounds__(64) void k_schur_p1(int64_t V, const int32_t* __restrict__ vrank,
-                                                 const int64_t* __restrict__ nadj_ptr, const int32_t* __restrict__ nadj,
-                                                 const int64_t* __restrict__ padj_ptr, const int32_t* __restrict__ padj,
-                                                 const int64_t* __restrict__ rowptr_pv, const double* __restrict__ Apv,
-                                                 const int64_t* __restrict__ rowptr_pp, const double* __restrict__ App,
-                                                 const int64_t* __restrict__ rowptr_vp, const double* __restrict__ Avp,
-                                                 const int64_t* __restrict__ diagpos3, const double* __restrict__ Avv,
-                                                 double* __restrict__ S1, int32_t* __restrict__ flags) {
-  __shared__ double acc[MAXS];
-  __shared__ int32_t scol[MAXS];
-  const int lane = threadIdx.x;
-  for (int64_t q = blockIdx.x; q < V; q += gridDim.x) {
-    const int32_t r = vrank[q];
-    const int64_t pa0 = padj_ptr[r];
-    const int len = (int)(padj_ptr[r + 1] - pa0);
-    const int64_t op = rowptr_pp[q];
-    if (len > MAXS) { if (lane == 0) atomicOr(&flags[1], 4); continue; }
-    __syncthreads();
-    for (int t = lane; t < len; t += 64) { acc[t] = App[op + t]; scol[t] = padj[pa0 + t]; }
-    __syncthreads();
-    const int64_t a = nadj_ptr[r], deg = nadj_ptr[r + 1] - a, ov = rowptr_pv[q];
-    for (int64_t e = lane; e < 3 * deg; e += 64) {
-      const int32_t b = nadj[a + e / 3];
-      const int j = (int)(e % 3);
-      const double bq = Apv[ov + e];
-      if (bq == 0.0) continue;
-      const int64_t R = 3 * (int64_t)b + j;
-      const double coef = bq / Avv[diagpos3[R]];
-      const int64_t pa = padj_ptr[b], pdeg = padj_ptr[b + 1] - pa, o = rowptr_vp[R];
-      for (int64_t k = 0; k < pdeg; ++k) {
-        const double v = Avp[o + k];
-        if (v == 0.0) continue;
-        const int32_t c = padj[pa + k];
-        int lo = 0, hi = len - 1;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (scol[mid] < c) lo = mid + 1; else hi = mid; }
-        if (scol[lo] == c) atomicAdd(&acc[lo], -coef * v);
-      }
-    }
-    __syncthreads();
-    for (int t = lane; t < len; t += 64) S1[op + t] = acc[t];
-  }
-}
-void launch_schur_p1(hipStream_t st, int64_t V, const int32_t* vrank, const int64_t* nadj_ptr, const int32_t* nadj,
-                     const int64_t* padj_ptr, const int32_t* padj, const int64_t* rowptr_pv, const double* Apv,
-                     const int64_t* rowptr_pp, const double* App, const int64_t* rowptr_vp, const double* Avp,
-                     const int64_t* diagpos3, const double* Avv, double* S1, int32_t* flags) {
-  const unsigned blocks = (unsigned)(V < 16384 ? V : 16384);
-  hipLaunchKernelGGL(k_schur_p1, dim3(blocks), dim3(64), 0, st, V, vrank, nadj_ptr, nadj, padj_ptr, padj, rowptr_pv, Apv,
-                     rowptr_pp, App, rowptr_vp, Avp, diagpos3, Avv, S1, flags);
-}
-
 // ---- explicit Schur complement S = A_pp - Apv~ D^-1 A_vp on its full pattern (vertices within two elements) ----------------
 // One wave per pressure row; the pattern (s_rowptr, s_cols: ascending pressure positions) is built once on the host.
 static constexpr int MAXS2 = 1024;
@@ -817,7 +762,7 @@ __global__ __launch_bounds__(1024) void k_sweep_tiled_f32(int64_t N2, const int6
 void launch_sweep_tiled_f32(hipStream_t st, int nv, int64_t N2, int max_nu, const int64_t* nadj_ptr, const float* vals,
                             const uint16_t* ploc, const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag,
                             const float* dinv, float c1, float c2, const float* din, float* dout, float* x, float* r) {
-  static const int threads = getenv("FSI_TILE_THREADS") ? atoi(getenv("FSI_TILE_THREADS")) : 512;
+  constexpr int threads = 512;      // measured: 1024 no gain over 512 (round 2)
   const int th = threads >= 1024 ? 1024 : (threads >= 512 ? 512 : 256);
   const unsigned tiles = (unsigned)((N2 + TILE_NODES - 1) / TILE_NODES);
   const size_t lds = (size_t)max_nu * sizeof(float4);
@@ -947,7 +892,7 @@ __global__ __launch_bounds__(1024) void k_sweep_tiled_h(int64_t N2, const int64_
 void launch_sweep_tiled_h(hipStream_t st, int nv, int64_t N2, int max_nu, const int64_t* nadj_ptr, const void* rec,
                           const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag, const float* dinv, float c1,
                           float c2, const float* din, float* dout, float* x, float* r) {
-  static const int threads = getenv("FSI_TILE_THREADS") ? atoi(getenv("FSI_TILE_THREADS")) : 512;
+  constexpr int threads = 512;      // measured: 1024 no gain over 512 (round 2)
   const int th = threads >= 1024 ? 1024 : (threads >= 512 ? 512 : 256);
   const unsigned tiles = (unsigned)((N2 + TILE_NODES - 1) / TILE_NODES);
   const size_t lds = (size_t)max_nu * sizeof(float4);
@@ -1542,28 +1487,6 @@ void launch_sbmg_prolong(hipStream_t st, int64_t nS, const int32_t* par, const f
   hipLaunchKernelGGL(k_sbmg_prolong, dim3(gridn(nS)), dim3(256), 0, st, nS, par, pw, flag, xc4, e4);
 }
 
-// One Jacobi-Chebyshev sweep on a scalar CSR matrix kept in FP32 (the explicit Schur complement: ~60 entries per row) in a
-// single launch: 16 lanes per row form t = A d_in, lane 0 does  r -= t,  x += d_in,  d_out = c1 d_in + c2 r / a_ii.
-__global__ __launch_bounds__(256) void k_sweep_csr_f32(int64_t n, const int64_t* __restrict__ rowptr,
-                                                       const int32_t* __restrict__ cols, const float* __restrict__ vals,
-                                                       const float* __restrict__ dinv, float c1, float c2,
-                                                       const float* __restrict__ din, float* __restrict__ dout,
-                                                       float* __restrict__ x, float* __restrict__ r) {
-  const int sub = threadIdx.x & 15;
-  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
-  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
-  for (int64_t i = grp; i < n; i += ngrp) {
-    float s = 0.f;
-    for (int64_t e = rowptr[i] + sub; e < rowptr[i + 1]; e += 16) s += vals[e] * din[cols[e]];
-    s = group_sum<16>(s);
-    if (sub == 0) {
-      const float di = din[i], ri = r[i] - s;
-      x[i] += di;
-      r[i] = ri;
-      dout[i] = c1 * di + c2 * ri * dinv[i];
-    }
-  }
-}
 // The same sweep with only the matrix VALUES in FP32 and every vector in FP64.  A rounded matrix is still one fixed linear
 // operator, so the preconditioner stays a linear map (what the Krylov method assumes); FP32 vectors instead add 6e-8 |dp| of
 // noise per sweep, which on a coarse mesh with a pressure-dominated right-hand side exceeded the velocity residual the outer
@@ -1622,7 +1545,7 @@ s = group_sum<LPR>(s);
 void launch_sweep_csr_mixed(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const float* vals,
                             const int64_t* diagpos, const double* dvals, double c1, double c2, const double* din, double* dout,
                             double* x, double* r) {
-  static const int lpr = getenv("FSI_SCHUR_LPR") ? atoi(getenv("FSI_SCHUR_LPR")) : 8;
+  constexpr int lpr = 8;            // lanes per row of the generic Schur sweep (round 2 scan: 8)
   const int rpb = 256 / (lpr == 16 ? 16 : (lpr == 4 ? 4 : 8));
   int64_t blocks = (n + rpb - 1) / rpb;
   if (blocks > 32768) blocks = 32768;
@@ -1698,30 +1621,6 @@ void launch_sweep_schur_tiled(hipStream_t st, int64_t n, int max_nu, const int64
   const unsigned tiles = (unsigned)((n + SCHUR_TILE - 1) / SCHUR_TILE);
   hipLaunchKernelGGL(k_sweep_schur_tiled, dim3(tiles), dim3(256), (size_t)max_nu * sizeof(double), st, n, rowptr, rec, tile_uptr, ulist,
                      dinv, c1, c2, din, dout, x, r);
-}
-__global__ void k_csr_dinv_f32(int64_t n, const int64_t* __restrict__ diagpos, const double* __restrict__ A, float* __restrict__ dinv) {
-  GS(i, n) dinv[i] = (float)(1.0 / A[diagpos[i]]);
-}
-__global__ void k_cheb_init_plain_f32(int64_t n, const double* __restrict__ rhs, const float* __restrict__ dinv, float inv_theta,
-                                      float* __restrict__ x, float* __restrict__ r, float* __restrict__ d, float* __restrict__ d2) {
-  GS(i, n) { const float ri = (float)rhs[i]; x[i] = 0.f; r[i] = ri; d[i] = ri * inv_theta * dinv[i]; d2[i] = 0.f; }
-}
-__global__ void k_f32_to_f64(int64_t n, const float* __restrict__ a, double* __restrict__ b) { GS(i, n) b[i] = (double)a[i]; }
-void launch_sweep_csr_f32(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const float* vals,
-                          const float* dinv, float c1, float c2, const float* din, float* dout, float* x, float* r) {
-  int64_t blocks = (n + 15) / 16;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(k_sweep_csr_f32, dim3((unsigned)blocks), dim3(256), 0, st, n, rowptr, cols, vals, dinv, c1, c2, din, dout, x, r);
-}
-void launch_csr_dinv_f32(hipStream_t st, int64_t n, const int64_t* diagpos, const double* A, float* dinv) {
-  hipLaunchKernelGGL(k_csr_dinv_f32, dim3(gridn(n)), dim3(256), 0, st, n, diagpos, A, dinv);
-}
-void launch_cheb_init_plain_f32(hipStream_t st, int64_t n, const double* rhs, const float* dinv, float inv_theta, float* x,
-                                float* r, float* d, float* d2) {
-  hipLaunchKernelGGL(k_cheb_init_plain_f32, dim3(gridn(n)), dim3(256), 0, st, n, rhs, dinv, inv_theta, x, r, d, d2);
-}
-void launch_f32_to_f64(hipStream_t st, int64_t n, const float* a, double* b) {
-  hipLaunchKernelGGL(k_f32_to_f64, dim3(gridn(n)), dim3(256), 0, st, n, a, b);
 }
 // One Chebyshev sweep of the solid block in a single launch: t = A d_in (3x3 block-CSR, 16 lanes per node), then on the
 // first three lanes of the group (one component each)  r -= t,  x += d_in,  d_out = c1 d_in + c2 B^-1 r.

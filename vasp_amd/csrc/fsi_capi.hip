@@ -2,70 +2,19 @@
 //
 // Host-side logic follows turtleFSI's monolithic.py / newtonsolver.py as VaSP uses them; the
 // arithmetic runs in the HIP kernels of fsi_assembly.hip / fsi_solver.hip.
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <numeric>
-
-#include "fsi_kernels.hpp"
+#include "fsi_host.hpp"
 
 using namespace fsi;
-
-#define HIPCHK(call)                                                                               \
-  do {                                                                                             \
-    hipError_t e_ = (call);                                                                        \
-    if (e_ != hipSuccess) {                                                                        \
-      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                                \
-      return FSI_ERR_DEVICE;                                                                       \
-    }                                                                                              \
-  } while (0)
-#define FSICHK(call)                 \
-  do {                               \
-    int r_ = (call);                 \
-    if (r_ != FSI_OK) return r_;     \
-  } while (0)
-
-int refresh_preconditioner(FsiCtx* ctx);
-void gcr_reset(FsiCtx* ctx);
+using namespace fsi::host;
 
 namespace {
 
 const int TET_EDGES[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
 
-// HIP-event bracket on the solver stream.  Nothing here waits for the device: the pair goes into the timer's ring and is
-// read back when the ring wraps (32 brackets later, long finished) or by resolve_timer() from fsi_get_timers.
-void resolve_timer(PhaseTimer* t, int64_t upto) {
-  for (; t->resolved < upto; ++t->resolved) {
-    const int k = (int)(t->resolved % PhaseTimer::RING);
-    float ms = 0.f;
-    if (hipEventSynchronize(t->e1[k]) == hipSuccess && hipEventElapsedTime(&ms, t->e0[k], t->e1[k]) == hipSuccess) t->ms += ms;
-  }
-}
-struct Phase {
-  FsiCtx* c;
-  PhaseTimer* t;
-  int k;
-  Phase(FsiCtx* ctx, PhaseTimer* tm) : c(ctx), t(tm) {
-    if (t->issued - t->resolved >= PhaseTimer::RING) resolve_timer(t, t->issued - PhaseTimer::RING + 1);
-    k = (int)(t->issued % PhaseTimer::RING);
-    if (!t->e0[k]) { (void)hipEventCreate(&t->e0[k]); (void)hipEventCreate(&t->e1[k]); }
-    (void)hipEventRecord(t->e0[k], c->stream);
-  }
-  ~Phase() {
-    (void)hipEventRecord(t->e1[k], c->stream);
-    t->issued += 1;
-    t->calls += 1;
-  }
-};
+}  // namespace
 
-template <class T>
-int upload(FsiCtx* ctx, DevBuf<T>& buf, const std::vector<T>& h) {
-  HIPCHK(buf.alloc(h.size()));
-  if (!h.empty()) HIPCHK(hipMemcpy(buf.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-  return FSI_OK;
-}
+namespace fsi {
+namespace host {
 
 ElemArrays elem_arrays(FsiCtx* c) {
   return ElemArrays{c->geom.p, c->cell_dofs.p, c->cell_kind.p, c->cell_region.p, c->cell_rank.p, c->cell_prow.p, c->enbr.p, c->epnbr.p};
@@ -156,1552 +105,8 @@ int rebuild_matrix_bc(FsiCtx* ctx) {
   return upload(ctx, ctx->mbc_dofs, m);
 }
 
-// ---- inner solves of the block preconditioner: BiCGStab on one field block, ILU(0)-preconditioned ----------------------
-// W holds 8 work vectors of length M.n.  Never fails: on breakdown it returns what it has (the outer method is flexible).
-template <class Apply>
-int inner_bicgstab(FsiCtx* ctx, const SubMat& M, Apply&& apply, const double* rhs, double* x, double* W, double rtol,
-                   int maxit, int64_t* its_acc) {
-  const int64_t n = M.n;
-  hipStream_t st = ctx->stream;
-  double *r = W, *r0 = W + n, *p = W + 2 * n, *v = W + 3 * n, *s = W + 4 * n, *t = W + 5 * n, *ph = W + 6 * n, *tmp = W + 7 * n;
-  auto ilu = [&](const double* in, double* out) {
-    launch_sptrsv_levels(st, M.levels, M.rowptr, M.cols, M.diagpos, M.LU.p, in, tmp, out);
-  };
-  launch_copy(st, r, rhs, n);
-  launch_copy(st, r0, rhs, n);
-  launch_fill(st, x, n, 0.0);
-  launch_fill(st, p, n, 0.0);
-  launch_fill(st, v, n, 0.0);
-  double bb = 0.0;
-  FSICHK(dot_n(ctx, r, r, n, &bb));
-  if (!(bb > 0.0) || !std::isfinite(bb)) return FSI_OK;
-  const double target = rtol * rtol * bb;
-  double rho = 1.0, alpha = 1.0, omega = 1.0;
-  for (int it = 0; it < maxit; ++it) {
-    double rho1 = 0.0;
-    FSICHK(dot_n(ctx, r0, r, n, &rho1));
-    if (rho1 == 0.0 || !std::isfinite(rho1)) break;
-    const double beta = (rho1 / rho) * (alpha / omega);
-    launch_axpy(st, p, -omega, v, n);
-    launch_axpby(st, p, 1.0, r, beta, p, n);
-    ilu(p, ph);
-    apply(ph, v);
-    double r0v = 0.0;
-    FSICHK(dot_n(ctx, r0, v, n, &r0v));
-    if (r0v == 0.0 || !std::isfinite(r0v)) break;
-    alpha = rho1 / r0v;
-    launch_axpby(st, s, 1.0, r, -alpha, v, n);
-    launch_axpy(st, x, alpha, ph, n);
-    *its_acc += 1;
-    double ss = 0.0;
-    FSICHK(dot_n(ctx, s, s, n, &ss));
-    if (!(ss > target)) break;
-    ilu(s, ph);
-    apply(ph, t);
-    double ts = 0.0, tt = 0.0;
-    FSICHK(dot_n(ctx, t, s, n, &ts));
-    FSICHK(dot_n(ctx, t, t, n, &tt));
-    omega = tt > 0.0 ? ts / tt : 0.0;
-    if (!std::isfinite(omega) || omega == 0.0) break;
-    launch_axpy(st, x, omega, ph, n);
-    launch_axpby(st, r, 1.0, s, -omega, t, n);
-    double rr = 0.0;
-    FSICHK(dot_n(ctx, r, r, n, &rr));
-    rho = rho1;
-    if (!(rr > target)) break;
-  }
-  return FSI_OK;
-}
-
-// Chebyshev solve of the masked velocity block (see fsi_block.hip); W: 2 work vectors (r, t) + d
-struct CsrRef { int64_t n; const int64_t* rowptr; const int32_t* cols; const double* vals; const int64_t* diagpos; };
-// Chebyshev solve with a Jacobi scaling taken from (dvals, diagpos); `apply(in, out)` is the operator. W: 3 work vectors.
-template <class Apply>
-void cheb_solve_op(FsiCtx* ctx, int64_t n, Apply&& apply, const double* dvals, const int64_t* diagpos, const double* mask,
-                   const double* rhs, double* x, double* W, int its, double lmax, double kappa) {
-  hipStream_t st = ctx->stream;
-  double *r = W, *d = W + n, *t = W + 2 * n;
-  const double lmin = lmax / kappa, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
-  double rho = 1.0 / sig;
-  launch_cheb_init(st, n, mask, rhs, diagpos, dvals, 1.0 / th, x, r, d);
-  for (int k = 0; k < its; ++k) {
-    apply(d, t);
-    const double rn = 1.0 / (2.0 * sig - rho);
-    launch_cheb_step(st, n, mask, t, diagpos, dvals, rn * rho, 2.0 * rn / de, x, r, d);
-    rho = rn;
-  }
-}
-void cheb_solve(FsiCtx* ctx, const CsrRef& M, const double* mask, const double* rhs, double* x, double* W, int its,
-                double lmax, double kappa) {
-  cheb_solve_op(ctx, M.n, [&](const double* in, double* out) { launch_spmv(ctx->stream, M.n, M.rowptr, M.cols, M.vals, in, out); },
-                M.vals, M.diagpos, mask, rhs, x, W, its, lmax, kappa);
-}
-CsrRef vv_ref(FsiCtx* c) { return CsrRef{3 * c->N2, c->rowptr3.p, c->cols3.p, c->Mvv.vals.p, c->diagpos3.p}; }
-CsrRef ss_ref(FsiCtx* c) { return CsrRef{3 * c->nS, c->ss_rowptr.p, c->ss_cols.p, c->ss_vals.p, c->ss_diagpos.p}; }
-// largest eigenvalue of mask D^-1 A mask by power iteration from a pseudo-random start (rich in element-scale modes)
-template <class Apply>
-int power_lmax_op(FsiCtx* ctx, int64_t n, Apply&& apply, const double* dvals, const int64_t* diagpos, const double* mask,
-                  double* W, double* out) {
-  hipStream_t st = ctx->stream;
-  double *x = W, *y = W + n;
-  launch_mask_ripple(st, n, mask, x);
-  double lam = 1.0;
-  for (int k = 0; k < 40; ++k) {
-    apply(x, y);
-    launch_mask_scale(st, n, mask, diagpos, dvals, y);
-    double xx = 0.0, yy = 0.0;
-    FSICHK(dot_n(ctx, x, x, n, &xx));
-    FSICHK(dot_n(ctx, y, y, n, &yy));
-    if (!(xx > 0.0) || !(yy > 0.0) || !std::isfinite(yy)) break;
-    lam = std::sqrt(yy / xx);
-    launch_copy(st, x, y, n);
-    launch_scale(st, x, 1.0 / std::sqrt(yy), n);
-  }
-  *out = 1.2 * lam;
-  return FSI_OK;
-}
-int power_lmax(FsiCtx* ctx, const CsrRef& M, const double* mask, double* W, double* out) {
-  return power_lmax_op(ctx, M.n, [&](const double* in, double* o) { launch_spmv(ctx->stream, M.n, M.rowptr, M.cols, M.vals, in, o); },
-                       M.vals, M.diagpos, mask, W, out);
-}
-// Schur operator y = (A_pp - Apv~ D^-1 A_vp) x ; w3: work vector of length 3 N2
-void schur_apply(FsiCtx* ctx, const double* in, double* out, double* w3) {
-  (void)w3;
-  launch_spmv(ctx->stream, ctx->V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->s_vals.p, in, out, SPMV_FIELD_BLOCK);
-}
-
-// FP32 Chebyshev sweeps on a component-diagonal node-block matrix; dinv carries the Jacobi scaling and the mask
-void cheb_db_f32(FsiCtx* ctx, const float* db, const float* dinv, const double* rhs, double* x, double* W, int its,
-                 double lmax, double kappa, hipStream_t st = nullptr) {
-  const int64_t n = 4 * ctx->N2;                 // float4 per node
-  if (!st) st = ctx->stream;
-  float* F = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(W) + 15) & ~uintptr_t(15));   // float4 loads
-  float *fr = F, *fd = F + n, *ft = F + 2 * n, *fx = F + 3 * n, *frhs = F + 4 * n;
-  launch_pad_to_f32(st, ctx->N2, rhs, nullptr, frhs);
-  const double lmin = lmax / kappa, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
-  double rho = 1.0 / sig;
-  launch_cheb_init_f32(st, n, frhs, dinv, (float)(1.0 / th), fx, fr, fd);
-  if (ctx->tiled && ctx->fused_sweeps) {
-    float *da = fd, *db_ = ft;                   // d is ping-ponged; the product stays in registers
-    for (int k = 0; k < its; ++k) {
-      const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->db_ev0[0] && ctx->db_samples_pending < 8;
-      if (timed) (void)hipEventRecord(ctx->db_ev0[ctx->db_samples_pending], st);
-      const double rn = 1.0 / (2.0 * sig - rho);
-      if (ctx->sweeps_fp16 && db == ctx->vv_db32.p)
-        launch_sweep_tiled_h(st, 3, ctx->N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->vv_rec.p, ctx->tile_uptr.p, ctx->tile_ulist.p, nullptr,
-                             dinv, (float)(rn * rho), (float)(2.0 * rn / de), da, db_, fx, fr);
-      else
-        launch_sweep_tiled_f32(st, 3, ctx->N2, ctx->tile_max_nu, ctx->nadj_ptr.p, db, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
-                               nullptr, dinv, (float)(rn * rho), (float)(2.0 * rn / de), da, db_, fx, fr);
-      if (timed) { (void)hipEventRecord(ctx->db_ev1[ctx->db_samples_pending], st); ctx->db_samples_pending += 1; }
-      std::swap(da, db_);
-      rho = rn;
-    }
-    launch_unpad_from_f32(st, ctx->N2, fx, x);
-    return;
-  }
-  for (int k = 0; k < its; ++k) {
-    const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->db_ev0[0] && ctx->db_samples_pending < 8;
-    if (timed) (void)hipEventRecord(ctx->db_ev0[ctx->db_samples_pending], st);
-    if (ctx->tiled)
-      launch_spmv_tiled_f32(st, 3, ctx->N2, ctx->tile_max_nu, ctx->nadj_ptr.p, db, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p, nullptr, fd, ft);
-    else
-      launch_spmv_db_f32(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, db, fd, ft);
-    if (timed) { (void)hipEventRecord(ctx->db_ev1[ctx->db_samples_pending], st); ctx->db_samples_pending += 1; }
-    const double rn = 1.0 / (2.0 * sig - rho);
-    launch_cheb_step_f32(st, n, ft, dinv, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
-    rho = rn;
-  }
-  launch_unpad_from_f32(st, ctx->N2, fx, x);
-}
-
-// z = M^-1 r with the approximate block factorisation (see fsi_block.hip):  (v,p) by SIMPLE with the d-eliminated
-// velocity block, then d.
-int precondition_block(FsiCtx* ctx, const double* r, double* z) {
-  const int64_t n3 = 3 * ctx->N2, V = ctx->V, N2 = ctx->N2;
-  hipStream_t st = ctx->stream;
-  double* W = ctx->blk.p;
-  double *rd = W, *rv = W + n3, *rp = W + 2 * n3, *vs = W + 3 * n3, *tp = W + 4 * n3, *dp = W + 5 * n3, *dv = W + 6 * n3,
-         *td = W + 7 * n3, *dd = W + 8 * n3, *IW = W + 9 * n3, *w3 = W + 19 * n3;     // IW: 10 vectors; its first 4 hold the (FP32, float4-padded) sweep work
-  // Two chains side by side (prec_streams; default configuration only: FP32 solid cycle, FP32 fluid sweeps, FP16 / FP32 Schur
-  // sweeps with FP64 vectors, scalar displacement block).  The application is a chain of ~215 dependent launches, most of them
-  // short of filling the chip (latency- and issue-bound sweeps on 0.1 - 0.6 GB of data), and its dependences are fewer than
-  // its order: the fluid predictor does not need the solid one (block Jacobi instead of Gauss-Seidel between the two parts:
-  // same Krylov counts, measured), and the displacement block needs the velocity on the SOLID rows only, where the pressure
-  // correction is small (dd_early: measured).  Stream A (the solver stream): split, solid predictor, displacement block,
-  // merge.  Stream B: fluid predictor, then - once the solid predictor is there - pressure right-hand side, Schur sweeps,
-  // velocity correction.  Work vectors of the two chains are disjoint: the solid and displacement sweeps use IW[0, 4 n3),
-  // the fluid sweeps IW[6 n3, 10 n3), the Schur sweeps the unused tail of rp (V of its n3 entries carry r_p).
-  const bool conc = ctx->prec_streams && ctx->stream2 && ctx->solid_fp32 && ctx->solid_block_jacobi && ctx->solid_fused && ctx->sbmg_ready &&
-                    ctx->sweeps_fp32 && ctx->tiled && ctx->fused_sweeps && ctx->cheb_its_p > 0 && ctx->schur_fp32 == 1 && ctx->s_vals32.p &&
-                    ctx->pv32_ok && ctx->adv_is_db && ctx->cheb_its_d > 0 && ctx->dd_is_scalar && 4 * V <= n3 && ctx->debug_prec_apply == 0;
-  hipStream_t sA = ctx->stream, sB = conc ? ctx->stream2 : ctx->stream;
-  launch_split(st, N2, V, r, rd, rv, rp);
-  if (conc) { HIPCHK(hipEventRecord(ctx->ev_split, sA)); HIPCHK(hipStreamWaitEvent(sB, ctx->ev_split, 0)); }
-  // velocity predictor: block Gauss-Seidel solid (elasticity-dominated, many cheap sweeps) -> fluid interior (mass-dominated)
-  {
-    double *xs = IW + 4 * n3, *xf = IW + 5 * n3, *rhs2 = IW + 6 * n3;
-    double *cs_rhs = IW + 7 * n3, *cs_x = IW + 8 * n3;            // compact solid vectors (3 nS <= n3)
-    if (conc)      // stream B, issued first: the fluid predictor straight from r_v (no coupling to the solid predictor), work area IW[6 n3, 10 n3)
-      cheb_db_f32(ctx, ctx->vv_db32.p, ctx->vvf_dinv32.p, rv, xf, IW + 6 * n3, ctx->cheb_its_f, ctx->lmax_f, ctx->cheb_kappa_f, sB);
-    if (ctx->solid_fp32) {
-      const int64_t n = 4 * ctx->nS;               // float4 per solid node
-      float* F = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(IW) + 15) & ~uintptr_t(15));   // float4 loads
-      float *fr = F, *fd = F + n, *ft = F + 2 * n, *fx = F + 3 * n, *frhs = F + 4 * n;
-      launch_gather3_f32(st, ctx->nS, ctx->snode.p, rv, frhs);
-      const double lmax = ctx->lmax_s, lmin = lmax / ctx->cheb_kappa_s, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
-      double rho = 1.0 / sig;
-      const bool bj = ctx->solid_block_jacobi != 0;
-      const bool fused = bj && ctx->solid_fused;
-      if (fused && ctx->sbmg_ready) {}      // the two-level cycle below starts its own recurrence
-      else if (bj) launch_cheb_init_b3(st, ctx->nS, frhs, ctx->sb_binv12.p, (float)(1.0 / th), fx, fr, fd);
-      else launch_cheb_init_f32(st, n, frhs, ctx->sb_dinv.p, (float)(1.0 / th), fx, fr, fd);
-      if (fused) HIPCHK(hipMemsetAsync(ft, 0, n * sizeof(float), st));     // second d buffer (ping-pong), pads stay zero
-      float *dcur = fd, *dnext = ft;
-      if (fused && ctx->sbmg_ready) {
-        // two-level cycle (see the displacement block): smoothing on [lmax/alpha, lmax], coarse solve on the solid vertices
-        const double slmin = lmax / ctx->sbmg_alpha, sth = 0.5 * (lmax + slmin), sde = 0.5 * (lmax - slmin), ssig = sth / sde;
-        double srho = 1.0 / ssig;
-        // FSI_CHEB4 bit 0: the smoothing sweeps as Chebyshev polynomials of the 4th kind (Lottes 2022: the smoother that
-        // minimises the two-level bound for a given degree; needs lmax only):  d_0 = 4/(3 lmax) B^-1 r,
-        // d_i = (2i-1)/(2i+3) d_{i-1} + (8i+4)/((2i+3) lmax) B^-1 r_i
-        const bool s4 = (ctx->cheb4 & 1) != 0;
-        const double sinit = s4 ? 4.0 / (3.0 * lmax) : 1.0 / sth;
-        auto s4c = [&](int i, float* c1, float* c2) { *c1 = (float)((2.0 * i - 1.0) / (2.0 * i + 3.0)); *c2 = (float)((8.0 * i + 4.0) / ((2.0 * i + 3.0) * lmax)); };
-        launch_cheb_init_b3(st, ctx->nS, frhs, ctx->sb_binv12.p, (float)sinit, fx, fr, fd);
-        auto sweep = [&](float c1, float c2, int sample) {
-          const bool timed = ctx->sample_budget > 0 && sample >= 0 && sample < 8 && ctx->ss_ev0[0];
-          if (timed) (void)hipEventRecord(ctx->ss_ev0[sample], st);
-          if (ctx->sweeps_fp16 && ctx->sb_rec.p)
-            launch_sweep_sb_h(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_rec.p, ctx->sb_binv12.p, c1, c2, dcur, dnext, fx, fr);
-          else
-            launch_sweep_sb_b3(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_col.p, ctx->sb_vals.p, ctx->sb_binv12.p, c1, c2, dcur, dnext, fx, fr);
-          if (timed) (void)hipEventRecord(ctx->ss_ev1[sample], st);
-          std::swap(dcur, dnext);
-        };
-        for (int k = 0; k < ctx->sbmg_pre; ++k) {
-          if (s4) { float c1, c2; s4c(k + 1, &c1, &c2); sweep(c1, c2, k); continue; }
-          const double rn = 1.0 / (2.0 * ssig - srho);
-          sweep((float)(rn * srho), (float)(2.0 * rn / sde), k);
-          srho = rn;
-        }
-        const int64_t nc = ctx->sbmg_nc, n4c = 4 * nc;
-        float *cr = ctx->sbmg_work.p, *cd = cr + n4c, *cd2 = cr + 2 * n4c, *cx = cr + 3 * n4c, *crhs = cr + 4 * n4c;
-        launch_sbmg_restrict(st, nc, ctx->sbmg_chptr.p, ctx->sbmg_child.p, ctx->sbmg_chw.p, ctx->snode.p, ctx->rowscale.p,
-                             ctx->sbmg_flag.p, ctx->sbmg_cflag.p, fr, crhs);
-        {
-          const double cl = ctx->sbmg_clmax, clmin = cl / ctx->sbmg_ckappa, cth = 0.5 * (cl + clmin), cde = 0.5 * (cl - clmin), csig = cth / cde;
-          double crho = 1.0 / csig;
-          launch_cheb_init_b3(st, nc, crhs, ctx->sbmg_cbinv12.p, (float)(1.0 / cth), cx, cr, cd);
-          HIPCHK(hipMemsetAsync(cd2, 0, n4c * sizeof(float), st));
-          float *ca = cd, *cb = cd2;
-          for (int k = 0; k < ctx->sbmg_cits; ++k) {
-            const double rn = 1.0 / (2.0 * csig - crho);
-            launch_sweep_sb_b3(st, nc, ctx->sbmg_cptr.p, ctx->sbmg_ccol.p, ctx->sbmg_cvals.p, ctx->sbmg_cbinv12.p, (float)(rn * crho),
-                               (float)(2.0 * rn / cde), ca, cb, cx, cr, 1);
-            std::swap(ca, cb);
-            crho = rn;
-          }
-        }
-        launch_sbmg_prolong(st, ctx->nS, ctx->sbmg_par.p, ctx->sbmg_pw.p, ctx->sbmg_flag.p, cx, dcur);   // correction as the next direction
-        sweep(0.f, (float)sinit, -1);                          // x += P x_c, r -= A P x_c, restart the recurrence
-        srho = 1.0 / ssig;
-        for (int k = 0; k < ctx->sbmg_post; ++k) {
-          if (s4) { float c1, c2; s4c(k + 1, &c1, &c2); sweep(c1, c2, -1); continue; }
-          const double rn = 1.0 / (2.0 * ssig - srho);
-          sweep((float)(rn * srho), (float)(2.0 * rn / sde), -1);
-          srho = rn;
-        }
-        ctx->inner_its[0] += ctx->sbmg_pre + 1 + ctx->sbmg_post - ctx->cheb_its_s;    // counted below as cheb_its_s
-        ctx->ss_samples_pending = (ctx->sample_budget > 0 && ctx->ss_ev0[0]) ? std::min(8, ctx->sbmg_pre) : 0;
-      } else
-      for (int k = 0; k < ctx->cheb_its_s; ++k) {
-        const bool timed = ctx->sample_budget > 0 && k < 8 && ctx->ss_ev0[0];
-        const double rn = 1.0 / (2.0 * sig - rho);
-        if (timed) (void)hipEventRecord(ctx->ss_ev0[k], st);
-        if (fused) {
-          launch_sweep_sb_b3(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_col.p, ctx->sb_vals.p, ctx->sb_binv12.p, (float)(rn * rho),
-                             (float)(2.0 * rn / de), dcur, dnext, fx, fr);
-          std::swap(dcur, dnext);
-          if (timed) (void)hipEventRecord(ctx->ss_ev1[k], st);
-        } else {
-          launch_spmv_sb(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_col.p, ctx->sb_vals.p, fd, ft);
-          if (timed) (void)hipEventRecord(ctx->ss_ev1[k], st);
-          if (bj) launch_cheb_step_b3(st, ctx->nS, ft, ctx->sb_binv12.p, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
-          else launch_cheb_step_f32(st, n, ft, ctx->sb_dinv.p, (float)(rn * rho), (float)(2.0 * rn / de), fx, fr, fd);
-        }
-        rho = rn;
-      }
-      if (!(fused && ctx->sbmg_ready)) ctx->ss_samples_pending = (ctx->sample_budget > 0 && ctx->ss_ev0[0]) ? std::min(8, ctx->cheb_its_s) : 0;
-      launch_fill(st, xs, n3, 0.0);
-      launch_scatter3_f32(st, ctx->nS, ctx->snode.p, fx, xs);
-    } else {
-    launch_gather3(st, ctx->nS, ctx->snode.p, rv, cs_rhs);
-    {
-      const CsrRef M = ss_ref(ctx);
-      int sample = 0;
-      cheb_solve_op(ctx, M.n,
-                    [&](const double* in, double* out) {
-                      const bool timed = ctx->sample_budget > 0 && sample < 8 && ctx->ss_ev0[0];
-                      if (timed) (void)hipEventRecord(ctx->ss_ev0[sample], st);
-                      launch_spmv(st, M.n, M.rowptr, M.cols, M.vals, in, out, SPMV_SOLID_BLOCK);
-                      if (timed) (void)hipEventRecord(ctx->ss_ev1[sample], st);
-                      sample += timed ? 1 : 0;
-                    },
-                    M.vals, M.diagpos, nullptr, cs_rhs, cs_x, IW, ctx->cheb_its_s, ctx->lmax_s, ctx->cheb_kappa_s);
-      ctx->ss_samples_pending = sample;
-    }
-    launch_fill(st, xs, n3, 0.0);
-    launch_scatter3(st, ctx->nS, ctx->snode.p, cs_x, xs);
-    }
-    if (conc) {
-      // when the solid predictor is there, the rest of the pressure step follows on B while A goes on to the displacement block
-      HIPCHK(hipEventRecord(ctx->ev_solid, sA));
-      HIPCHK(hipStreamWaitEvent(sB, ctx->ev_solid, 0));
-      st = sB;
-    } else {
-    // rhs of the fluid part: rv - Avv~ xs; xs lives on the solid nodes, the fluid solve masks the solid rows, so only
-    // the fluid rows with solid columns differ from rv
-    launch_copy(st, rhs2, rv, n3);
-    if (!ctx->vel_jacobi)      // (vel_jacobi: block Jacobi instead of Gauss-Seidel between the solid and the fluid part of the predictor)
-      launch_residual_rows(st, ctx->nfs, ctx->fs_rows.p, ctx->fs_ptr.p, ctx->fs_col.p, ctx->fs_src.p, ctx->Mvv.vals.p, xs, rv, rhs2);
-    }
-    if (conc) {}
-    else if (ctx->sweeps_fp32)
-      cheb_db_f32(ctx, ctx->vv_db32.p, ctx->vvf_dinv32.p, rhs2, xf, IW, ctx->cheb_its_f, ctx->lmax_f, ctx->cheb_kappa_f);
-    else
-      cheb_solve_op(ctx, n3, [&](const double* in, double* out) { launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->vv_db.p, in, out); },
-                    ctx->Mvv.vals.p, ctx->diagpos3.p, ctx->mask_f.p, rhs2, xf, IW, ctx->cheb_its_f, ctx->lmax_f, ctx->cheb_kappa_f);
-    launch_axpby(st, vs, 1.0, xs, 1.0, xf, n3);
-    ctx->inner_its[0] += ctx->cheb_its_s + ctx->cheb_its_f;
-  }
-  // pressure: S dp = rp - Apv~ vs,  S x = App x - Apv~ D^-1 Avp x
-  if (ctx->pv32_ok)
-    launch_pres_rhs32(st, V, ctx->vrank.p, ctx->nadj_ptr.p, ctx->nadj.p, ctx->rowptr_pv.p, ctx->Apv32.p, vs, rp, tp);
-  else
-    launch_pres_rows(st, V, ctx->rowptr_pp.p, ctx->cols_pp.p, ctx->App.p, nullptr, 0.0, ctx->rowptr_pv.p, ctx->cols_pv.p,
-                     ctx->Apv.p, vs, -1.0, rp, 1.0, tp);
-  if (ctx->cheb_its_p > 0 && ctx->schur_fp32 && ctx->s_vals32.p) {
-    // matrix values in FP32, vectors in FP64 (k_sweep_csr_mixed); schur_fp32 == 2: the all-FP32 sweep (measurement only)
-    const double lmax = ctx->lmax_p, lmin = lmax / ctx->cheb_kappa_p, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
-    double rho = 1.0 / sig;
-    if (ctx->schur_fp32 == 2) {
-      float *fx = ctx->s_work32.p, *fr = fx + V, *fa = fx + 2 * V, *fb = fx + 3 * V;
-      launch_cheb_init_plain_f32(st, V, tp, ctx->s_dinv32.p, (float)(1.0 / th), fx, fr, fa, fb);
-      for (int k = 0; k < ctx->cheb_its_p; ++k) {
-        const double rn = 1.0 / (2.0 * sig - rho);
-        launch_sweep_csr_f32(st, V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->s_vals32.p, ctx->s_dinv32.p, (float)(rn * rho),
-                             (float)(2.0 * rn / de), fa, fb, fx, fr);
-        std::swap(fa, fb);
-        rho = rn;
-      }
-      launch_f32_to_f64(st, V, fx, dp);
-    } else {
-      double *pr = conc ? rp + V : IW, *pa = pr + V, *pb = pr + 2 * V;
-      // FSI_CHEB4 bit 2: the Schur sweeps as the 4th-kind polynomial (needs lmax only; see the solid block)
-      const bool p4 = (ctx->cheb4 & 4) != 0;
-      launch_cheb_init(st, V, nullptr, tp, ctx->s_diagpos.p, ctx->s_vals.p, p4 ? 4.0 / (3.0 * lmax) : 1.0 / th, dp, pr, pa);
-      const bool tiled16 = ctx->schur_tiled && ctx->sweeps_fp16 && ctx->s_rec.p;
-      for (int k = 0; k < ctx->cheb_its_p; ++k) {
-        const double rn = 1.0 / (2.0 * sig - rho);
-        const int i4 = k + 1;
-        const double c1 = p4 ? (2.0 * i4 - 1.0) / (2.0 * i4 + 3.0) : rn * rho;
-        const double c2 = p4 ? (8.0 * i4 + 4.0) / ((2.0 * i4 + 3.0) * lmax) : 2.0 * rn / de;
-        const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->sch_ev0[0];
-        if (timed) (void)hipEventRecord(ctx->sch_ev0[k], st);
-        if (tiled16)
-          launch_sweep_schur_tiled(st, V, ctx->s_tile_max_nu, ctx->s_rowptr.p, ctx->s_rec.p, ctx->s_tile_uptr.p, ctx->s_tile_ulist.p,
-                                   ctx->s_dinv.p, c1, c2, pa, pb, dp, pr);
-        else
-        launch_sweep_csr_mixed(st, V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->s_vals32.p, ctx->s_diagpos.p, ctx->s_vals.p, c1,
-                               c2, pa, pb, dp, pr);
-        if (timed) { (void)hipEventRecord(ctx->sch_ev1[k], st); ctx->sch_samples_pending = k + 1; }
-        std::swap(pa, pb);
-        rho = rn;
-      }
-    }
-    ctx->inner_its[1] += ctx->cheb_its_p;
-  } else if (ctx->cheb_its_p > 0 && ctx->fused_sweeps) {
-    // all-FP64 Schur sweeps, product fused with the Chebyshev update (one launch per sweep)
-    const double lmax = ctx->lmax_p, lmin = lmax / ctx->cheb_kappa_p, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
-    double rho = 1.0 / sig;
-    double *pr = IW, *pa = IW + V, *pb = IW + 2 * V;
-    launch_cheb_init(st, V, nullptr, tp, ctx->s_diagpos.p, ctx->s_vals.p, 1.0 / th, dp, pr, pa);
-    for (int k = 0; k < ctx->cheb_its_p; ++k) {
-      const double rn = 1.0 / (2.0 * sig - rho);
-      const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->sch_ev0[0];
-      if (timed) (void)hipEventRecord(ctx->sch_ev0[k], st);
-      launch_sweep_csr_f64(st, V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->s_vals.p, ctx->s_diagpos.p, rn * rho, 2.0 * rn / de, pa, pb, dp, pr);
-      if (timed) { (void)hipEventRecord(ctx->sch_ev1[k], st); ctx->sch_samples_pending = k + 1; }
-      std::swap(pa, pb);
-      rho = rn;
-    }
-    ctx->inner_its[1] += ctx->cheb_its_p;
-  } else if (ctx->cheb_its_p > 0) {
-    int sample = 0;
-    cheb_solve_op(ctx, V,
-                  [&](const double* in, double* out) {
-                    const bool timed = ctx->sample_budget > 0 && sample < 4 && ctx->sch_ev0[0];
-                    if (timed) (void)hipEventRecord(ctx->sch_ev0[sample], st);
-                    schur_apply(ctx, in, out, w3);
-                    if (timed) { (void)hipEventRecord(ctx->sch_ev1[sample], st); sample += 1; ctx->sch_samples_pending = sample; }
-                  },
-                  ctx->s_vals.p, ctx->s_diagpos.p, nullptr, tp, dp, IW, ctx->cheb_its_p, ctx->lmax_p, ctx->cheb_kappa_p);
-    ctx->inner_its[1] += ctx->cheb_its_p;
-  } else {
-    FSICHK(inner_bicgstab(ctx, ctx->Ms, [&](const double* in, double* out) { schur_apply(ctx, in, out, w3); }, tp, dp, IW,
-                          ctx->inner_rtol, ctx->inner_maxit_p, &ctx->inner_its[1]));
-  }
-  // velocity correction and displacement
-  if (ctx->pv32_ok)
-    launch_vel_correct32(st, N2, ctx->padj_ptr.p, ctx->padj.p, ctx->Avp32.p, dp, ctx->vv_dinv.p, vs, dv);
-  else
-    launch_vel_correct(st, n3, ctx->rowptr_vp.p, ctx->cols_vp.p, ctx->Avp.p, dp, ctx->diagpos3.p, ctx->Mvv.vals.p, vs, dv, ctx->vv_dinv.p);
-  if (conc) { HIPCHK(hipEventRecord(ctx->ev_b, sB)); st = sA; }      // the rest (displacement block) is stream A's, behind the solid predictor
-  if (ctx->adv_is_db) {
-    // dd_early: the displacement block sees the solid PREDICTOR instead of the corrected velocity - what it has when its chain
-    // runs beside the pressure step instead of after it
-    launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->adv_db.p, (ctx->dd_early || conc) ? IW + 4 * n3 : dv, w3, ctx->adv_rowmask.p);
-    launch_axpby(st, td, 1.0, rd, -1.0, w3, n3);
-  } else {
-    launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Adv.p, dv, rd, td);
-  }
-  if (ctx->cheb_its_d > 0) {
-    if (ctx->dd_is_scalar && ctx->sweeps_fp32) {
-      // Jacobi-scaled system  (D^-1 A_dd) dd = D^-1 td  with the one-number-per-node-pair operator
-      const int64_t n = 4 * N2;
-      float* F = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(IW) + 15) & ~uintptr_t(15));   // float4 loads
-      float *fr = F, *fd = F + n, *ft = F + 2 * n, *fx = F + 3 * n, *frhs = F + 4 * n;
-      launch_pad_to_f32(st, N2, td, ctx->dd_dinv32.p, frhs);
-      const double lmax = ctx->lmax_d, lmin = lmax / ctx->cheb_kappa_d, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
-      double rho = 1.0 / sig;
-      const bool fused = ctx->tiled && ctx->fused_sweeps;
-      float *dcur = fd, *dnext = ft;               // fused sweeps ping-pong the direction; ft is otherwise the product
-      auto fine_spmv = [&](int k_sample) {
-        const bool timed = ctx->sample_budget > 0 && k_sample >= 0 && k_sample < 4 && ctx->sc_ev0[0];
-        if (timed) (void)hipEventRecord(ctx->sc_ev0[k_sample], st);
-        if (ctx->tiled)
-          launch_spmv_tiled_f32(st, 1, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_chat.p, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
-                                ctx->dd_rowflag.p, fd, ft);
-        else
-          launch_spmv_sc_f32(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_chat.p, ctx->dd_rowflag.p, fd, ft);
-        if (timed) { (void)hipEventRecord(ctx->sc_ev1[k_sample], st); ctx->sc_samples_pending = k_sample + 1; }
-      };
-      // one sweep: product + Chebyshev update (one launch when fused)
-      auto fine_sweep = [&](float c1, float c2, int k_sample) {
-        if (!fused) {
-          fine_spmv(k_sample);
-          launch_cheb_step_f32(st, n, ft, ctx->ones32.p, c1, c2, fx, fr, fd);
-          return;
-        }
-        const bool timed = ctx->sample_budget > 0 && k_sample >= 0 && k_sample < 4 && ctx->sc_ev0[0];
-        if (timed) (void)hipEventRecord(ctx->sc_ev0[k_sample], st);
-        if (ctx->sweeps_fp16)
-          launch_sweep_tiled_h(st, 1, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_rec.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
-                               ctx->dd_rowflag.p, nullptr, c1, c2, dcur, dnext, fx, fr);
-        else
-          launch_sweep_tiled_f32(st, 1, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_chat.p, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
-                                 ctx->dd_rowflag.p, nullptr, c1, c2, dcur, dnext, fx, fr);
-        if (timed) { (void)hipEventRecord(ctx->sc_ev1[k_sample], st); ctx->sc_samples_pending = k_sample + 1; }
-        std::swap(dcur, dnext);
-      };
-      if (ctx->mg_ready) {
-        // two-level cycle: Chebyshev smoothing on [lmax/alpha, lmax], coarse solve on the vertex graph, smoothing again
-        const double slmin = lmax / ctx->mg_alpha, sth = 0.5 * (lmax + slmin), sde = 0.5 * (lmax - slmin), ssig = sth / sde;
-        double srho = 1.0 / ssig;
-        const bool d4 = (ctx->cheb4 & 2) != 0;                 // FSI_CHEB4 bit 1: 4th-kind smoothing sweeps (see the solid block)
-        const double dinit = d4 ? 4.0 / (3.0 * lmax) : 1.0 / sth;
-        auto d4c = [&](int i, float* c1, float* c2) { *c1 = (float)((2.0 * i - 1.0) / (2.0 * i + 3.0)); *c2 = (float)((8.0 * i + 4.0) / ((2.0 * i + 3.0) * lmax)); };
-        launch_cheb_init_f32(st, n, frhs, ctx->ones32.p, (float)dinit, fx, fr, fd);
-        for (int k = 0; k < ctx->mg_pre; ++k) {
-          if (d4) { float c1, c2; d4c(k + 1, &c1, &c2); fine_sweep(c1, c2, k); continue; }
-          const double rn = 1.0 / (2.0 * ssig - srho);
-          fine_sweep((float)(rn * srho), (float)(2.0 * rn / sde), k);
-          srho = rn;
-        }
-        const int64_t nc = ctx->mg_nc, n4c = 4 * nc;
-        float *cr = ctx->mg_work.p, *cd = cr + n4c, *ct = cr + 2 * n4c, *cx = cr + 3 * n4c, *crhs = cr + 4 * n4c;
-        launch_mg_restrict(st, nc, ctx->mg_chptr.p, ctx->mg_child.p, ctx->mg_chw.p, ctx->mg_d0.p, fr, ctx->mg_dcinv4.p, crhs);
-        {
-          const double cl = ctx->mg_clmax, clmin = cl / ctx->mg_ckappa, cth = 0.5 * (cl + clmin), cde = 0.5 * (cl - clmin), csig = cth / cde;
-          double crho = 1.0 / csig;
-          launch_cheb_init_f32(st, n4c, crhs, ctx->mg_cones.p, (float)(1.0 / cth), cx, cr, cd);
-          float *ca = cd, *cb = ct;
-          for (int k = 0; k < ctx->mg_cits; ++k) {
-            const double rn = 1.0 / (2.0 * csig - crho);
-            if (ctx->fused_sweeps) {
-              launch_sweep_sc_f32(st, nc, ctx->mg_cptr.p, ctx->mg_ccol.p, ctx->mg_cc.p, ctx->mg_cflag.p, (float)(rn * crho),
-                                  (float)(2.0 * rn / cde), ca, cb, cx, cr);
-              std::swap(ca, cb);
-            } else {
-              launch_spmv_sc_f32(st, nc, ctx->mg_cptr.p, ctx->mg_ccol.p, ctx->mg_cc.p, ctx->mg_cflag.p, cd, ct);
-              launch_cheb_step_f32(st, n4c, ct, ctx->mg_cones.p, (float)(rn * crho), (float)(2.0 * rn / cde), cx, cr, cd);
-            }
-            crho = rn;
-          }
-        }
-        launch_mg_prolong(st, N2, ctx->mg_par.p, ctx->mg_pw.p, ctx->mg_d0.p, cx, dcur);   // correction as the next direction
-        fine_sweep(0.f, (float)dinit, -1);                                             // x += P x_c, r -= C P x_c, restart
-        srho = 1.0 / ssig;
-        for (int k = 0; k < ctx->mg_post; ++k) {
-          if (d4) { float c1, c2; d4c(k + 1, &c1, &c2); fine_sweep(c1, c2, -1); continue; }
-          const double rn = 1.0 / (2.0 * ssig - srho);
-          fine_sweep((float)(rn * srho), (float)(2.0 * rn / sde), -1);
-          srho = rn;
-        }
-        ctx->inner_its[2] += ctx->mg_pre + 1 + ctx->mg_post - ctx->cheb_its_d;     // counted below as cheb_its_d
-      } else {
-        launch_cheb_init_f32(st, n, frhs, ctx->ones32.p, (float)(1.0 / th), fx, fr, fd);
-        for (int k = 0; k < ctx->cheb_its_d; ++k) {
-          const double rn = 1.0 / (2.0 * sig - rho);
-          fine_sweep((float)(rn * rho), (float)(2.0 * rn / de), k);
-          rho = rn;
-        }
-      }
-      launch_unpad_from_f32(st, N2, fx, dd);
-    } else if (ctx->dd_is_db && ctx->sweeps_fp32)
-      cheb_db_f32(ctx, ctx->dd_db32.p, ctx->dd_dinv32.p, td, dd, IW, ctx->cheb_its_d, ctx->lmax_d, ctx->cheb_kappa_d);
-    else if (ctx->dd_is_db)
-      cheb_solve_op(ctx, n3, [&](const double* in, double* out) { launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_db.p, in, out); },
-                    ctx->Mdd.vals.p, ctx->diagpos3.p, nullptr, td, dd, IW, ctx->cheb_its_d, ctx->lmax_d, ctx->cheb_kappa_d);
-    else
-      cheb_solve(ctx, CsrRef{n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Mdd.vals.p, ctx->diagpos3.p}, nullptr, td, dd, IW,
-                 ctx->cheb_its_d, ctx->lmax_d, ctx->cheb_kappa_d);
-    ctx->inner_its[2] += ctx->cheb_its_d;
-  } else {
-    FSICHK(inner_bicgstab(ctx, ctx->Mdd,
-                          [&](const double* in, double* out) { launch_spmv(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Mdd.vals.p, in, out); },
-                          td, dd, IW, ctx->inner_rtol, ctx->inner_maxit, &ctx->inner_its[2]));
-  }
-  if (conc) HIPCHK(hipStreamWaitEvent(sA, ctx->ev_b, 0));
-  launch_merge(st, N2, V, dd, dv, dp, z);
-  if (ctx->debug_prec_apply > 0) {                 // FSI_DEBUG_PRECOND=2: non-finite entries of the parts, first applications only
-    ctx->debug_prec_apply -= 1;
-    auto bad = [&](const double* p, int64_t n) { std::vector<double> h(n); (void)hipMemcpy(h.data(), p, n * sizeof(double), hipMemcpyDeviceToHost);
-                                                  int64_t b = 0; double m = 0.0; for (double v : h) { if (!std::isfinite(v)) b++; else m = std::max(m, std::fabs(v)); }
-                                                  return std::make_pair(b, m); };
-    const auto bt = bad(tp, V), bp = bad(dp, V), bv = bad(dv, n3), bd = bad(dd, n3), bs = bad(vs, n3);
-    fprintf(stderr, "[precond] apply: rhs_p max %.3e (%lld bad)  dp max %.3e (%lld bad)  v* max %.3e (%lld bad)  dv max %.3e (%lld bad)  dd max %.3e (%lld bad)\n",
-            bt.second, (long long)bt.first, bp.second, (long long)bp.first, bs.second, (long long)bs.first, bv.second, (long long)bv.first, bd.second, (long long)bd.first);
-  }
-  ctx->inner_calls += 1;
-  if (ctx->sample_budget > 0) ctx->sample_budget -= 1;
-  if (ctx->sc_samples_pending > 0) {      // sampled launch durations of the scalar-ratio displacement SpMV
-    (void)hipEventSynchronize(ctx->sc_ev1[ctx->sc_samples_pending - 1]);
-    for (int k = 0; k < ctx->sc_samples_pending; ++k) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, ctx->sc_ev0[k], ctx->sc_ev1[k]) == hipSuccess) { ctx->t_sc.ms += ms; ctx->t_sc.calls += 1; }
-    }
-    ctx->sc_samples_pending = 0;
-  }
-  if (ctx->sch_samples_pending > 0) {     // sampled launch durations of the Schur-complement sweeps
-    (void)hipEventSynchronize(ctx->sch_ev1[ctx->sch_samples_pending - 1]);
-    for (int k = 0; k < ctx->sch_samples_pending; ++k) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, ctx->sch_ev0[k], ctx->sch_ev1[k]) == hipSuccess) { ctx->t_sch.ms += ms; ctx->t_sch.calls += 1; }
-    }
-    ctx->sch_samples_pending = 0;
-  }
-  if (ctx->db_samples_pending > 0) {      // sampled launch durations of the FP32 component-diagonal SpMV
-    (void)hipEventSynchronize(ctx->db_ev1[ctx->db_samples_pending - 1]);
-    for (int k = 0; k < ctx->db_samples_pending; ++k) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, ctx->db_ev0[k], ctx->db_ev1[k]) == hipSuccess) { ctx->t_db.ms += ms; ctx->t_db.calls += 1; }
-    }
-    ctx->db_samples_pending = 0;
-  }
-  if (ctx->ss_samples_pending > 0) {      // sampled launch durations of the solid-block SpMV (first 8 of every apply)
-    (void)hipEventSynchronize(ctx->ss_ev1[ctx->ss_samples_pending - 1]);
-    for (int k = 0; k < ctx->ss_samples_pending; ++k) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, ctx->ss_ev0[k], ctx->ss_ev1[k]) == hipSuccess) { ctx->t_ss.ms += ms; ctx->t_ss.calls += 1; }
-    }
-    ctx->ss_samples_pending = 0;
-  }
-  return FSI_OK;
-}
-
-int precondition(FsiCtx* ctx, const double* r, double* z) {
-  Phase ph(ctx, &ctx->t_prec);
-  if (ctx->precond == 0) return precondition_block(ctx, r, z);
-  launch_sptrsv_levels(ctx->stream, ctx->levels, ctx->rowptr.p, ctx->cols.p, ctx->diagpos.p, ctx->LU.p, r, ctx->tmp7.p, z);
-  return FSI_OK;
-}
-// working = true: the product inside a Krylov iteration, which may run on the FP32 copy of the matrix while the basis of this
-// Jacobian's lifetime is kept in FP32 (see solve_gcr); every other product (true residuals, the other solvers) is FP64
-int spmv(FsiCtx* ctx, const double* x, double* y, bool working = false) {
-  Phase ph(ctx, &ctx->t_spmv);
-  if (working && ctx->op32_ok && ctx->kry_fp32) {
-    ctx->op32_products += 1;
-    launch_spmv_node6p(ctx->stream, ctx->N2, ctx->V, ctx->a32_ptr.p, ctx->a32_cols.p, ctx->A32.p, ctx->rowptr.p, ctx->cols.p,
-                       ctx->a32_ptail - ctx->a32_tail_src, x, y);
-    return FSI_OK;
-  }
-  static const bool node6 = getenv("FSI_SPMV_GENERIC") == nullptr;      // FSI_SPMV_GENERIC=1: one wave per row on the plain CSR arrays
-  if (node6) launch_spmv_node6(ctx->stream, ctx->N2, ctx->V, ctx->rowptr.p, ctx->cols.p, ctx->A.p, x, y);
-  else launch_spmv(ctx->stream, ctx->ndof, ctx->rowptr.p, ctx->cols.p, ctx->A.p, x, y, SPMV_MONOLITHIC);
-  return FSI_OK;
-}
-
-}  // namespace
-
-// ---- GCR with directions kept across solves while the matrix is unchanged ----------------------------------
-// Right-preconditioned, flexible; Q = A P orthonormal.  Per iteration only Q streams through HBM (two passes: the
-// coefficients and the update, fsi_gcr.hip) and the host reads two small results; P is touched once per solve.
-void gcr_reset(FsiCtx* ctx) {
-  ctx->gs_rtol = 0.0;
-  ctx->f32_last_drift = -1.0;                // no verified cycle yet on this store
-  ctx->f64_suspect = false;                  // the pairs that were suspected are gone
-  std::fill(ctx->hot_slots.begin(), ctx->hot_slots.end(), -1);
-  ctx->hot_next = 0;
-  ctx->kry_m = 0;
-  ctx->kry_hw = 0;
-  ctx->kry_free.clear();
-  std::fill(ctx->kry_born.begin(), ctx->kry_born.end(), (int64_t)-1);
-}
-
-namespace {
-
-// device -> pinned host read of `cnt` doubles; the only host waits of the Krylov loop go through here
-int gcr_read(FsiCtx* ctx, const double* dptr, int cnt, double* host) {
-  HIPCHK(hipMemcpyAsync(host, dptr, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  return FSI_OK;
-}
-size_t qbytes(const FsiCtx* ctx) { return ctx->kry_fp32 ? sizeof(float) : sizeof(double); }
-
-// One solve cycle's bookkeeping: the directions made since the last flush are p_k = sum_j cn[k][j] Z_j (Z_j explicit
-// for older slots, the raw preconditioned vector for the new ones) and x = x_flushed + sum_j y[j] Z_j.
-struct GcrCycle {
-  std::vector<double> y;                 // [cap]
-  std::vector<std::vector<double>> cn;   // knew columns of length cap
-  std::vector<int32_t> slots;            // their slots
-};
-
-// retire the oldest directions of the rotating part of the store (everything explicit: call after a flush)
-int gcr_retire(FsiCtx* ctx, int batch) {
-  const int64_t cap = ctx->kry_cap;
-  const int64_t ring = std::min<int64_t>(64, cap / 2);
-  const int64_t protect = cap - ring;          // the first `protect` directions of this Jacobian stay: they resolved the hardest modes
-  std::vector<std::pair<int64_t, int32_t>> cand;
-  for (int64_t sidx = 0; sidx < ctx->kry_hw; ++sidx)
-    if (ctx->kry_born[sidx] >= protect) cand.emplace_back(ctx->kry_born[sidx], (int32_t)sidx);
-  std::sort(cand.begin(), cand.end());
-  for (int k = 0; k < batch && k < (int)cand.size(); ++k) {
-    const int32_t sidx = cand[k].second;
-    HIPCHK(hipMemsetAsync(ctx->KQ.p + (size_t)sidx * ctx->ldq * qbytes(ctx), 0, (size_t)ctx->ldq * qbytes(ctx), ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->KZ.p + (size_t)sidx * ctx->ldz, 0, (size_t)ctx->ldz * sizeof(double), ctx->stream));
-    ctx->kry_born[sidx] = -1;
-    ctx->kry_free.push_back(sidx);
-  }
-  return FSI_OK;
-}
-
-int gcr_flush(FsiCtx* ctx, GcrCycle& cy, double* x) {
-  const int64_t n = ctx->ndof;
-  const int m = (int)ctx->kry_hw, knew = (int)cy.slots.size();
-  if (m == 0) return FSI_OK;
-  bool any = knew > 0;
-  for (int j = 0; j < m && !any; ++j) any = cy.y[j] != 0.0;
-  if (!any) return FSI_OK;
-  Phase ph(ctx, &ctx->t_flush);
-  const int kw = gcr_flush_width(knew);
-  std::vector<double> pack((size_t)m * (kw + 1), 0.0);
-  std::copy(cy.y.begin(), cy.y.begin() + m, pack.begin());
-  for (int k = 0; k < knew; ++k) std::copy(cy.cn[k].begin(), cy.cn[k].begin() + m, pack.begin() + (size_t)m * (k + 1));
-  HIPCHK(hipMemcpyAsync(ctx->gcr_y.p, pack.data(), (size_t)m * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  if (knew > 0) {
-    HIPCHK(hipMemcpyAsync(ctx->gcr_cn.p, pack.data() + m, (size_t)m * kw * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->gcr_slots.p, cy.slots.data(), (size_t)knew * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-  }
-  launch_gcr_flush(ctx->stream, ctx->KZ.p, ctx->ldz, n, m, ctx->gcr_y.p, ctx->gcr_cn.p, ctx->gcr_slots.p, knew, x);
-  HIPCHK(hipStreamSynchronize(ctx->stream));       // `pack` is pageable host memory: keep it alive until the copies are done
-  ctx->ortho_z_cols += m;
-  ctx->ortho_z_launches += 1;
-  std::fill(cy.y.begin(), cy.y.end(), 0.0);
-  cy.cn.clear();
-  cy.slots.clear();
-  return FSI_OK;
-}
-
-// One cycle: reduce |r| (r holds the current residual, updated by recurrence) to `target` (absolute).  x accumulates.
-int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floor, int max_it, int* iters, double* rnorm_out) {
-  const int64_t n = ctx->ndof;
-  hipStream_t st = ctx->stream;
-  const bool f32 = ctx->kry_fp32 != 0;
-  double* z = ctx->tmp2.p;
-  double* w = ctx->tmp3.p;
-  double* hh = ctx->gcr_host;
-  const int64_t cap = ctx->kry_cap;
-  const int batch = (int)std::max<int64_t>(1, std::min<int64_t>(32, cap / 4));
-  GcrCycle cy;
-  cy.y.assign(cap, 0.0);
-  // FP32 storage: a cycle never has to reach below 1e-5 of its start, and the restart from the true residual absorbs
-  // what a single pass leaves behind, so only a cancellation beyond 100x asks for the second pass
-  double reorth = ctx->kry_fp32 ? 0.01 : std::min(0.5, std::max(0.01, 1.0 / (rtol_floor * 9e10)));
-  if (ctx->part && !ctx->kry_fp32) reorth = std::max(reorth, 0.1);      // partitioned FP64 basis: |w'|^2 is not measured in the first pass (see below)
-  if (ctx->gcr_reorth > 0.0) reorth = ctx->gcr_reorth;
-  std::fill(ctx->hot_slots.begin(), ctx->hot_slots.end(), -1);      // FP64 window: directions of this cycle only
-  ctx->hot_next = 0;
-  double rn2 = 0.0, r_entry = 0.0;
-  {   // projection on the recycled space: r -= Q (Q^T r), x-coefficients y = Q^T r
-    Phase ph(ctx, &ctx->t_ortho);
-    const int m = (int)ctx->kry_hw;
-    launch_gcr_dots(st, f32, ctx->KQ.p, ctx->ldq, n, m, r, nullptr, ctx->scratch.p, ctx->hcoef.p);
-    FSICHK(gcr_read(ctx, ctx->hcoef.p, m + 2, hh));
-    ctx->ortho_q_cols += m; ctx->ortho_q_launches += 1;
-    if (ctx->part) {
-      FSICHK(allreduce(ctx, hh, m + 2));
-      HIPCHK(hipMemcpyAsync(ctx->hcoef.p, hh, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
-    }
-    rn2 = hh[m];
-    r_entry = std::sqrt(std::max(rn2, 0.0));
-    if (m > 0) {
-      for (int j = 0; j < m; ++j) cy.y[j] = ctx->kry_born[j] >= 0 ? hh[j] : 0.0;
-      launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, r, nullptr, ctx->scratch.p, ctx->gcr_out.p);
-      FSICHK(gcr_read(ctx, ctx->gcr_out.p, 2, hh));
-      ctx->ortho_q_cols += m; ctx->ortho_q_launches += 1;
-      FSICHK(allreduce(ctx, hh, 1));
-      rn2 = hh[0];
-    }
-  }
-  double rnorm = std::sqrt(std::max(rn2, 0.0));
-  // New directions are made from the residual (GCR).  FSI_GCR_ARNOLDI=1 makes them from the latest q instead (the same
-  // Krylov space in exact arithmetic, without the cancellation of A M^-1 r_k against the previous direction after a step
-  // of little progress) - measured on the 6.6 k-tet fixture: twice the iterations and stagnation near 1e-3, because the
-  // FP32 sweeps of the preconditioner resolve what is large in their input, and only the residual has the components
-  // that still matter as its large ones.
-  double* qd = ctx->tmp5.p;
-  const double* src = r;
-  // attainable accuracy: near round-off (a tolerance of 1e-11 on a system with the 1e7 penalty) the recurrence can hover just
-  // above the target for thousands of iterations; 40 iterations without a 10 % gain within a factor 100 of the target (FP32
-  // basis: anywhere - the restart from the true residual is harmless) end the cycle and solve_gcr decides
-  double best = rnorm;
-  int since_gain = 0;
-  ctx->gcr_stagnated = false;
-  ctx->gcr_stalled = false;
-  bool rr_pending = false;     // partitioned: the last update's local |r|^2 has not been all-reduced yet (it rides with the next pass)
-  while (rnorm > target && *iters < max_it) {
-    if (since_gain >= 40 && (f32 || rnorm <= 100.0 * target)) { ctx->gcr_stagnated = true; break; }
-    // FP32 basis, four decades below the residual the cycle was entered with and six iterations without a 10 % gain: this is
-    // the floor of the FP32 columns, not a plateau - the new q are orthogonal to the kept ones to 1e-7 times the cancellation,
-    // r has collected that much of span(Q), and directions made orthogonal to Q cannot remove it.  Ending the cycle costs the
-    // verdict's product and a projection, which removes it at once (48 k-tet mesh: |r| crawled from 6.05e-8 to 6.01e-8 in 37
-    // iterations, and the projection that followed took it to a third of the target without a single new direction).
-    if (f32 && since_gain >= 6 && rnorm <= 1e-4 * r_entry) { ctx->gcr_stagnated = true; break; }
-    // Far from the target, the store full (the oldest directions kept, a ring of 64 rotating) and no 10 % gain in two turns
-    // of the ring: the TRUNCATED recurrence is stuck where the full one would sit out the plateau - seen late in a Jacobian's
-    // life on the known-answer case driven to round-off, |r| flat to four digits for 3 700 iterations.  solve_gcr drops the
-    // kept directions and restarts from the true residual with room for a full recurrence again.  (Not applied while the
-    // store still grows: plateaus of 100+ iterations are normal on these systems, and a restart inside one loses the space
-    // that is about to end it.)
-    if (since_gain >= 128 && ctx->kry_hw == cap && ctx->kry_free.empty()) { ctx->gcr_stalled = true; break; }
-    if (ctx->part && ctx->ras) {
-      // restricted additive Schwarz: the local solve sees the residual on its overlap (complete ghost rows), zero on the
-      // outermost layer; below, the owners' part of the result replaces whatever the overlap produced
-      double* rin = ctx->tmp4.p;
-      launch_copy(st, rin, src, n);
-      FSICHK(halo_update(ctx, rin));
-      if (ctx->nident) launch_bc_set(st, rin, ctx->ident_idx.p, ctx->ghost_zero.p, ctx->nident);
-      FSICHK(precondition(ctx, rin, z));
-    } else {
-      FSICHK(precondition(ctx, src, z));
-    }
-    FSICHK(halo_update(ctx, z));      // partitioned: the preconditioner is rank-local (additive Schwarz on the ghost layer)
-    FSICHK(spmv(ctx, z, w, true));
-    zero_ghost(ctx, w);               // ghost rows are identity rows; residual-type vectors carry zeros there
-    // a free slot for the new direction; when the store is full everything is made explicit first, then the oldest
-    // directions of its rotating part are retired in a batch
-    if (ctx->kry_free.empty() && ctx->kry_hw == cap) {
-      FSICHK(gcr_flush(ctx, cy, x));
-      FSICHK(gcr_retire(ctx, batch));
-      for (int k = 0; k < 32; ++k)
-        if (ctx->hot_slots[k] >= 0 && ctx->kry_born[ctx->hot_slots[k]] < 0) {      // a retired direction leaves the window too
-          ctx->hot_slots[k] = -1;
-          if (ctx->KQh.p) HIPCHK(hipMemsetAsync(ctx->KQh.p + (size_t)k * ctx->ldq, 0, (size_t)ctx->ldq * sizeof(double), st));
-        }
-    }
-    int slot;
-    if (!ctx->kry_free.empty()) { slot = ctx->kry_free.back(); ctx->kry_free.pop_back(); }
-    else { slot = (int)ctx->kry_hw; ctx->kry_hw += 1; }
-    // the slot's old q column is zero (retired) or about to be scanned as garbage: a fresh slot beyond the previous
-    // high-water mark must not contribute, so it is cleared once here
-    if (slot == (int)ctx->kry_hw - 1 && ctx->kry_born[slot] < 0)
-      HIPCHK(hipMemsetAsync(ctx->KQ.p + (size_t)slot * ctx->ldq * qbytes(ctx), 0, (size_t)ctx->ldq * qbytes(ctx), st));
-    const int m = (int)ctx->kry_hw;
-    std::vector<double> htot(m, 0.0);
-    double wn = 0.0, wr = 0.0, w0 = 0.0, w_first = 0.0;
-    {
-      // classical Gram-Schmidt; a second pass when the first one cancelled w by more than 1 / reorth.  With recycled
-      // directions w = A M^-1 r lies mostly IN the kept space, so the usual 2x criterion fires on most iterations; the
-      // orthogonality lost in one pass only matters relative to the tolerance asked for.
-      // The update kernel reads the coefficients from device memory, so in a single context it is queued right behind
-      // the product kernel and the host reads both results in one wait per pass (partitioned: the coefficients are
-      // all-reduced by the host in between).  The phase timer brackets the kernels only, not the host's wait.
-      double* hh_hot = hh + cap + 4;                 // second staging area of the pinned buffer (nh + 2 <= 34 values)
-      int nh = 0;
-      if (f32) {
-        // exact (FP64) Gram-Schmidt against the window of this cycle's directions first;
-        // columns [0, nh) of the window are in use (it fills from 0 and then turns into a ring)
-        for (int k = 0; k < 32; ++k)
-          if (ctx->hot_slots[k] >= 0) nh = k + 1;
-        if (nh > 0) {
-          {
-            Phase ph(ctx, &ctx->t_ortho);
-            launch_gcr_dots(st, false, ctx->KQh.p, ctx->ldq, n, nh, w, nullptr, ctx->scratch.p, ctx->hcoef_hot.p);
-            if (!ctx->part)
-              launch_gcr_axpy(st, false, ctx->KQh.p, ctx->ldq, n, nh, ctx->hcoef_hot.p, w, nullptr, ctx->scratch.p, ctx->gcr_out.p);
-          }
-          if (ctx->part) {
-            FSICHK(gcr_read(ctx, ctx->hcoef_hot.p, nh + 2, hh_hot));
-            FSICHK(allreduce(ctx, hh_hot, nh + 2));
-            ctx->part_allreduces += 1;
-            HIPCHK(hipMemcpyAsync(ctx->hcoef_hot.p, hh_hot, (size_t)nh * sizeof(double), hipMemcpyHostToDevice, st));
-            Phase ph(ctx, &ctx->t_ortho);
-            launch_gcr_axpy(st, false, ctx->KQh.p, ctx->ldq, n, nh, ctx->hcoef_hot.p, w, nullptr, ctx->scratch.p, ctx->gcr_out.p);
-          } else {
-            // read with the first pass below (stream order: the copy sees the values before hcoef_hot is reused)
-            HIPCHK(hipMemcpyAsync(hh_hot, ctx->hcoef_hot.p, (size_t)(nh + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
-          }
-          ctx->ortho_q_cols += 2 * (int64_t)nh * 2; ctx->ortho_q_launches += 2;      // FP64 columns counted as two FP32 ones
-        }
-      }
-      bool hot_pending = nh > 0;
-      for (int pass = 0; pass < 2; ++pass) {
-        double h2[2] = {0.0, 0.0};
-        if (ctx->part) {
-          // ONE all-reduce per pass while the basis is FP64: the m coefficients, |w|^2, w.r and - riding along - this rank's
-          // part of |r|^2 as the previous iteration's update kernel left it (the exact norm of the residual this iteration
-          // starts from).  What the update needs follows without a second reduction: |w'|^2 = |w|^2 - |h|^2 (the pass is
-          // repeated when that cancels by more than 1 / reorth, and the repeat measures |w'|^2 directly), w'.r = w.r because
-          // r is kept orthogonal to every q.  With an FP32 basis the identity is not good enough: the stored columns are
-          // orthonormal to 1e-7 only, |w'|^2 comes out wrong by h^T (Q^T Q - I) h, the new column is then not a unit vector
-          // and every later projection on it is off by that factor (measured: a 2-rank run lost a cycle and fell back to
-          // FP64, a 1-rank run needed 184 instead of 50 iterations every other time) - so the FP32 basis pays a second,
-          // two-number reduction for the exact |w'|^2 and w'.r after the update of w, as in round 2.
-          {
-            Phase ph(ctx, &ctx->t_ortho);
-            launch_gcr_dots(st, f32, ctx->KQ.p, ctx->ldq, n, m, w, r, ctx->scratch.p, ctx->hcoef.p);
-          }
-          static const bool rccl_host = getenv("FSI_RCCL_HOST_REDUCE") != nullptr;      // debugging aid: stage the reductions through the host
-          double exact2[2] = {0.0, 0.0};
-          if (ctx->rccl && !rccl_host) {
-            // the library's own communicator: the reductions run on the vectors where they are (device memory, solver stream)
-            // and the update kernel is queued right behind them; the host reads the reduced numbers once per pass, for its
-            // bookkeeping, exactly as in a single context
-            if (rr_pending) HIPCHK(hipMemcpyAsync(ctx->hcoef.p + m + 2, ctx->gcr_out.p + 4, sizeof(double), hipMemcpyDeviceToDevice, st));
-            else HIPCHK(hipMemsetAsync(ctx->hcoef.p + m + 2, 0, sizeof(double), st));
-            FSICHK(rccl_allreduce_dev(ctx, ctx->hcoef.p, m + 3));
-            {
-              Phase ph(ctx, &ctx->t_ortho);
-              launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, w, r, ctx->scratch.p, ctx->gcr_out.p + 2);
-            }
-            if (f32) {
-              FSICHK(rccl_allreduce_dev(ctx, ctx->gcr_out.p + 2, 2));
-              HIPCHK(hipMemcpyAsync(exact2, ctx->gcr_out.p + 2, sizeof exact2, hipMemcpyDeviceToHost, st));
-            }
-            HIPCHK(hipMemcpyAsync(hh, ctx->hcoef.p, (size_t)(m + 3) * sizeof(double), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-          } else {
-            HIPCHK(hipMemcpyAsync(hh, ctx->hcoef.p, (size_t)(m + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
-            if (rr_pending) HIPCHK(hipMemcpyAsync(hh + m + 2, ctx->gcr_out.p + 4, sizeof(double), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            if (!rr_pending) hh[m + 2] = 0.0;
-            FSICHK(allreduce(ctx, hh, m + 3));
-            HIPCHK(hipMemcpyAsync(ctx->hcoef.p, hh, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
-            {
-              Phase ph(ctx, &ctx->t_ortho);
-              launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, w, r, ctx->scratch.p, ctx->gcr_out.p + 2);
-            }
-            if (f32) {
-              FSICHK(gcr_read(ctx, ctx->gcr_out.p + 2, 2, exact2));
-              FSICHK(allreduce(ctx, exact2, 2));
-            }
-          }
-          ctx->part_allreduces += f32 ? 2 : 1;
-          if (rr_pending) { rn2 = hh[m + 2]; rr_pending = false; }      // exact |r|^2 before this iteration's update
-          double hsq = 0.0;
-          for (int j = 0; j < m; ++j) hsq += hh[j] * hh[j];
-          h2[0] = f32 ? exact2[0] : std::max(hh[m] - hsq, 0.0);
-          h2[1] = f32 ? exact2[1] : hh[m + 1];
-          if (ctx->debug_gcr && *iters < 6)
-            fprintf(stderr, "[gcr]   partitioned pass %d: |w|^2 %.6e |h|^2 %.6e w.r %.6e lagged |r|^2 %.6e window: nh %d |w|^2 %.6e\n", pass, hh[m], hsq,
-                    hh[m + 1], hh[m + 2], nh, nh > 0 ? hh_hot[nh] : 0.0);
-        } else {
-          {
-            Phase ph(ctx, &ctx->t_ortho);
-            launch_gcr_dots(st, f32, ctx->KQ.p, ctx->ldq, n, m, w, nullptr, ctx->scratch.p, ctx->hcoef.p);
-            launch_gcr_axpy(st, f32, ctx->KQ.p, ctx->ldq, n, m, ctx->hcoef.p, w, r, ctx->scratch.p, ctx->gcr_out.p);
-          }
-          HIPCHK(hipMemcpyAsync(hh, ctx->hcoef.p, (size_t)(m + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
-          HIPCHK(hipMemcpyAsync(hh + m + 2, ctx->gcr_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-          HIPCHK(hipStreamSynchronize(st));
-          h2[0] = hh[m + 2]; h2[1] = hh[m + 3];
-        }
-        if (hot_pending) {                       // the window's coefficients (read by the wait above, or all-reduced before)
-          w0 = std::sqrt(std::max(hh_hot[nh], 0.0));
-          for (int k = 0; k < nh; ++k)
-            if (ctx->hot_slots[k] >= 0) htot[ctx->hot_slots[k]] += hh_hot[k];
-          hot_pending = false;
-        }
-        if (pass == 0 && w0 == 0.0) w0 = std::sqrt(std::max(hh[m], 0.0));
-        if (pass == 0) w_first = w0;
-        for (int j = 0; j < m; ++j) htot[j] += hh[j];
-        if (ctx->debug_gcr) {
-          const double wref = std::sqrt(std::max(hh[m], 0.0));
-          for (int j = 0; j < m; ++j) {
-            const double a = std::fabs(hh[j]);
-            ctx->dbg_cols += 1;
-            if (a > 1e-6 * wref) ctx->dbg_sig6 += 1;
-            if (a > 1e-9 * wref) ctx->dbg_sig9 += 1;
-            if (a > 1e-12 * wref) ctx->dbg_sig12 += 1;
-          }
-        }
-        ctx->ortho_q_cols += 2 * (int64_t)m; ctx->ortho_q_launches += 2;
-        wn = std::sqrt(std::max(h2[0], 0.0));
-        wr = h2[1];
-        // What one pass leaves of span(Q) in w' is (non-orthonormality of Q) x (cancellation |w| / |w'|), and that is the new
-        // column's own error against the kept ones: with cancellations of 10 - 200 on most iterations a loose criterion lets
-        // Q^T Q - I grow by that factor per column (measured on the avf problem, FP64 basis, second pass only beyond 100x:
-        // 1.5e-4, 4e-3, then q_217 . q_221 = 1.0 - duplicate columns, |r| flat for 40 iterations at a time).  The pass itself
-        // tells: |w'|^2 measured by the update kernel against |w|^2 - |h|^2, which differ by h^T (Q^T Q - I) h; their relative
-        // difference over the cancellation estimates the error the new column would carry, and a second pass is made when
-        // that exceeds the floor of the basis (FP64: 1e-9; FP32 columns are orthonormal to 6e-8 by storage: 3e-7 - scanned on the
-        // 100-step run of the bench problem: 1e-5 and 1e-6 leave two fall-backs from the FP32 basis late in a Jacobian's life,
-        // 3e-7 none, 13.1 against 12.2 - 12.35 Newton-it/s; the 20-step bench pays 0.6 %).
-        bool lost = false;
-        if (pass == 0 && (!ctx->part || f32) && h2[0] > 0.0 && hh[m] > 0.0) {
-          double hsq2 = 0.0;
-          for (int j = 0; j < m; ++j) hsq2 += hh[j] * hh[j];
-          const double disc = std::fabs(h2[0] - (hh[m] - hsq2)) / h2[0];
-          const double canc = std::sqrt(hh[m] / h2[0]);
-          lost = disc / canc > (f32 ? ctx->orth_floor32 : ctx->orth_floor64);
-          if (lost) ctx->gcr_reorth_forced += 1;
-        }
-        if (wn > reorth * w0 && !lost) break;
-        w0 = wn;
-      }
-    }
-    if (!(wn > 0.0) || !std::isfinite(wn)) {
-      char buf[200];
-      snprintf(buf, sizeof buf, "GCR breakdown (A M^-1 r vanished or is not finite): |w'| %.3e, |w| %.3e, w.r %.3e, %d kept, iteration %d", wn, w0, wr, m, *iters);
-      ctx->err = buf;
-      return FSI_ERR_LINEAR;
-    }
-    const double alpha = wr / wn;          // q . r with q = w / wn
-    if (f32) {                              // the exact q goes into the FP64 window (ring of 32)
-      qd = ctx->KQh.p + (size_t)ctx->hot_next * ctx->ldq;
-      ctx->hot_slots[ctx->hot_next] = slot;
-      ctx->hot_next = (ctx->hot_next + 1) % 32;
-    }
-    launch_gcr_update(st, f32, ctx->KQ.p, ctx->ldq, ctx->KZ.p, ctx->ldz, slot, n, w, z, 1.0 / wn, alpha, r, qd, ctx->scratch.p,
-                      ctx->gcr_out.p + 4);
-    src = (ctx->gcr_arnoldi && !f32) ? qd : r;
-    // A direction that left the residual where it was (alpha^2 below 1e-3 |r|^2): A M^-1 r lies in the kept space, and as r
-    // has not moved the next A M^-1 r is the same vector again - GCR proper cannot leave this point (seen on the 100 k-tet
-    // mesh: |r| constant to four digits for 40 iterations until the stagnation rule ended the cycle, and again in the next
-    // solve, which then lost the FP32 basis and the recycled space).  The next direction is made from the q just stored
-    // instead (an Arnoldi step: the Krylov space of A M^-1 keeps growing whatever r does) until the residual moves again.
-    if (alpha * alpha <= ctx->gcr_escape * rnorm * rnorm) { src = qd; ctx->gcr_arnoldi_steps += 1; }
-    // coefficients of the new direction on the store:  p = (z - sum_j h_j p_j) / wn
-    std::vector<double> c(cap, 0.0);
-    c[slot] = 1.0;
-    for (int j = 0; j < m; ++j) {
-      const double hj = htot[j];
-      if (hj == 0.0 || j == slot) continue;
-      bool is_new = false;
-      for (size_t k = 0; k < cy.slots.size(); ++k)
-        if (cy.slots[k] == j) {                 // a direction of this cycle: expand it on the store
-          for (int64_t i = 0; i < cap; ++i) c[i] -= hj * cy.cn[k][i];
-          is_new = true;
-          break;
-        }
-      if (!is_new) c[j] -= hj;
-    }
-    for (auto& v : c) v /= wn;
-    for (int64_t i = 0; i < cap; ++i) cy.y[i] += alpha * c[i];
-    cy.cn.push_back(std::move(c));
-    cy.slots.push_back(slot);
-    ctx->kry_born[slot] = ctx->kry_m;
-    ctx->kry_m += 1;
-    *iters += 1;
-    ctx->kry_iters += 1;
-    // |r|: the recurrence value; read back (it is one host wait, shared with nothing else) because the analytic
-    // |r|^2 - alpha^2 loses its digits exactly when the iteration converges fast
-    if (ctx->part) {
-      // |r'|^2 = |r|^2 - alpha^2 from the exact |r|^2 this iteration started with; the exact value of |r'|^2 (this rank's
-      // part is in gcr_out[4]) travels with the next pass's reduction.  Only an iteration that looks converged pays a
-      // reduction of its own, to be sure.
-      rn2 = std::max(rn2 - alpha * alpha, 0.0);
-      rr_pending = true;
-      if (std::sqrt(rn2) <= target || !std::isfinite(rn2)) {
-        FSICHK(gcr_read(ctx, ctx->gcr_out.p + 4, 1, hh));
-        FSICHK(allreduce(ctx, hh, 1));
-        ctx->part_allreduces += 1;
-        rn2 = hh[0];
-        rr_pending = false;
-      }
-      rnorm = std::sqrt(std::max(rn2, 0.0));
-    } else {
-      FSICHK(gcr_read(ctx, ctx->gcr_out.p + 4, 1, hh));
-      rnorm = std::sqrt(std::max(hh[0], 0.0));
-    }
-    if (ctx->debug_gcr && getenv("FSI_DEBUG_GCR_ALL"))
-      fprintf(stderr, "[gcr]     it %d: |w'|/|w| %.2e alpha/|r| %.2e |r| %.4e%s\n", *iters, wn / std::max(w_first, 1e-300), alpha / std::max(rnorm, 1e-300), rnorm, src == r ? "" : " (next from q)");
-    if (ctx->debug_gcr && (*iters % 10 == 0)) {
-      fprintf(stderr, "[gcr] it %d |r| %.3e target %.3e m %d  |h_j| > 1e-6/1e-9/1e-12 |w|: %.2f %.2f %.2f of the columns\n", *iters, rnorm, target, m,
-              (double)ctx->dbg_sig6 / std::max<int64_t>(1, ctx->dbg_cols), (double)ctx->dbg_sig9 / std::max<int64_t>(1, ctx->dbg_cols),
-              (double)ctx->dbg_sig12 / std::max<int64_t>(1, ctx->dbg_cols));
-      fflush(stderr);
-    }
-    if (!std::isfinite(rnorm)) { ctx->err = "GCR diverged (non-finite residual)"; return FSI_ERR_LINEAR; }
-    if (rnorm < 0.9 * best) { best = rnorm; since_gain = 0; } else since_gain += 1;
-    if ((int)cy.slots.size() == 32) FSICHK(gcr_flush(ctx, cy, x));
-  }
-  FSICHK(gcr_flush(ctx, cy, x));
-  *rnorm_out = rnorm;
-  return FSI_OK;
-}
-
-}  // namespace
-
-int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it, int* iters, double* relres) {
-  const int64_t n = ctx->ndof;
-  hipStream_t st = ctx->stream;
-  double* r = ctx->tmp1.p;
-  launch_copy(st, r, rhs, n);
-  launch_fill(st, x, n, 0.0);
-  double bnorm = 0.0, rnorm = 0.0;
-  FSICHK(gnorm2(ctx, r, &bnorm));
-  *iters = 0;
-  if (bnorm == 0.0) { *relres = 0.0; return FSI_OK; }
-  if (!std::isfinite(bnorm)) { ctx->err = "non-finite right-hand side"; return FSI_ERR_LINEAR; }
-  // Storage of Q for this Jacobian's lifetime, decided by the first solve after the refresh: FP32 (half the dominant
-  // stream, exact FP64 window for the directions of the current cycle, restart from the true residual) when the accuracy
-  // that may be asked for during the lifetime leaves room for it.  Inside fsi_newton_solve that is the floor of the
-  // forcing term at the largest right-hand side seen so far (tol_hint); the inexact-Newton tolerances of a production run
-  // qualify (5e-7 on the bench), the parity tests that drive Newton to round-off keep FP64.
-  if (ctx->kry_hw == 0 && ctx->kry_fp32_policy == 3) ctx->kry_fp32 = 0;
-  if (ctx->kry_hw == 0 && ctx->kry_fp32_policy == 2) {
-    const double lowest = ctx->tol_hint > 0.0 ? std::min(ctx->tol_hint, rtol) : rtol;
-    ctx->kry_fp32 = lowest >= 1e-7;
-  }
-  // the kept directions serve every later solve with this matrix, so the tightest tolerance asked for since the refresh
-  // decides the re-orthogonalisation criterion, not this solve's
-  ctx->gs_rtol = ctx->gs_rtol > 0.0 ? std::min(ctx->gs_rtol, rtol) : rtol;
-  double rstart = bnorm;
-  rnorm = bnorm;
-  auto true_residual = [&]() -> int {
-    FSICHK(halo_update(ctx, x));
-    FSICHK(spmv(ctx, x, ctx->tmp3.p));
-    zero_ghost(ctx, ctx->tmp3.p);
-    launch_axpby(st, r, 1.0, rhs, -1.0, ctx->tmp3.p, n);
-    return gnorm2(ctx, r, &rnorm);
-  };
-  int stalls = 0;
-  bool near_ok = false;
-  const int64_t cap_now = ctx->kry_cap;
-  for (int cyc = 0; cyc < 8 && *iters < max_it; ++cyc) {
-    // FP32 storage of Q: the residual recurrence of one cycle is good to about 1e-6 of the residual the cycle started from;
-    // a tighter request is met by restarting the cycle from the true residual b - A x (iterative refinement).  With the FP32
-    // copy of the matrix in the iterations every answer is judged on the residual of the FP64 matrix before it is returned
-    // (one FP64 product per cycle); without it, every answer asked for below 1e-4
-    const bool f32 = ctx->kry_fp32 != 0;
-    // (measured on the bench workload, round 3: at a recurrence residual of 6e-6 |b| the true one differs in the third digit,
-    // at 1e-2 not in the fourth; the first solve on a fresh FP32 store is the exception - 6e-5 against 4e-4 - and the
-    // verdict below catches it.  A cycle may therefore run down to 1e-6 of its start; round 2's 1e-5 cost every first solve
-    // of a time step - tolerances of 3e-6 .. 9e-6 - a second cycle: one more FP64 product and two passes over Q.)
-    const double target = f32 ? std::max(rtol * bnorm, ctx->f32_cycle_floor * rstart) : rtol * bnorm;
-    const int its0 = *iters;
-    FSICHK(gcr_cycle(ctx, r, x, target, ctx->gs_rtol, max_it, iters, &rnorm));
-    if (!f32) {
-      // FP64 basis.  The recurrence residual is only as good as the kept pairs: x is built from the directions p_k, the
-      // recurrence from q_k, and A p_k = q_k holds to round-off TIMES what the recursion p_k = (z_k - sum_j h_jk p_j) / |w'|
-      // has amplified - measured on the known-answer case driven to 1e-11: 1e-9 for the pairs of a fresh Jacobian, 5e-6 within
-      // 33 directions of a hard solve (every step cancelling w a hundredfold), 1e+2 a Jacobian lifetime later, with the
-      // recurrence reporting 1e-11 all along.  So the answer of every cycle is judged on b - A x with the FP64 matrix (one
-      // product, as the FP32 basis always did), the next cycle starts from that residual (iterative refinement over the
-      // pairs' inconsistency), and a cycle that does not halve the true residual means the kept pairs are no longer pairs:
-      // they are dropped.
-      //
-      // When the verdict is taken: always for tight answers (below 1e-8), after anything that has shown the pairs at risk - a
-      // fall-back from the FP32 basis in this Jacobian's life, a full (rotating) store, a cycle of more than 64 iterations, a
-      // stalled or stagnated cycle, an earlier verdict of this store that differed from its recurrence by more than a tenth
-      // of the tolerance - and on the first cycle's answer otherwise NOT: with a fresh Jacobian, a growing store and loose
-      // tolerances (the all-FP64-storage production runs: 1e-5 .. 1e-2) the pairs hold to 1e-9 (measured), the FP64
-      // operator is the one the iterations ran on, and the product is 2.7 % of such a run.
-      const bool at_risk = rtol < 1e-8 || ctx->kry_fp32_policy == 3 || (ctx->kry_hw == cap_now && ctx->kry_free.empty()) ||
-                           *iters - its0 > 64 || ctx->gcr_stalled || ctx->gcr_stagnated || ctx->f64_suspect || cyc > 0 ||
-                           rnorm > rtol * bnorm;
-      if (!at_risk) break;
-      const double rec64 = rnorm;
-      FSICHK(true_residual());
-      if (std::fabs(rnorm - rec64) > 0.1 * rtol * bnorm) ctx->f64_suspect = true;
-      if (rnorm <= rtol * bnorm) break;
-      // attainable accuracy: a tolerance at round-off level (1e-11 on a system with the 1e7 penalty rows) may be met by the
-      // recurrence and missed by a factor of a few by b - A x; a second verified cycle that is still within 100x is as good
-      // as FP64 makes it, and Newton's own residual check judges the step
-      if (rtol <= 1e-9 && rnorm <= 100.0 * rtol * bnorm && (ctx->gcr_stagnated || cyc >= 1)) { near_ok = true; break; }
-      if (*iters >= max_it) break;
-      if (ctx->gcr_stalled || !(rnorm < 0.5 * rstart)) {      // (stalled: the truncated recurrence of a full store made no progress)
-        if (stalls >= 2) break;
-        stalls += 1;
-        ctx->gcr_restarts += 1;
-        gcr_reset(ctx);                      // x keeps what the flushed directions gave it
-      }
-      rstart = rnorm;
-      continue;
-    }
-    const bool final_cycle = target <= rtol * bnorm * (1.0 + 1e-12);
-    if (final_cycle && rtol >= 1e-4 && !ctx->op32_ok) break;
-    // A loose answer (the later Newton iterations of a step ask for 1e-3 .. 1e-2; 38 of the bench's 58 solves, 2.65 ms of FP64
-    // product each): recurrence and truth agree to three digits and better there (every FP32 cycle of the bench and of the avf
-    // runs, once the kept columns stay orthonormal - the first attempt at this skip met a solve that reported 1e-2 with a
-    // true residual of 1.7 |b|: duplicate columns, see the orthogonality criterion in gcr_cycle), and the next thing that
-    // happens is Newton's assembly of the FP64 residual from the updated state, the judge of the step either way.  Skipped
-    // only while the LAST VERIFIED cycle on this store found recurrence and truth closer than 1 % of what is asked now, the
-    // new directions all sat in the exact FP64 window and nothing stagnated.
-    // Only inside fsi_newton_solve (in_newton): there the FP64 residual assembled from the updated state follows and judges the
-    // step.  A direct fsi_solve caller has no such judge, so its answers always get the FP64 verdict and `relres`
-    // is the true residual; when verdicts_skipped counts up, the FsiNewtonIter.lin_relres of that iteration is the recurrence value.
-    if (ctx->in_newton && final_cycle && rtol >= ctx->f32_verdict_skip_rtol && rnorm <= rtol * bnorm && *iters - its0 <= 32 && !ctx->gcr_stagnated &&
-        ctx->f32_last_drift >= 0.0 && ctx->f32_last_drift <= 0.01 * rtol) {
-      ctx->verdicts_skipped += 1;
-      break;
-    }
-    const double rec32 = rnorm;
-    FSICHK(true_residual());
-    ctx->f32_last_drift = std::fabs(rnorm - rec32) / bnorm;
-    if (getenv("FSI_DEBUG_TRUERES"))
-      fprintf(stderr, "[gcr]   fp32 cycle %d: recurrence |r|/|b| %.3e (target %.3e), true %.3e, rtol %.1e, its %d\n", cyc, rec32 / bnorm, target / bnorm, rnorm / bnorm, rtol, *iters);
-    if (rnorm <= rtol * bnorm) break;
-    if (!(rnorm < 0.5 * rstart)) {
-      // the cycle did not bring the true residual down: FP32 storage has lost this system (a tolerance near round-off,
-      // or a cancellation the FP64 window did not cover).  Drop the kept directions and finish in FP64 from here.
-      if (ctx->kry_fp32_policy == 1) {
-        // FSI_KRYLOV_FP32=1 sized the basis store for 4-byte columns: there is no FP64 store to fall back to, and
-        // addressing it with 8-byte columns would run past the allocation.  The policy was forced, so say so.
-        char buf[200];
-        snprintf(buf, sizeof buf, "GCR: the FP32 Krylov basis forced by FSI_KRYLOV_FP32=1 cannot reach rtol %.1e on this system "
-                 "(true residual %.3e of |b| after a cycle); use the default policy", rtol, rnorm / bnorm);
-        ctx->err = buf;
-        *relres = rnorm / bnorm;
-        return FSI_ERR_LINEAR;
-      }
-      // (Tried in round 3: dropping the kept pairs once and staying FP32 before giving FP32 up - on a full store late in a
-      // Jacobian's life the solves that follow then need 200+ iterations each and the 100-step run loses a third: the FP64
-      // basis for the rest of the lifetime is the cheaper answer.)
-      gcr_reset(ctx);
-      ctx->kry_fp32 = 0;
-      if (ctx->kry_fp32_policy == 2) {      // FP64 for the rest of this Jacobian's life; re-armed at the next refresh (twice at most)
-        ctx->kry_fp32_policy = 3;
-        ctx->kry_fp32_failures += 1;
-        ctx->kry_fp32_failures_total += 1;
-      }
-    }
-    rstart = rnorm;
-  }
-  *relres = rnorm / bnorm;
-  if (getenv("FSI_DEBUG_TRUERES")) {
-    const double rec = rnorm;
-    FSICHK(true_residual());
-    fprintf(stderr, "[gcr] solve: %d its, recurrence |r|/|b| %.3e, true %.3e, kept %lld (hw %lld), restarts %lld, basis fp%d policy %d, rtol %.1e gs_rtol %.1e |b| %.3e\n", *iters, rec / bnorm, rnorm / bnorm,
-            (long long)(ctx->kry_hw - (int64_t)ctx->kry_free.size()), (long long)ctx->kry_hw, (long long)ctx->gcr_restarts, ctx->kry_fp32 ? 32 : 64, ctx->kry_fp32_policy, rtol, ctx->gs_rtol, bnorm);
-    rnorm = rec;
-    if (!ctx->kry_fp32 && ctx->kry_hw > 0) {      // A p_k = q_k for the kept pairs?
-      double worst = 0.0; int64_t wk = -1; double qn_w = 0.0;
-      for (int64_t k = 0; k < ctx->kry_hw; ++k) {
-        if (ctx->kry_born[k] < 0) continue;
-        FSICHK(spmv(ctx, ctx->KZ.p + (size_t)k * ctx->ldz, ctx->tmp3.p));
-        const double* qk = reinterpret_cast<const double*>(ctx->KQ.p) + (size_t)k * ctx->ldq;
-        launch_axpby(st, ctx->tmp3.p, 1.0, ctx->tmp3.p, -1.0, qk, n);
-        double e = 0.0, qn = 0.0;
-        FSICHK(dot_n(ctx, ctx->tmp3.p, ctx->tmp3.p, n, &e));
-        FSICHK(dot_n(ctx, qk, qk, n, &qn));
-        const double rel = std::sqrt(e / std::max(qn, 1e-300));
-        if (rel > worst) { worst = rel; wk = k; qn_w = qn; }
-        if (rel > 1e-9) fprintf(stderr, "[gcr]     slot %lld born %lld: |A p - q|/|q| %.3e |q| %.6f\n", (long long)k, (long long)ctx->kry_born[k], rel, std::sqrt(qn));
-      }
-      fprintf(stderr, "[gcr]   worst pair: slot %lld |A p - q|/|q| %.3e (|q| %.6f)\n", (long long)wk, worst, std::sqrt(qn_w));
-      // orthonormality of the kept columns: rows of Q^T Q for the last few slots
-      const int mm = (int)ctx->kry_hw;
-      double worst_o = 0.0; int wi = -1, wj = -1;
-      for (int j = std::max(0, mm - 6); j < mm; ++j) {
-        if (ctx->kry_born[j] < 0) continue;
-        const double* qj = reinterpret_cast<const double*>(ctx->KQ.p) + (size_t)j * ctx->ldq;
-        launch_gcr_dots(st, false, ctx->KQ.p, ctx->ldq, n, mm, qj, nullptr, ctx->scratch.p, ctx->hcoef.p);
-        FSICHK(gcr_read(ctx, ctx->hcoef.p, mm + 2, ctx->gcr_host));
-        for (int i = 0; i < mm; ++i) {
-          if (ctx->kry_born[i] < 0) continue;
-          const double dev = std::fabs(ctx->gcr_host[i] - (i == j ? 1.0 : 0.0));
-          if (dev > worst_o) { worst_o = dev; wi = i; wj = j; }
-        }
-      }
-      fprintf(stderr, "[gcr]   orthonormality of the last columns: max |q_i . q_j - delta| = %.3e (i %d, j %d)\n", worst_o, wi, wj);
-    }
-  }
-  // stagnation within a factor 100 of a tolerance below 1e-9 (after the restarts above): the answer is as accurate as FP64 makes it on this system, and
-  // the caller (Newton's own residual check) judges the step; reported through relres
-  if ((near_ok || ctx->gcr_stagnated) && rtol <= 1e-9 && rnorm <= 100.0 * rtol * bnorm) return FSI_OK;
-  if (!(rnorm <= rtol * bnorm)) {
-    char buf[160];
-    snprintf(buf, sizeof buf, "GCR: no convergence in %d iterations (relres %.3e, tol %.1e)", *iters, *relres, rtol);
-    ctx->err = buf;
-    return FSI_ERR_LINEAR;
-  }
-  return FSI_OK;
-}
-
-namespace {
-
-// ---- BiCGStab, right-preconditioned ---------------------------------------------------------------------------
-int solve_bicgstab(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it, int* iters, double* relres) {
-  const int64_t n = ctx->ndof;
-  hipStream_t st = ctx->stream;
-  double *r = ctx->tmp1.p, *r0 = ctx->tmp2.p, *p = ctx->tmp3.p, *v = ctx->tmp4.p, *s = ctx->tmp5.p, *t = ctx->tmp6.p;
-  double *ph = ctx->bs.p;   // preconditioned vector (bs is free once rhs was copied)
-  launch_copy(st, r, rhs, n);
-  launch_copy(st, r0, rhs, n);
-  launch_fill(st, x, n, 0.0);
-  launch_fill(st, p, n, 0.0);
-  launch_fill(st, v, n, 0.0);
-  double bnorm = 0.0, rnorm = 0.0;
-  FSICHK(norm2(ctx, r, &bnorm));
-  *iters = 0;
-  if (bnorm == 0.0) { *relres = 0.0; return FSI_OK; }
-  rnorm = bnorm;
-  double rho = 1.0, alpha = 1.0, omega = 1.0;
-  while (rnorm > rtol * bnorm && *iters < max_it) {
-    double rho1 = 0.0;
-    FSICHK(dot(ctx, r0, r, &rho1));
-    if (rho1 == 0.0 || !std::isfinite(rho1)) { ctx->err = "BiCGStab breakdown (rho = 0)"; return FSI_ERR_LINEAR; }
-    const double beta = (rho1 / rho) * (alpha / omega);
-    launch_axpy(st, p, -omega, v, n);             // p = r + beta (p - omega v)
-    launch_axpby(st, p, 1.0, r, beta, p, n);
-    FSICHK(precondition(ctx, p, ph));
-    FSICHK(spmv(ctx, ph, v));
-    double r0v = 0.0;
-    FSICHK(dot(ctx, r0, v, &r0v));
-    if (r0v == 0.0 || !std::isfinite(r0v)) { ctx->err = "BiCGStab breakdown (r0.v = 0)"; return FSI_ERR_LINEAR; }
-    alpha = rho1 / r0v;
-    launch_axpby(st, s, 1.0, r, -alpha, v, n);
-    launch_axpy(st, x, alpha, ph, n);
-    FSICHK(precondition(ctx, s, ph));
-    FSICHK(spmv(ctx, ph, t));
-    double ts = 0.0, tt = 0.0;
-    FSICHK(dot(ctx, t, s, &ts));
-    FSICHK(dot(ctx, t, t, &tt));
-    omega = tt > 0.0 ? ts / tt : 0.0;
-    launch_axpy(st, x, omega, ph, n);
-    launch_axpby(st, r, 1.0, s, -omega, t, n);
-    FSICHK(norm2(ctx, r, &rnorm));
-    rho = rho1;
-    *iters += 1;
-    ctx->kry_iters += 1;
-    if (omega == 0.0 && rnorm > rtol * bnorm) { ctx->err = "BiCGStab breakdown (omega = 0)"; return FSI_ERR_LINEAR; }
-    if (!std::isfinite(rnorm)) { ctx->err = "BiCGStab diverged"; return FSI_ERR_LINEAR; }
-  }
-  *relres = rnorm / bnorm;
-  // stagnation within a factor 10 of a tolerance below 1e-9: the answer is as accurate as FP64 makes it on this system, and
-  // the caller (Newton's own residual check) judges the step; reported through relres
-  if (ctx->gcr_stagnated && rtol <= 1e-9 && rnorm <= 10.0 * rtol * bnorm) return FSI_OK;
-  if (!(rnorm <= rtol * bnorm)) {
-    char buf[160];
-    snprintf(buf, sizeof buf, "BiCGStab: no convergence in %d iterations (relres %.3e, tol %.1e)", *iters, *relres, rtol);
-    ctx->err = buf;
-    return FSI_ERR_LINEAR;
-  }
-  return FSI_OK;
-}
-
-}  // namespace
-
-// Factorisations for the active preconditioner, from the row-equilibrated Jacobian in ctx->A.
-namespace {
-// Largest eigenvalue of a coarse level's scaled operator by power iteration with the level's own sweep kernel: a sweep with
-// c1 = 0, c2 = 1 on a zero residual returns d_out = -(scaled operator) d_in.  The Gershgorin row-sum bound the levels used
-// in round 2 is 2.2x the true value on the solid vertices of the bench mesh - every Chebyshev interval [bound / kappa, bound]
-// built on it reaches that much less far down the spectrum for the same number of sweeps.  work: 4 vectors of n4 floats.
-template <class Sweep>
-int coarse_power_lmax(FsiCtx* ctx, int64_t nnodes, float* work, Sweep&& sweep, double bound, double* out) {
-  hipStream_t st = ctx->stream;
-  const int64_t n4 = 4 * nnodes;
-  float *r = work, *da = work + n4, *db = work + 2 * n4, *x = work + 3 * n4;
-  launch_f32_ripple4(st, nnodes, da);
-  double* acc = ctx->scratch.p + 4100;
-  const int its = 30;
-  for (int k = 0; k < its; ++k) {
-    HIPCHK(hipMemsetAsync(r, 0, n4 * sizeof(float), st));
-    sweep(da, db, x, r);
-    std::swap(da, db);
-    if (k == its - 2) launch_f32_sumsq(st, n4, da, acc);
-    if (k == its - 1) launch_f32_sumsq(st, n4, da, acc + 1);
-  }
-  double h[2] = {0.0, 0.0};
-  HIPCHK(hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  *out = bound;
-  if (h[0] > 0.0 && h[1] > 0.0 && std::isfinite(h[0]) && std::isfinite(h[1])) {
-    const double lam = std::sqrt(h[1] / h[0]);
-    if (std::isfinite(lam) && lam > 0.0) *out = std::min(bound, 1.2 * lam);      // same head room as the fine levels' estimates
-  }
-  return FSI_OK;
-}
-}  // namespace
-
-int refresh_preconditioner(FsiCtx* ctx) {
-  Phase ph(ctx, &ctx->t_fac);
-  hipStream_t st = ctx->stream;
-  int32_t flags[4] = {0, 0, 0, 0};
-  if (!ctx->coloured && (ctx->precond != 0 || ctx->cheb_its_d <= 0 || ctx->cheb_its_p <= 0)) {
-    ctx->err = "the ILU(0)-based solver options need the multicolour node ordering: create the context with FSI_ORDER=colour";
-    return FSI_ERR_INVALID;
-  }
-  if (ctx->precond == 0) {
-    launch_extract_blocks(st, ctx->N2, ctx->V, ctx->scheme.k * ctx->scheme.th0, ctx->rowptr.p, ctx->A.p, ctx->nadj_ptr.p,
-                          ctx->nadj.p, ctx->padj_ptr.p, ctx->vrank.p, ctx->node_solid.p, ctx->rowptr3.p, ctx->rowptr_vp.p,
-                          ctx->rowptr_pv.p, ctx->rowptr_pp.p, ctx->Mdd.vals.p, ctx->Adv.p, ctx->Mvv.vals.p, ctx->Avp.p,
-                          ctx->Apv.p, ctx->App.p);
-    HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
-    launch_schur_p1(st, ctx->V, ctx->vrank.p, ctx->nadj_ptr.p, ctx->nadj.p, ctx->padj_ptr.p, ctx->padj.p, ctx->rowptr_pv.p,
-                    ctx->Apv.p, ctx->rowptr_pp.p, ctx->App.p, ctx->rowptr_vp.p, ctx->Avp.p, ctx->diagpos3.p,
-                    ctx->Mvv.vals.p, ctx->Ms.vals.p, ctx->iflags.p);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
-    launch_schur_full(st, ctx->V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->vrank.p, ctx->nadj_ptr.p, ctx->nadj.p, ctx->padj_ptr.p,
-                      ctx->padj.p, ctx->rowptr_pv.p, ctx->Apv.p, ctx->rowptr_pp.p, ctx->App.p, ctx->rowptr_vp.p, ctx->Avp.p,
-                      ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->s_vals.p, ctx->iflags.p);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
-    if (flags[1] & 4) { ctx->err = "Schur complement: a vertex has too many (two-ring) vertex neighbours"; return FSI_ERR_INVALID; }
-    {
-      const int64_t npairs = (int64_t)ctx->dd_db.n / 3;
-      launch_extract_db(st, ctx->N2, npairs, ctx->nadj_ptr.p, ctx->rowptr3.p, ctx->Mdd.vals.p, ctx->dd_db.p, ctx->iflags.p, 1);
-      launch_extract_db(st, ctx->N2, npairs, ctx->nadj_ptr.p, ctx->rowptr3.p, ctx->Mvv.vals.p, ctx->vv_db.p, ctx->iflags.p, 0);
-      HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
-      ctx->dd_is_db = !(flags[1] & 8);      // A_dd acts per component (always so for the forms of SURVEY.md A.2)
-      HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
-      launch_extract_db(st, ctx->N2, npairs, ctx->nadj_ptr.p, ctx->rowptr3.p, ctx->Adv.p, ctx->adv_db.p, ctx->iflags.p, 1);
-      HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
-      ctx->adv_is_db = !(flags[1] & 8);
-      ctx->pv32_ok = false;
-      if (!(getenv("FSI_PV_FP32") && atoi(getenv("FSI_PV_FP32")) == 0)) {      // FP32 copies for the two block products of the pressure step
-        if (!ctx->Avp32.p) { HIPCHK(ctx->Avp32.alloc(ctx->Avp.n)); HIPCHK(ctx->Apv32.alloc(ctx->Apv.n)); }
-        launch_to_f32(st, (int64_t)ctx->Avp.n, ctx->Avp.p, ctx->Avp32.p);
-        launch_to_f32(st, (int64_t)ctx->Apv.n, ctx->Apv.p, ctx->Apv32.p);
-        ctx->pv32_ok = true;
-      }
-      if (!ctx->vv_dinv.p) HIPCHK(ctx->vv_dinv.alloc(3 * ctx->N2));
-      launch_diag_inverse(st, 3 * ctx->N2, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->vv_dinv.p);
-      if (!ctx->adv_rowmask.p) HIPCHK(ctx->adv_rowmask.alloc(ctx->N2));
-      launch_db_rowmask(st, ctx->N2, ctx->nadj_ptr.p, ctx->adv_db.p, ctx->adv_rowmask.p);     // A_dv has no entries in fluid rows
-      HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
-      launch_extract_chat(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_db.p, ctx->dd_chat.p, ctx->dd_rowflag.p, ctx->iflags.p);
-      HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
-      ctx->dd_is_scalar = ctx->dd_is_db && !(flags[1] & 16) && !getenv("FSI_NO_SCALAR_DD");
-      // The displacement block (solid mass + mesh Laplacian with a constant coefficient) does not change from one Jacobian
-      // to the next for the forms VaSP uses: what is derived from it alone - its coarse operator here, its eigenvalue
-      // estimate below - is kept while a checksum of the block's values (sum of squares, one pass) stays the same.
-      // Three numbers: the sum of squares, a sum with index-hashed weights (sign changes, permuted entries, entries
-      // far below the largest one) and the same hashed sum over the row scaling of the d rows, which the Galerkin product
-      // takes as a separate input.  fsi_get_timers counts the hits (dd_cache_hits).
-      double cs[3] = {0.0, 0.0, 0.0};
-      FSICHK(dot_n(ctx, ctx->Mdd.vals.p, ctx->Mdd.vals.p, (int64_t)ctx->Mdd.nnz, &cs[0]));
-      launch_hashed_sum(st, ctx->Mdd.vals.p, 0, 1, (int64_t)ctx->Mdd.nnz, ctx->scratch.p, ctx->scratch.p + 4096);
-      FSICHK(host_scalar(ctx, ctx->scratch.p + 4096, &cs[1]));
-      for (int c = 0; c < 3; ++c) {
-        double part = 0.0;
-        launch_hashed_sum(st, ctx->rowscale.p, c, 6, ctx->N2, ctx->scratch.p, ctx->scratch.p + 4096);
-        FSICHK(host_scalar(ctx, ctx->scratch.p + 4096, &part));
-        cs[2] += (c + 1) * part;
-      }
-      bool same = ctx->dd_checksum_valid;
-      for (int k = 0; k < 3; ++k) same = same && std::isfinite(cs[k]) && std::fabs(cs[k] - ctx->dd_checksum[k]) <= 1e-12 * std::fabs(cs[k]);
-      ctx->dd_same = same;
-      for (int k = 0; k < 3; ++k) ctx->dd_checksum[k] = cs[k];
-      ctx->dd_checksum_valid = std::isfinite(cs[0]) && std::isfinite(cs[1]) && std::isfinite(cs[2]);
-      if (ctx->dd_same) ctx->dd_cache_hits += 1;
-      static const bool mg_keep_on = !(getenv("FSI_MG_KEEP") && atoi(getenv("FSI_MG_KEEP")) == 0);
-      const bool mg_keep = mg_keep_on && ctx->dd_same && ctx->mg_ready && ctx->dd_mg && ctx->dd_is_scalar && ctx->sweeps_fp32 && ctx->mg_nc > 0;
-      if (!mg_keep) ctx->mg_ready = false;
-      if (!mg_keep && ctx->dd_mg && ctx->dd_is_scalar && ctx->sweeps_fp32 && ctx->mg_nc > 0) {
-        // Galerkin coarse operator of the displacement block, A_c = P^T A0 P, and its Jacobi-scaled single-precision form
-        HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
-        HIPCHK(hipMemsetAsync(ctx->mg_Ac.p, 0, ctx->mg_cnnz * sizeof(double), st));
-        launch_mg_d0(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_db.p, ctx->rowscale.p, ctx->dd_rowflag.p, ctx->mg_d0.p, ctx->iflags.p);
-        launch_mg_rap(st, ctx->mg_nc, ctx->mg_chptr.p, ctx->mg_child.p, ctx->mg_chw.p, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_db.p,
-                      ctx->rowscale.p, ctx->dd_rowflag.p, ctx->mg_par.p, ctx->mg_pw.p, ctx->mg_cptr.p, ctx->mg_ccol.p, ctx->mg_Ac.p,
-                      ctx->iflags.p);
-        launch_mg_coarse_finish(st, ctx->mg_nc, ctx->mg_cptr.p, ctx->mg_ccol.p, ctx->mg_Ac.p, ctx->mg_cfine.p, ctx->dd_rowflag.p,
-                                ctx->mg_cc.p, ctx->mg_cflag.p, ctx->mg_dcinv4.p, ctx->iflags.p + 2);
-        HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
-        float rowmax;
-        std::memcpy(&rowmax, &flags[2], sizeof rowmax);
-        ctx->mg_ready = !(flags[1] & (32 | 64)) && std::isfinite(rowmax) && rowmax > 0.f;
-        ctx->mg_clmax = ctx->mg_gersh = rowmax;   // Gershgorin bound of the Jacobi-scaled coarse operator
-        if (ctx->mg_ready && ctx->coarse_power) {
-          double lam = rowmax;
-          FSICHK(coarse_power_lmax(ctx, ctx->mg_nc, ctx->mg_work.p,
-                                   [&](const float* din, float* dout, float* x, float* r) {
-                                     launch_sweep_sc_f32(st, ctx->mg_nc, ctx->mg_cptr.p, ctx->mg_ccol.p, ctx->mg_cc.p, ctx->mg_cflag.p, 0.f, 1.f, din, dout, x, r);
-                                   }, rowmax, &lam));
-          if (getenv("FSI_DEBUG")) fprintf(stderr, "[fsi] displacement coarse level: lmax %.3f by power iteration (Gershgorin bound %.3f)\n", lam, (double)rowmax);
-          ctx->mg_clmax = lam;
-        }
-        HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
-      }
-      launch_to_f32(st, 3 * npairs, ctx->dd_db.p, ctx->dd_db32.p);
-      launch_to_f32(st, 3 * npairs, ctx->vv_db.p, ctx->vv_db32.p);
-      if (ctx->sweeps_fp16 && ctx->tiled) {      // packed FP16 records of the two tiled operators (see k_pack_h1 / k_pack_h3)
-        if (!ctx->dd_rec.p) { HIPCHK(ctx->dd_rec.alloc(npairs)); HIPCHK(ctx->vv_rec.alloc(2 * npairs)); }
-        launch_pack_h1(st, npairs, ctx->dd_chat.p, ctx->tile_ploc.p, ctx->dd_rec.p);
-        launch_pack_h3(st, npairs, ctx->vv_db32.p, ctx->tile_ploc.p, ctx->vv_rec.p);
-      }
-      launch_dinv_f32(st, ctx->N2, nullptr, ctx->diagpos3.p, ctx->Mdd.vals.p, ctx->dd_dinv32.p);
-      launch_dinv_f32(st, ctx->N2, ctx->mask_f.p, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->vvf_dinv32.p);
-    }
-    launch_gather_vals(st, (int64_t)ctx->ss_vals.n, ctx->ss_src.p, ctx->Mvv.vals.p, ctx->ss_vals.p);
-    launch_sb_gather(st, ctx->sb_nblocks, ctx->sb_row.p, ctx->sb_src.p, ctx->sb_stride.p, ctx->Mvv.vals.p, ctx->sb_vals.p);
-    if (ctx->sweeps_fp16 && ctx->solid_fp32 && ctx->sb_nblocks > 0) {
-      if (!ctx->sb_rec.p) HIPCHK(ctx->sb_rec.alloc(6 * ctx->sb_nblocks));
-      launch_pack_sb(st, ctx->sb_nblocks, ctx->sb_vals.p, ctx->sb_col.p, ctx->sb_rec.p);
-    }
-    launch_sb_dinv(st, ctx->nS, ctx->snode.p, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->sb_dinv.p);
-    launch_sb_binv(st, ctx->nS, ctx->snode.p, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->sb_binv12.p, ctx->sb_binv9.p);
-    ctx->sbmg_ready = false;
-    if (ctx->solid_mg && ctx->sbmg_nc > 0 && ctx->solid_fp32 && ctx->solid_block_jacobi && ctx->solid_fused) {
-      HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
-      HIPCHK(hipMemsetAsync(ctx->sbmg_cvals.p, 0, 9 * ctx->sbmg_nblk * sizeof(float), st));
-      launch_sbmg_flags(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_col.p, ctx->sb_vals.p, ctx->sbmg_flag.p);
-      launch_sbmg_rap(st, ctx->sbmg_nc, ctx->sbmg_chptr.p, ctx->sbmg_child.p, ctx->sbmg_chw.p, ctx->sb_ptr.p, ctx->sb_col.p,
-                      ctx->sb_vals.p, ctx->snode.p, ctx->rowscale.p, ctx->sbmg_flag.p, ctx->sbmg_par.p, ctx->sbmg_pw.p,
-                      ctx->sbmg_cptr.p, ctx->sbmg_ccol.p, ctx->sbmg_cvals.p, ctx->iflags.p);
-      launch_sbmg_coarse_finish(st, ctx->sbmg_nc, ctx->sbmg_cptr.p, ctx->sbmg_ccol.p, ctx->sbmg_cvals.p, ctx->sbmg_cfine.p,
-                                ctx->sbmg_flag.p, ctx->sbmg_cbinv12.p, ctx->sbmg_cflag.p, ctx->iflags.p + 2);
-      HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
-      float rowmax;
-      std::memcpy(&rowmax, &flags[2], sizeof rowmax);
-      ctx->sbmg_ready = !(flags[1] & 64) && std::isfinite(rowmax) && rowmax > 0.f;
-      ctx->sbmg_clmax = ctx->sbmg_gersh = rowmax;
-      if (ctx->sbmg_ready && ctx->coarse_power) {
-        double lam = rowmax;
-        FSICHK(coarse_power_lmax(ctx, ctx->sbmg_nc, ctx->sbmg_work.p,
-                                 [&](const float* din, float* dout, float* x, float* r) {
-                                   launch_sweep_sb_b3(st, ctx->sbmg_nc, ctx->sbmg_cptr.p, ctx->sbmg_ccol.p, ctx->sbmg_cvals.p, ctx->sbmg_cbinv12.p, 0.f, 1.f, din, dout, x, r, 1);
-                                 }, rowmax, &lam));
-        if (getenv("FSI_DEBUG")) fprintf(stderr, "[fsi] solid coarse level: lmax %.3f by power iteration (Gershgorin bound %.3f)\n", lam, (double)rowmax);
-        ctx->sbmg_clmax = lam;
-      }
-      HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
-      if (getenv("FSI_DEBUG")) fprintf(stderr, "[fsi] solid two-level: %lld coarse nodes, clmax %.3f, ready %d\n", (long long)ctx->sbmg_nc, rowmax, (int)ctx->sbmg_ready);
-    }
-    if (ctx->solid_block_jacobi && ctx->solid_fp32) {      // largest eigenvalue of D_b^-1 A_SS (power iteration, as power_lmax_op)
-      const CsrRef M = ss_ref(ctx);
-      double *x = ctx->blk.p, *y = ctx->blk.p + M.n, lam = 1.0;
-      launch_mask_ripple(st, M.n, nullptr, x);
-      for (int k = 0; k < 40; ++k) {
-        launch_spmv(st, M.n, M.rowptr, M.cols, M.vals, x, y, SPMV_SOLID_BLOCK);
-        launch_block_scale_d(st, ctx->nS, ctx->sb_binv9.p, y);
-        double xx = 0.0, yy = 0.0;
-        FSICHK(dot_n(ctx, x, x, M.n, &xx));
-        FSICHK(dot_n(ctx, y, y, M.n, &yy));
-        if (!(xx > 0.0) || !(yy > 0.0) || !std::isfinite(yy)) break;
-        lam = std::sqrt(yy / xx);
-        launch_copy(st, x, y, M.n);
-        launch_scale(st, x, 1.0 / std::sqrt(yy), M.n);
-      }
-      ctx->lmax_s = 1.2 * lam;
-    } else {
-      FSICHK(power_lmax(ctx, ss_ref(ctx), nullptr, ctx->blk.p, &ctx->lmax_s));
-    }
-    FSICHK(power_lmax_op(ctx, 3 * ctx->N2, [&](const double* in, double* o) { launch_spmv_db(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->vv_db.p, in, o); },
-                         ctx->Mvv.vals.p, ctx->diagpos3.p, ctx->mask_f.p, ctx->blk.p, &ctx->lmax_f));
-    {
-      // its 40 power iterations on a 3 N2-row CSR matrix were 60 ms of every refresh: kept while the block is unchanged (dd_same)
-      if (ctx->lmax_d_cached > 0.0 && ctx->dd_same) {
-        ctx->lmax_d = ctx->lmax_d_cached;
-      } else {
-        FSICHK(power_lmax(ctx, CsrRef{3 * ctx->N2, ctx->rowptr3.p, ctx->cols3.p, ctx->Mdd.vals.p, ctx->diagpos3.p}, nullptr,
-                          ctx->blk.p, &ctx->lmax_d));
-        ctx->lmax_d_cached = ctx->lmax_d;
-      }
-    }
-    FSICHK(power_lmax_op(ctx, ctx->V, [&](const double* in, double* o) { schur_apply(ctx, in, o, ctx->blk.p + 19 * 3 * ctx->N2); },
-                         ctx->s_vals.p, ctx->s_diagpos.p, nullptr, ctx->blk.p, &ctx->lmax_p));
-    if (ctx->schur_fp32) {
-      if (!ctx->s_vals32.p) {
-        HIPCHK(ctx->s_vals32.alloc(ctx->s_vals.n));
-        HIPCHK(ctx->s_dinv32.alloc(ctx->V));
-        HIPCHK(ctx->s_work32.alloc(4 * ctx->V));
-      }
-      launch_to_f32(st, (int64_t)ctx->s_vals.n, ctx->s_vals.p, ctx->s_vals32.p);
-      launch_csr_dinv_f32(st, ctx->V, ctx->s_diagpos.p, ctx->s_vals.p, ctx->s_dinv32.p);
-      if (ctx->schur_tiled && ctx->sweeps_fp16 && ctx->schur_fp32 == 1) {
-        if (!ctx->s_rec.p) { HIPCHK(ctx->s_rec.alloc(ctx->s_vals.n)); HIPCHK(ctx->s_dinv.alloc(ctx->V)); }
-        launch_pack_h1(st, (int64_t)ctx->s_vals.n, ctx->s_vals32.p, ctx->s_ploc.p, ctx->s_rec.p);
-        launch_diag_inverse(st, ctx->V, ctx->s_diagpos.p, ctx->s_vals.p, ctx->s_dinv.p);
-      }
-      if (getenv("FSI_DEBUG_PRECOND")) {
-        std::vector<float> h(ctx->V), hv(ctx->s_vals.n);
-        HIPCHK(hipMemcpy(h.data(), ctx->s_dinv32.p, h.size() * sizeof(float), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(hv.data(), ctx->s_vals32.p, hv.size() * sizeof(float), hipMemcpyDeviceToHost));
-        double lo = 1e300, hi = 0.0, vhi = 0.0; int64_t bad = 0, vbad = 0, neg = 0;
-        for (float f : h) { if (!std::isfinite(f)) { bad++; continue; } lo = std::min(lo, (double)std::fabs(f)); hi = std::max(hi, (double)std::fabs(f)); neg += f < 0; }
-        for (float f : hv) { if (!std::isfinite(f)) vbad++; else vhi = std::max(vhi, (double)std::fabs(f)); }
-        fprintf(stderr, "[precond] schur fp32: 1/diag in [%.3e, %.3e], %lld negative, %lld non-finite; values max %.3e, %lld non-finite\n",
-                lo, hi, (long long)neg, (long long)bad, vhi, (long long)vbad);
-      }
-    }
-    for (SubMat* M : {&ctx->Mdd, &ctx->Ms}) {
-      if ((M == &ctx->Mdd && ctx->cheb_its_d > 0) || (M == &ctx->Ms && ctx->cheb_its_p > 0)) continue;   // Jacobi-Chebyshev: no factors
-      HIPCHK(hipMemcpyAsync(M->LU.p, M->vals.p, M->nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
-      launch_ilu0_levels(st, M->levels, M->rowptr, M->cols, M->diagpos, M->LU.p, ctx->iflags.p);
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
-      if (flags[1] & 1) { ctx->err = "ILU(0): a row has more than 1024 entries"; return FSI_ERR_INVALID; }
-      if (flags[1] & 2) ctx->pivot_warnings += 1;      // pivot replaced by 1: the inner solve stays approximate
-    }
-    // self-test: a Chebyshev interval that misses the top of a spectrum (non-normal blocks at rough states) blows up;
-    // widen the intervals until one application to a rippled vector stays finite and bounded
-    ctx->prec_bad = false;
-    double prev_out = 0.0;
-    const double l0[4] = {ctx->lmax_s, ctx->lmax_f, ctx->lmax_p, ctx->lmax_d};
-    for (int attempt = 0; attempt < 8; ++attempt) {
-      launch_mask_ripple(st, ctx->ndof, nullptr, ctx->tmp1.p);
-      FSICHK(precondition_block(ctx, ctx->tmp1.p, ctx->tmp2.p));
-      double zin = 0.0, zout = 0.0;
-      FSICHK(norm2(ctx, ctx->tmp1.p, &zin));
-      FSICHK(norm2(ctx, ctx->tmp2.p, &zout));
-      if (getenv("FSI_DEBUG_PRECOND"))
-        fprintf(stderr, "[precond] self-test %d: |in| %.3e |out| %.3e  lmax solid %.4g fluid %.4g schur %.4g disp %.4g  coarse solid %.4g disp %.4g\n",
-                attempt, zin, zout, ctx->lmax_s, ctx->lmax_f, ctx->lmax_p, ctx->lmax_d, ctx->sbmg_clmax, ctx->mg_clmax);
-      if (std::isfinite(zout) && zout < 1e8 * zin) break;
-      // a diverging Chebyshev recurrence grows exponentially with the sweep count and collapses once the interval covers
-      // the spectrum; an output that is large but barely moves when the intervals widen by 1.6x is the genuine size of
-      // M^-1 on this matrix (small time steps: the avf problem runs at dt = 1e-4 and answers a unit ripple with 4e9):
-      // keep the estimated intervals
-      if (attempt > 0 && std::isfinite(zout) && std::isfinite(prev_out) && zout > 0.25 * prev_out) {
-        ctx->lmax_s = l0[0]; ctx->lmax_f = l0[1]; ctx->lmax_p = l0[2]; ctx->lmax_d = l0[3];
-        break;
-      }
-      prev_out = zout;
-      if (attempt == 7) { ctx->prec_bad = true; break; }      // reported by fsi_solve: assembling such a Jacobian is legal
-      ctx->lmax_s *= 1.6; ctx->lmax_f *= 1.6; ctx->lmax_p *= 1.6; ctx->lmax_d *= 1.6;
-      ctx->sbmg_clmax = std::min(ctx->sbmg_clmax * 1.6, std::max(ctx->sbmg_clmax, (double)ctx->sbmg_gersh));      // towards the row-sum bounds
-      ctx->mg_clmax = std::min(ctx->mg_clmax * 1.6, std::max(ctx->mg_clmax, (double)ctx->mg_gersh));
-    }
-    return FSI_OK;
-  }
-  if (!ctx->LU.p) HIPCHK(ctx->LU.alloc(ctx->nnz));
-  HIPCHK(hipMemcpyAsync(ctx->LU.p, ctx->A.p, ctx->nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
-  launch_ilu0_levels(st, ctx->levels, ctx->rowptr.p, ctx->cols.p, ctx->diagpos.p, ctx->LU.p, ctx->iflags.p);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
-  ctx->have_monolithic_lu = true;
-  if (flags[1] & 1) { ctx->err = "ILU(0): a row has more than 1024 entries"; return FSI_ERR_INVALID; }
-  if (flags[1] & 2) { ctx->err = "ILU(0): zero or non-finite pivot"; return FSI_ERR_PIVOT; }
-  return FSI_OK;
-}
+}  // namespace host
+}  // namespace fsi
 
 // =========================================================================================================
 extern "C" {
@@ -1727,13 +132,11 @@ int fsi_set_newton_forcing(FsiCtx* ctx, double forcing) {
   return FSI_OK;
 }
 
-int fsi_set_linear_solver(FsiCtx* ctx, int32_t precond, double inner_rtol, int32_t inner_max_it) {
+int fsi_set_linear_solver(FsiCtx* ctx, int32_t precond) {
   if (!ctx || precond < 0 || precond > 1) return FSI_ERR_INVALID;
   HIPCHK(hipSetDevice(ctx->device));
   const bool changed = precond != ctx->precond;
   ctx->precond = precond;
-  if (inner_rtol > 0.0) ctx->inner_rtol = inner_rtol;
-  if (inner_max_it > 0) { ctx->inner_maxit = inner_max_it; ctx->inner_maxit_p = inner_max_it + inner_max_it / 2; }
   if (changed && ctx->have_jacobian) { gcr_reset(ctx); return refresh_preconditioner(ctx); }
   return FSI_OK;
 }
@@ -1767,7 +170,7 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->sbmg_chw.release(); ctx->sbmg_cvals.release(); ctx->sbmg_cbinv12.release(); ctx->sbmg_work.release(); ctx->sbmg_cptr.release();
   ctx->sbmg_chptr.release(); ctx->sbmg_flag.release(); ctx->sbmg_cflag.release();
   rccl_destroy(ctx);
-  ctx->s_vals32.release(); ctx->s_dinv32.release(); ctx->s_work32.release(); ctx->s_rec.release(); ctx->s_dinv.release();
+  ctx->s_vals32.release(); ctx->s_rec.release(); ctx->s_dinv.release();
   ctx->s_ploc.release(); ctx->s_tile_uptr.release(); ctx->s_tile_ulist.release();
   ctx->fs_rows.release(); ctx->fs_col.release(); ctx->fs_ptr.release(); ctx->fs_src.release();
   ctx->mg_par.release(); ctx->mg_ccol.release(); ctx->mg_child.release(); ctx->mg_cfine.release(); ctx->mg_pw.release();
@@ -1777,8 +180,7 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->enbr.release();
   ctx->epnbr.release();
   ctx->cellvals.release();
-  for (auto* b : {&ctx->Adv, &ctx->Avp, &ctx->Apv, &ctx->App, &ctx->blk, &ctx->Mdd.vals, &ctx->Mdd.LU, &ctx->Mvv.vals,
-                  &ctx->Mvv.LU, &ctx->Ms.vals, &ctx->Ms.LU, &ctx->mask_s, &ctx->mask_f, &ctx->ss_vals, &ctx->dd_db, &ctx->vv_db, &ctx->adv_db, &ctx->s_vals}) b->release();
+  for (auto* b : {&ctx->Adv, &ctx->Avp, &ctx->Apv, &ctx->App, &ctx->blk, &ctx->Mdd.vals, &ctx->Mvv.vals, &ctx->mask_s, &ctx->mask_f, &ctx->ss_vals, &ctx->dd_db, &ctx->vv_db, &ctx->adv_db, &ctx->s_vals}) b->release();
   ctx->s_rowptr.release(); ctx->s_diagpos.release(); ctx->s_cols.release();
   for (auto* b : {&ctx->snode, &ctx->ss_cols, &ctx->sb_col, &ctx->sb_row, &ctx->sb_stride}) b->release();
   ctx->sb_ptr.release(); ctx->sb_src.release(); ctx->sb_vals.release(); ctx->sb_dinv.release();
@@ -1805,10 +207,55 @@ int fsi_destroy(FsiCtx* ctx) {
 }
 
 int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx** out) {
+  FsiTuning t;
+  fsi_tuning_from_env(&t);        // defaults + the FSI_<NAME> overrides of the environment (csrc/fsi_tuning.hip)
+  return fsi_create_tuned(mesh, prm, device, &t, out);
+}
+
+int fsi_get_tuning(const FsiCtx* ctx, FsiTuning* out) {
+  if (!ctx || !out) return FSI_ERR_INVALID;
+  *out = ctx->tune;
+  return FSI_OK;
+}
+
+// FsiTuning -> the context's fields (the kernels and the solver read those)
+static void apply_tuning(FsiCtx* ctx, const FsiTuning& t) {
+  ctx->tune = t;
+  ctx->kry_fp32_policy = t.krylov_fp32; ctx->op32_policy = t.operator_fp32; ctx->schur_fp32 = t.schur_fp32 != 0;
+  ctx->sweeps_fp32 = t.sweeps_fp32; ctx->solid_fp32 = t.solid_fp32;
+  ctx->fused_sweeps = t.fused_sweeps != 0; ctx->sweeps_fp16 = ctx->fused_sweeps && t.sweeps_fp16 != 0;
+  ctx->coloured = t.node_order == 2;
+  ctx->newton_forcing = t.newton_forcing; ctx->newton_forcing_late = t.newton_forcing_late; ctx->newton_late_factor = t.newton_late_factor;
+  ctx->f32_cycle_floor = t.f32_cycle_floor; ctx->f32_verdict_skip_rtol = t.f32_verdict_skip_rtol;
+  ctx->orth_floor32 = t.orth_floor32; ctx->orth_floor64 = t.orth_floor64; ctx->gcr_escape = t.gcr_escape; ctx->gcr_reorth = t.gcr_reorth;
+  ctx->prec_streams = t.prec_streams; ctx->cheb4 = t.cheb4; ctx->coarse_power = t.coarse_power; ctx->solid_mg = t.solid_mg; ctx->dd_mg = t.dd_mg;
+  ctx->solid_block_jacobi = t.solid_block_jacobi; ctx->solid_fused = t.solid_fused;
+  ctx->cheb_its_s = t.its_solid; ctx->cheb_its_f = t.its_fluid; ctx->cheb_its_p = t.its_schur; ctx->cheb_its_d = t.its_disp;
+  ctx->cheb_kappa_s = t.kappa_solid; ctx->cheb_kappa_f = t.kappa_fluid; ctx->cheb_kappa_p = t.kappa_schur; ctx->cheb_kappa_d = t.kappa_disp;
+  ctx->sbmg_pre = t.sbmg_pre; ctx->sbmg_post = t.sbmg_post; ctx->sbmg_cits = t.sbmg_cits; ctx->sbmg_alpha = t.sbmg_alpha; ctx->sbmg_ckappa = t.sbmg_ckappa;
+  ctx->mg_pre = t.mg_pre; ctx->mg_post = t.mg_post; ctx->mg_cits = t.mg_cits; ctx->mg_alpha = t.mg_alpha; ctx->mg_ckappa = t.mg_ckappa;
+}
+
+int fsi_create_tuned(const FsiMeshDesc* mesh, const FsiParams* prm, int device, const FsiTuning* tuning, FsiCtx** out) {
   if (!mesh || !prm || !out) return FSI_ERR_INVALID;
   *out = nullptr;
   FsiCtx* ctx = new FsiCtx();
   *out = ctx;   // returned even on failure so that fsi_last_error() can be read; caller destroys it
+  {
+    FsiTuning t;
+    fsi_tuning_defaults(&t);
+    if (tuning) {      // a caller built against a shorter struct: its fields, the defaults for the rest
+      const size_t n = std::min<size_t>(sizeof(FsiTuning), tuning->struct_size > 0 ? (size_t)tuning->struct_size : sizeof(FsiTuning));
+      std::memcpy(&t, tuning, n);
+      t.struct_size = (int32_t)sizeof(FsiTuning);
+    }
+    if (t.its_schur <= 0 || t.its_disp <= 0 || t.its_fluid <= 0 || t.its_solid <= 0 || t.krylov_capacity < 8 || t.krylov_fp32 < 0 || t.krylov_fp32 > 2 ||
+        (t.jacobian_waves != 1 && t.jacobian_waves != 2) || !(t.newton_forcing >= 0.0)) {
+      ctx->err = "fsi_create: FsiTuning out of range (sweep counts must be positive, krylov_capacity >= 8, krylov_fp32 in 0..2, jacobian_waves 1 | 2)";
+      return FSI_ERR_INVALID;
+    }
+    apply_tuning(ctx, t);
+  }
   ctx->device = device;
   const int64_t V = mesh->num_vertices, N2 = mesh->num_nodes, C = mesh->num_cells;
   if (V <= 0 || N2 < V || C <= 0 || !mesh->coords || !mesh->tet_nodes || !mesh->cell_kind || !mesh->cell_region) {
@@ -1880,8 +327,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   });
   {   // default numbering: P2 nodes along a Morton (Z-order) curve through their coordinates - spatially compact runs of
       // consecutive nodes are what the gathers of every SpMV, the element scatters and the LDS tiles live on
-    const char* e = getenv("FSI_ORDER");
-    const bool morton = !(e && (e[0] == 'c' || e[0] == 'C' || e[0] == 'm' || e[0] == 'M'));   // colour / mesh keep `base`
+    const bool morton = ctx->tune.node_order == 0;      // mesh / multicolour order keep `base`
     if (morton) {
       double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
       for (int64_t v = 0; v < V; ++v)
@@ -1935,10 +381,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   // ---- greedy multicolouring of the node graph (base order): nodes of one colour share no element -----------------
   // (only the ILU(0) paths need it; the default Chebyshev-based preconditioner keeps the mesh's own node order, whose
   //  locality is what the gathers of every SpMV live on.  FSI_ORDER=colour selects the multicolour ordering.)
-  {
-    const char* e = getenv("FSI_ORDER");
-    ctx->coloured = e && (e[0] == 'c' || e[0] == 'C');
-  }
+  ctx->coloured = ctx->tune.node_order == 2;
   std::vector<int32_t> color(N2, ctx->coloured ? -1 : 0);
   if (!ctx->coloured) ctx->ncolors = 1;
   if (ctx->coloured) {
@@ -2058,8 +501,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   // ---- assembly colouring: greedy, balanced (the least used admissible colour), at most 128 colours ---------------------
   ctx->ncellcol = 0;
   {
-    const char* am = getenv("FSI_ASSEMBLY");
-    if (!(am && std::string(am) == "atomic") && C > 0) {
+    if (!ctx->tune.assembly_atomic && C > 0) {
       constexpr int MAXCOL = 128;
       std::vector<uint64_t> used((size_t)N2 * 2, 0);
       std::vector<uint8_t> colour((size_t)C);
@@ -2230,10 +672,6 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
         HIPCHK(ctx->sb_dinv.alloc(4 * nS));
         HIPCHK(ctx->sb_binv12.alloc(12 * nS));
         HIPCHK(ctx->sb_binv9.alloc(9 * nS));
-        if (const char* e = getenv("FSI_SOLID_BJ")) ctx->solid_block_jacobi = atoi(e);
-        if (const char* e = getenv("FSI_SOLID_FUSED")) ctx->solid_fused = atoi(e);
-        if (const char* e = getenv("FSI_SCHUR_FP32")) ctx->schur_fp32 = atoi(e);
-        if (const char* e = getenv("FSI_SOLID_FP32")) ctx->solid_fp32 = atoi(e);
       }
       {   // rows of fluid-interior nodes that see solid columns: the only rows the solid predictor changes in the fluid rhs
         std::vector<int32_t> fs_rows, fs_col;
@@ -2273,14 +711,6 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
       for (int k = 0; k < 4; ++k) { HIPCHK(hipEventCreate(&ctx->sch_ev0[k])); HIPCHK(hipEventCreate(&ctx->sch_ev1[k])); }
       FSICHK(upload(ctx, ctx->mask_s, ms));
       FSICHK(upload(ctx, ctx->mask_f, mf));
-      if (const char* e = getenv("FSI_CHEB_S")) ctx->cheb_its_s = atoi(e);
-      if (const char* e = getenv("FSI_CHEB_F")) ctx->cheb_its_f = atoi(e);
-      if (const char* e = getenv("FSI_KAPPA_S")) ctx->cheb_kappa_s = atof(e);
-      if (const char* e = getenv("FSI_KAPPA_F")) ctx->cheb_kappa_f = atof(e);
-      if (const char* e = getenv("FSI_CHEB_D")) ctx->cheb_its_d = atoi(e);
-      if (const char* e = getenv("FSI_KAPPA_D")) ctx->cheb_kappa_d = atof(e);
-      if (const char* e = getenv("FSI_CHEB_P")) ctx->cheb_its_p = atoi(e);
-      if (const char* e = getenv("FSI_KAPPA_P")) ctx->cheb_kappa_p = atof(e);
     }
     const int64_t nadj_total = ctx->h_nadj_ptr[N2], padj_total = ctx->h_padj_ptr[N2];
     std::vector<int64_t> rowptr_pv(V + 1, 0), rowptr_pp(V + 1, 0), diagpos_pp(V, 0);
@@ -2330,7 +760,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
       std::vector<int32_t> ulist;
       std::vector<uint16_t> ploc(nadj_total);
       std::vector<int32_t> tmpu;
-      bool ok = !getenv("FSI_NO_TILES");
+      bool ok = ctx->tune.tiles != 0;
       for (int64_t t = 0; t < ntiles && ok; ++t) {
         const int64_t r0 = t * TN, r1 = std::min<int64_t>(N2, r0 + TN);
         const int64_t e0 = ctx->h_nadj_ptr[r0], e1 = ctx->h_nadj_ptr[r1];
@@ -2363,12 +793,6 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
       FSICHK(upload(ctx, ctx->ones32, ones));
     }
     {   // P2 -> P1 hierarchy of the displacement block: parents of every node, vertex graph, children of every vertex
-      if (const char* e = getenv("FSI_DD_MG")) ctx->dd_mg = atoi(e);
-      if (const char* e = getenv("FSI_MG_PRE")) ctx->mg_pre = atoi(e);
-      if (const char* e = getenv("FSI_MG_POST")) ctx->mg_post = atoi(e);
-      if (const char* e = getenv("FSI_MG_CITS")) ctx->mg_cits = atoi(e);
-      if (const char* e = getenv("FSI_MG_ALPHA")) ctx->mg_alpha = atof(e);
-      if (const char* e = getenv("FSI_MG_CKAPPA")) ctx->mg_ckappa = atof(e);
       std::vector<int32_t> cidx(N2, -1), cfine;
       for (int64_t r = 0; r < N2; ++r)
         if (ctx->h_rank2node[r] < V) { cidx[r] = (int32_t)cfine.size(); cfine.push_back((int32_t)r); }
@@ -2432,13 +856,6 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
         for (int64_t i = 0; i < nc; ++i) cones[4 * i + 3] = 0.0f;
         FSICHK(upload(ctx, ctx->mg_cones, cones));
         // the same hierarchy on the compact solid numbering (3x3-block operator of the velocity predictor)
-        if (const char* e = getenv("FSI_SOLID_MG")) ctx->solid_mg = atoi(e);
-        if (const char* e = getenv("FSI_COARSE_POWER")) ctx->coarse_power = atoi(e);
-        if (const char* e = getenv("FSI_SBMG_PRE")) ctx->sbmg_pre = atoi(e);
-        if (const char* e = getenv("FSI_SBMG_POST")) ctx->sbmg_post = atoi(e);
-        if (const char* e = getenv("FSI_SBMG_CITS")) ctx->sbmg_cits = atoi(e);
-        if (const char* e = getenv("FSI_SBMG_ALPHA")) ctx->sbmg_alpha = atof(e);
-        if (const char* e = getenv("FSI_SBMG_CKAPPA")) ctx->sbmg_ckappa = atof(e);
         const int64_t nS = ctx->nS;
         if (ctx->solid_mg && nS > 0) {
           std::vector<int32_t> sidx2(N2, -1), scidx(nS, -1), scfine;
@@ -2501,7 +918,6 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
       }
     }
     HIPCHK(ctx->vvf_dinv32.alloc(4 * N2));
-    if (const char* e = getenv("FSI_SWEEPS_FP32")) ctx->sweeps_fp32 = atoi(e);
     HIPCHK(ctx->Avp.alloc(3 * padj_total));
     HIPCHK(ctx->Apv.alloc(rowptr_pv[V]));
     HIPCHK(ctx->App.alloc(rowptr_pp[V]));
@@ -2509,17 +925,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
       M->n = 3 * N2; M->nnz = 9 * nadj_total;
       M->rowptr = ctx->rowptr3.p; M->cols = ctx->cols3.p; M->diagpos = ctx->diagpos3.p;
       HIPCHK(M->vals.alloc(M->nnz));
-      if (M == &ctx->Mdd) HIPCHK(M->LU.alloc(M->nnz));
     }
-    ctx->Ms.n = V; ctx->Ms.nnz = rowptr_pp[V];
-    ctx->Ms.rowptr = ctx->rowptr_pp.p; ctx->Ms.cols = ctx->cols_pp.p; ctx->Ms.diagpos = ctx->diagpos_pp.p;
-    HIPCHK(ctx->Ms.vals.alloc(ctx->Ms.nnz));
-    HIPCHK(ctx->Ms.LU.alloc(ctx->Ms.nnz));
-    for (const Level& L : ctx->levels) {
-      if (L.group_rows == 6) { ctx->Mdd.levels.push_back(Level{L.first_row / 2, L.ngroups, 3}); }
-      else ctx->Ms.levels.push_back(Level{L.first_row - 6 * N2, L.ngroups, 1});
-    }
-    ctx->Mvv.levels = ctx->Mdd.levels;
     {   // pattern of the explicit Schur complement: vertices that share a velocity node's element neighbourhood
       std::vector<int64_t> s_rowptr(V + 1, 0), s_diagpos(V, 0);
       std::vector<int32_t> s_cols, mark(V, -1), row;
@@ -2581,9 +987,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   // Krylov space: sized from free memory (the recycled directions are what 288 GB of HBM are used for)
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
-  ctx->kry_fp32_policy = getenv("FSI_KRYLOV_FP32") ? atoi(getenv("FSI_KRYLOV_FP32")) : 2;
   ctx->kry_fp32 = ctx->kry_fp32_policy == 1;
-  ctx->op32_policy = getenv("FSI_OPERATOR_FP32") ? atoi(getenv("FSI_OPERATOR_FP32")) : 1;
   if (ctx->op32_policy && ctx->kry_fp32_policy != 0) {
     // layout of the FP32 copy (see k_spmv_node6p): node blocks padded to multiples of four entries, pressure rows behind
     std::vector<int64_t> rp(6 * (size_t)ctx->N2 + 2), p32((size_t)ctx->N2 + 1, 0);
@@ -2602,23 +1006,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
   }
   ctx->debug_gcr = getenv("FSI_DEBUG_GCR") != nullptr;
-  ctx->fused_sweeps = !(getenv("FSI_FUSED_SWEEPS") && atoi(getenv("FSI_FUSED_SWEEPS")) == 0);
-  ctx->sweeps_fp16 = ctx->fused_sweeps && !(getenv("FSI_SWEEPS_FP16") && atoi(getenv("FSI_SWEEPS_FP16")) == 0);
   ctx->debug_prec_apply = (getenv("FSI_DEBUG_PRECOND") && atoi(getenv("FSI_DEBUG_PRECOND")) >= 2) ? 12 : 0;
-  if (getenv("FSI_NEWTON_FORCING")) ctx->newton_forcing = atof(getenv("FSI_NEWTON_FORCING"));
-  if (getenv("FSI_NEWTON_FORCING_LATE")) ctx->newton_forcing_late = atof(getenv("FSI_NEWTON_FORCING_LATE"));
-  if (getenv("FSI_NEWTON_LATE_FACTOR")) ctx->newton_late_factor = atof(getenv("FSI_NEWTON_LATE_FACTOR"));
-  if (getenv("FSI_VEL_JACOBI")) ctx->vel_jacobi = atoi(getenv("FSI_VEL_JACOBI"));
-  if (getenv("FSI_DD_EARLY")) ctx->dd_early = atoi(getenv("FSI_DD_EARLY"));
-  if (getenv("FSI_PREC_STREAMS")) ctx->prec_streams = atoi(getenv("FSI_PREC_STREAMS"));
-  if (getenv("FSI_GCR_REORTH")) ctx->gcr_reorth = atof(getenv("FSI_GCR_REORTH"));
-  if (getenv("FSI_CHEB4")) ctx->cheb4 = atoi(getenv("FSI_CHEB4"));
-  if (getenv("FSI_F32_CYCLE_FLOOR")) ctx->f32_cycle_floor = atof(getenv("FSI_F32_CYCLE_FLOOR"));
-  if (getenv("FSI_F32_VERDICT_SKIP")) ctx->f32_verdict_skip_rtol = atof(getenv("FSI_F32_VERDICT_SKIP"));      // 1: never skip
-  if (getenv("FSI_ORTH_FLOOR32")) ctx->orth_floor32 = atof(getenv("FSI_ORTH_FLOOR32"));
-  if (getenv("FSI_ORTH_FLOOR64")) ctx->orth_floor64 = atof(getenv("FSI_ORTH_FLOOR64"));
-  if (getenv("FSI_GCR_ESCAPE")) ctx->gcr_escape = atof(getenv("FSI_GCR_ESCAPE"));      // 0: never leave the residual-based directions
-  if (getenv("FSI_GCR_ARNOLDI")) ctx->gcr_arnoldi = atoi(getenv("FSI_GCR_ARNOLDI")) != 0;
   ctx->ldq = (n + 3) & ~(int64_t)3;
   ctx->ldz = (n + 1) & ~(int64_t)1;
   const double per_dir = (double)ctx->ldz * 8.0 + (double)ctx->ldq * (ctx->kry_fp32_policy == 1 ? 4.0 : 8.0);
@@ -2626,7 +1014,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
   // 600 kept directions (round 2: 400): a Jacobian's life of 20 steps makes ~380 early in a run and ~550 once the ramp is up
   // (4.6 Newton iterations per step); a full store rotates, and the 100-step run is 5 % faster without that (12.0 against
   // 11.4 Newton-it/s); the 20-step bench does not notice.  Half of the free HBM remains the upper limit.
-  cap = std::max<int64_t>(8, std::min<int64_t>(cap, getenv("FSI_KRYLOV_CAP") ? atoi(getenv("FSI_KRYLOV_CAP")) : 600));
+  cap = std::max<int64_t>(8, std::min<int64_t>(cap, ctx->tune.krylov_capacity));
   ctx->kry_cap = cap;
   HIPCHK(ctx->KZ.alloc((size_t)cap * ctx->ldz));
   HIPCHK(ctx->KQ.alloc((size_t)cap * ctx->ldq * (ctx->kry_fp32_policy == 1 ? 4 : 8)));      // FP64-sized unless FP32 is forced
@@ -2852,192 +1240,6 @@ int fsi_set_robin_facets(FsiCtx* ctx, int64_t nf, const int32_t* facet_nodes, co
   FSICHK(upload(ctx, ctx->rb_pos, pos));
   return FSI_OK;
 }
-
-int fsi_solver_setup(FsiCtx* ctx) {
-  if (!ctx) return FSI_ERR_INVALID;
-  HIPCHK(hipSetDevice(ctx->device));
-  Phase ph(ctx, &ctx->t_jac);
-  HIPCHK(hipMemsetAsync(ctx->A_pre.p, 0, ctx->nnz * sizeof(double), ctx->stream));
-  launch_jacobian(ctx->stream, PART_LINEAR, ctx->C, elem_arrays(ctx), elem_params(ctx), ctx->U.p, ctx->U1.p,
-                  ctx->rowptr.p, ctx->nadj_ptr.p, ctx->A_pre.p, cell_colours(ctx));
-  launch_add_at(ctx->stream, ctx->A_pre.p, ctx->rb_pos.p, ctx->rb_val.p, ctx->scheme.th0, ctx->nrobin);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->have_jacobian = false;
-  return FSI_OK;
-}
-
-int fsi_assemble_residual(FsiCtx* ctx, double* norm) {
-  if (!ctx) return FSI_ERR_INVALID;
-  HIPCHK(hipSetDevice(ctx->device));
-  {
-    Phase ph(ctx, &ctx->t_res);
-    if (!ctx->Re.p) HIPCHK(hipMemsetAsync(ctx->F.p, 0, ctx->ndof * sizeof(double), ctx->stream));    // the gather writes every entry
-    launch_residual(ctx->stream, ctx->C, elem_arrays(ctx), elem_params(ctx), ctx->U.p, ctx->U1.p, ctx->F.p, residual_gather(ctx));
-    launch_add_indexed(ctx->stream, ctx->F.p, ctx->pf_dofs.p, ctx->pf_coef.p, ctx->P, ctx->npf);
-    launch_robin_residual(ctx->stream, ctx->nrobin_rows, ctx->rb_urow.p, ctx->rb_ptr.p, ctx->rb_col.p, ctx->rb_val.p, ctx->scheme.th0,
-                          ctx->scheme.th1, ctx->U.p, ctx->U1.p, ctx->F.p);
-    launch_negate(ctx->stream, ctx->b.p, ctx->F.p, ctx->ndof);
-    launch_bc_rhs(ctx->stream, ctx->b.p, ctx->U.p, ctx->bc_dofs.p, ctx->bc_vals.p, ctx->nbc);
-    zero_ghost(ctx, ctx->b.p);
-    HIPCHK(hipGetLastError());
-  }
-  double nrm = 0.0;
-  FSICHK(gnorm2(ctx, ctx->b.p, &nrm));
-  if (norm) *norm = nrm;
-  return FSI_OK;
-}
-
-int fsi_assemble_jacobian(FsiCtx* ctx) {
-  if (!ctx) return FSI_ERR_INVALID;
-  HIPCHK(hipSetDevice(ctx->device));
-  {
-    Phase ph(ctx, &ctx->t_jac);
-    HIPCHK(hipMemsetAsync(ctx->A.p, 0, ctx->nnz * sizeof(double), ctx->stream));
-    launch_jacobian(ctx->stream, PART_NONLINEAR, ctx->C, elem_arrays(ctx), elem_params(ctx), ctx->U.p, ctx->U1.p,
-                    ctx->rowptr.p, ctx->nadj_ptr.p, ctx->A.p, cell_colours(ctx));
-    if (getenv("FSI_DEBUG")) { HIPCHK(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[fsi] jacobian kernel done\n"); fflush(stderr); }
-    launch_matrix_finish(ctx->stream, ctx->ndof, ctx->rowptr.p, ctx->diagpos.p, ctx->A.p, ctx->A_pre.p, ctx->mbc_dofs.p,
-                         ctx->nmbc, ctx->rowscale.p, ctx->iflags.p + 16);
-    HIPCHK(hipGetLastError());
-    if (getenv("FSI_DEBUG")) { HIPCHK(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[fsi] matrix finish done\n"); fflush(stderr); }
-  }
-  ctx->op32_ok = false;
-  if (ctx->op32_policy && ctx->kry_fp32_policy != 0 && ctx->precond == 0 && ctx->A32.p) {
-    launch_pad_vals32(ctx->stream, ctx->N2, ctx->V, ctx->rowptr.p, ctx->A.p, ctx->a32_ptr.p, ctx->a32_ptail, ctx->a32_tail_nnz,
-                      ctx->a32_tail_src, ctx->A32.p);       // rows are equilibrated: |entries| <= 1
-    ctx->op32_ok = true;
-  }
-  gcr_reset(ctx);          // the recycled directions belong to the previous matrix
-  // what decides the storage precision of the basis belongs to the Jacobian that has just been replaced: the largest
-  // right-hand side seen (one large early |b|, e.g. the first step from rest, must not keep tol_hint low for the whole run)
-  // and a fall-back to FP64 after a failed cycle (a system that lost FP32 once may not lose it with the next matrix; after
-  // two such failures the context stays FP64)
-  ctx->bnorm_max = 0.0;
-  if (ctx->kry_fp32_policy == 3 && ctx->kry_fp32_failures < 2) ctx->kry_fp32_policy = 2;
-  ctx->have_jacobian = true;
-  ctx->have_monolithic_lu = false;
-  const int rc = refresh_preconditioner(ctx);
-  if (getenv("FSI_DEBUG_FORCE_PREC_BAD")) ctx->prec_bad = true;     // test hook: this rank's self-test "fails"
-  if (!ctx->part) return rc;
-  // the self-test and the pivot checks above are rank-local: all ranks leave with the same verdict, so that either all
-  // of them enter the collectives of the next solve or none does
-  const bool bad = ctx->precond == 0 && ctx->prec_bad;
-  const int all = agree(ctx, (rc != FSI_OK || bad) ? FSI_ERR_LINEAR : FSI_OK);
-  if (all == FSI_ERR_DEVICE) return all;
-  if (all != FSI_OK) ctx->prec_bad = true;      // fsi_solve reports it on every rank
-  return rc;
-}
-
-int fsi_solve(FsiCtx* ctx, double lin_rtol, int32_t lin_max_it, int32_t lin_solver, int32_t* iters, double* relres) {
-  if (!ctx) return FSI_ERR_INVALID;
-  if (!ctx->have_jacobian) { ctx->err = "fsi_solve: no Jacobian assembled"; return FSI_ERR_INVALID; }
-  if (ctx->precond == 0 && ctx->prec_bad) { ctx->err = "block preconditioner: Chebyshev sweeps diverge on this Jacobian"; return FSI_ERR_LINEAR; }
-  HIPCHK(hipSetDevice(ctx->device));
-  if (ctx->part && lin_solver == 1) { ctx->err = "fsi_solve: the partitioned path runs GCR only (lin_solver 0)"; return FSI_ERR_INVALID; }
-  launch_mul(ctx->stream, ctx->bs.p, ctx->rowscale.p, ctx->b.p, ctx->ndof);
-  int it = 0;
-  double rr = 0.0;
-  int rc;
-  {
-    Phase ph(ctx, &ctx->t_kry);
-    if (lin_solver == 1) {
-      launch_copy(ctx->stream, ctx->F.p, ctx->bs.p, ctx->ndof);     // F is free between residual assemblies
-      rc = solve_bicgstab(ctx, ctx->F.p, ctx->du.p, lin_rtol, lin_max_it, &it, &rr);
-    } else {
-      rc = solve_gcr(ctx, ctx->bs.p, ctx->du.p, lin_rtol, lin_max_it, &it, &rr);
-    }
-  }
-  if (iters) *iters = it;
-  if (relres) *relres = rr;
-  return rc;
-}
-
-int fsi_newton_solve(FsiCtx* ctx, const FsiNewtonOpts* o, FsiNewtonIter* iters, int32_t* n_iters) {
-  if (!ctx || !o || !iters || !n_iters) return FSI_ERR_INVALID;
-  HIPCHK(hipSetDevice(ctx->device));
-  int it = 0;
-  double residual = 1e8, rel_res = 1e8, last_residual = 1e8;
-  *n_iters = 0;
-  while (rel_res > o->rtol && residual > o->atol && it < o->max_it) {
-    const bool rec = (it == 0 && o->recompute_tstep > 0 && o->counter % o->recompute_tstep == 0) ||
-                     (it > 0 && o->recompute > 0 && it % o->recompute == 0) || (it > 0 && last_residual < residual) ||
-                     (it == 0 && o->counter == o->first_step_num) || !ctx->have_jacobian;
-    if (rec) FSICHK(fsi_assemble_jacobian(ctx));
-    double bnorm = 0.0;
-    FSICHK(fsi_assemble_residual(ctx, &bnorm));
-    last_residual = residual;
-    int32_t lit = 0;
-    double lrr = 0.0;
-    // inexact Newton: the update only has to push the residual three orders below the Newton tolerance, never tighter
-    // than lin_rtol; without this the last iteration of every step solves a 1e-10-sized system to 1e-20
-    double eta = o->lin_rtol;
-    if (bnorm > 0.0 && o->atol > 0.0) eta = std::max(eta, std::min(1e-2, ctx->newton_forcing * o->atol / bnorm));
-    // Late iterations - the previous update was already within `late_factor` of the stopping tolerance, so this one is
-    // likely the last of the step - are solved with the tighter forcing term: what an inexact LAST solve leaves in the state is
-    // what separates the run from the reference's direct-LU trajectory (production defaults against
-    // exact solves).  Only while |b| is so far below the largest right-hand side of this Jacobian's life that the tighter
-    // tolerance stays above the floor the storage precision of the Krylov basis was chosen for (tol_hint below).
-    const double f_late = ctx->newton_forcing_late;
-    if (it > 0 && f_late > 0.0 && f_late < ctx->newton_forcing && bnorm > 0.0 && o->atol > 0.0 &&
-        (rel_res <= ctx->newton_late_factor * o->rtol || bnorm <= ctx->newton_late_factor * o->atol) &&
-        bnorm <= (f_late / ctx->newton_forcing) * ctx->bnorm_max) {
-      eta = std::max(o->lin_rtol, std::min(eta, f_late * o->atol / bnorm));
-      ctx->newton_late_solves += 1;
-    }
-    // the tightest linear tolerance this Newton policy can ask for while the present Jacobian lives: its forcing term at
-    // the largest right-hand side seen so far (decides the storage precision of the Krylov basis, see solve_gcr)
-    ctx->bnorm_max = std::max(ctx->bnorm_max, bnorm);
-    ctx->tol_hint = o->lin_rtol;
-    if (ctx->bnorm_max > 0.0 && o->atol > 0.0 && ctx->newton_forcing > 0.0)
-      ctx->tol_hint = std::max(o->lin_rtol, std::min(1e-2, ctx->newton_forcing * o->atol / ctx->bnorm_max));
-    ctx->in_newton = true;
-    int src = fsi_solve(ctx, eta, o->lin_max_it, o->lin_solver, &lit, &lrr);
-    bool rec_retry = false;
-    if (src == FSI_ERR_LINEAR && !rec && !ctx->prec_bad) {
-      // The iteration did not converge with a Jacobian (and a preconditioner, and a recycled space) that other states made:
-      // what the reference's policy does when the residual grows - assemble the Jacobian at the present state - is done
-      // here for the linear solver's sake, once, and the system is solved again; the iteration is reported as a refresh.
-      FSICHK(fsi_assemble_jacobian(ctx));
-      int32_t lit2 = 0;
-      src = fsi_solve(ctx, eta, o->lin_max_it, o->lin_solver, &lit2, &lrr);
-      lit += lit2;
-      rec_retry = true;
-      ctx->newton_retries += 1;
-    }
-    ctx->tol_hint = 0.0;
-    ctx->in_newton = false;
-    FSICHK(src);
-    launch_axpy(ctx->stream, ctx->U.p, o->lmbda, ctx->du.p, ctx->ndof);
-    launch_bc_set(ctx->stream, ctx->U.p, ctx->bc_dofs.p, ctx->bc_vals.p, ctx->nbc);
-    residual = bnorm;
-    // "r (rel)": L2(Omega) function norm of the update, as dolfin.norm(Function, 'l2') in the reference's newtonsolver
-    HIPCHK(hipMemsetAsync(ctx->scratch.p + 4097, 0, sizeof(double), ctx->stream));
-    if ((ctx->part ? ctx->C_owned : ctx->C) > 0)
-      launch_l2norm(ctx->stream, ctx->part ? ctx->C_owned : ctx->C, elem_arrays(ctx), ctx->du.p, ctx->scratch.p, ctx->scratch.p + 4097);
-    FSICHK(host_scalar(ctx, ctx->scratch.p + 4097, &rel_res));
-    FSICHK(allreduce(ctx, &rel_res, 1));
-    rel_res = std::sqrt(rel_res);
-    iters[it] = FsiNewtonIter{residual, rel_res, (rec || rec_retry) ? 1 : 0, lit, lrr};
-    if (getenv("FSI_DEBUG")) fprintf(stderr, "[fsi] newton %d: |b| %.3e |du|_L2 %.3e refresh %d retry %d krylov %d relres %.2e eta %.1e\n", it, residual, rel_res, (int)rec, (int)rec_retry, (int)lit, lrr, eta);
-    it += 1;
-    *n_iters = it;
-    if (!(residual <= 1e20) || !(rel_res <= 1e20)) {
-      ctx->err = "Error: The simulation has diverged during the Newton solve.";
-      return FSI_ERR_DIVERGED;
-    }
-  }
-  return FSI_OK;
-}
-
-int fsi_shift(FsiCtx* ctx) {
-  if (!ctx) return FSI_ERR_INVALID;
-  HIPCHK(hipSetDevice(ctx->device));
-  launch_copy(ctx->stream, ctx->U1.p, ctx->U.p, ctx->ndof);
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  return FSI_OK;
-}
-
 static double* state_ptr(FsiCtx* ctx, int which) {
   switch (which) {
     case 0: return ctx->U.p;

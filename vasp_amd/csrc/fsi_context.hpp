@@ -46,14 +46,13 @@ struct Level {
   int group_rows;
 };
 
-// A square sparse block with its ILU(0) factors, in CSR on structure arrays owned by the context.
+// A square sparse field block in CSR on structure arrays owned by the context.
 struct SubMat {
   int64_t n = 0, nnz = 0;
   const int64_t* rowptr = nullptr;
   const int32_t* cols = nullptr;
   const int64_t* diagpos = nullptr;
-  DevBuf<double> vals, LU;
-  std::vector<Level> levels;
+  DevBuf<double> vals;
 };
 
 // Phase timer on the solver stream.  Event pairs are recorded into a ring and resolved lazily (when the ring wraps or
@@ -69,6 +68,7 @@ struct PhaseTimer {
 }  // namespace fsi
 
 struct FsiCtx {
+  FsiTuning tune{};                          // what the context was created with (fsi_create_tuned); the fields below are set from it
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
@@ -183,10 +183,8 @@ struct FsiCtx {
   fsi::DevBuf<int64_t> s_rowptr, s_diagpos;  // explicit Schur complement on its full (two-ring) vertex pattern
   fsi::DevBuf<int32_t> s_cols;
   fsi::DevBuf<double> s_vals;
-  fsi::DevBuf<float> s_vals32, s_dinv32, s_work32;   // FSI_SCHUR_FP32: 1 (default) matrix values in FP32, vectors FP64, product fused
-  int schur_fp32 = 1;                                 // with the Chebyshev update (k_sweep_csr_mixed); 0: FP64 product + update; 2: vectors
-                                                      // in FP32 too (on the 50 k-tet generated mesh the outer GCR then makes no progress:
-                                                      // rounding noise of the pressure exceeds the velocity residual; measurement only)
+  fsi::DevBuf<float> s_vals32;                        // FSI_SCHUR_FP32: 1 (default) matrix values in FP16 / FP32, vectors FP64, product fused
+  int schur_fp32 = 1;                                 // with the Chebyshev update; 0: FP64 values
   bool schur_tiled = false; int s_tile_max_nu = 0;   // FP16 records + tile-local columns for the Schur sweep (k_sweep_schur_tiled)
   fsi::DevBuf<uint32_t> s_rec; fsi::DevBuf<uint16_t> s_ploc; fsi::DevBuf<int64_t> s_tile_uptr; fsi::DevBuf<int32_t> s_tile_ulist;
   fsi::DevBuf<double> s_dinv;
@@ -215,7 +213,7 @@ struct FsiCtx {
   fsi::DevBuf<uint8_t> mg_cflag;
   int mg_pre = 3, mg_post = 5, mg_cits = 24;  // fine Chebyshev sweeps before / after the coarse solve; coarse sweeps (round 2: 4, 6, 40 on the Gershgorin interval)
   double mg_alpha = 20.0, mg_ckappa = 250.0, mg_clmax = 2.0;   // smoothing interval [lmax/alpha, lmax]; coarse interval
-  fsi::SubMat Mdd, Mvv, Ms;                  // A_dd, Avv~, sparsified Schur complement (ILU only)
+  fsi::SubMat Mdd, Mvv;                      // A_dd, Avv~
   fsi::DevBuf<double> blk;                   // work vectors of the block preconditioner
   int64_t nS = 0;                            // solid (incl. interface) nodes; compact velocity block A_SS on them
   fsi::DevBuf<int32_t> snode, ss_cols;
@@ -248,8 +246,6 @@ struct FsiCtx {
   fsi::DevBuf<double> mask_s, mask_f;        // [3 N2] 1 on velocity dofs of solid (incl. interface) / fluid-interior nodes
   int cheb_its_s = 300, cheb_its_f = 4, cheb_its_p = 30, cheb_its_d = 60;     // Chebyshev sweeps on the solid / fluid part of the velocity block
   double cheb_kappa_s = 1e4, cheb_kappa_f = 5.0, cheb_kappa_p = 100.0, lmax_s = 1.0, lmax_f = 1.0, lmax_p = 1.0, cheb_kappa_d = 1000.0, lmax_d = 1.0;
-  double inner_rtol = 1e-2;
-  int inner_maxit = 40, inner_maxit_p = 60;
   int64_t inner_its[3] = {0, 0, 0};          // accumulated inner iterations: vv, schur, dd
   int64_t inner_calls = 0;
   int64_t pivot_warnings = 0;
@@ -280,7 +276,6 @@ struct FsiCtx {
   std::vector<int32_t> kry_free;             // free slots (retired in batches when the store is full)
   double gs_rtol = 0.0;                      // tightest linear tolerance asked for since the last Jacobian (re-orthogonalisation criterion)
   int64_t ortho_q_cols = 0, ortho_z_cols = 0, ortho_q_launches = 0, ortho_z_launches = 0;   // columns streamed (exact bytes of the orthogonalisation)
-  bool gcr_arnoldi = false;                  // FSI_GCR_ARNOLDI=1: new directions from the latest q instead of the residual (measured: worse)
   fsi::DevBuf<float> A32;                         // FP32 copy of A for the products inside the Krylov iterations (FSI_OPERATOR_FP32, default on)
   bool op32_ok = false; int op32_policy = 1; int64_t op32_products = 0;
   fsi::DevBuf<int64_t> a32_ptr;              // [N2 + 1] first entry of a node's padded block in A32 (k_spmv_node6p)

@@ -231,12 +231,12 @@ __global__ __launch_bounds__(256) void k_gcr_flush(double* __restrict__ Z, int64
 template <class QT>
 void dots_t(hipStream_t st, const void* Q, int64_t ldq, int64_t n, int m, const double* w, const double* r,
             double* scratch, double* out) {
-  static const int npmax = getenv("FSI_GCR_NP") ? atoi(getenv("FSI_GCR_NP")) : 128;      // 128: 3 000 workgroups at m = 180 (64: 4 % slower, 256: same)
+  constexpr int npmax = 128;      // 128: 3 000 workgroups at m = 180 (64: 4 % slower, 256: same)
   int np = (int)((n + 16383) / 16384);
   if (np < 1) np = 1;
   if (np > npmax) np = npmax;
   // columns per read of w: 8 for FP32 and (round 3) for FP64 columns: w is re-read for 1/8 instead of 1/4 of Q's bytes; FSI_GCR_NC64=4: round 2
-  static const int nc64 = getenv("FSI_GCR_NC64") ? atoi(getenv("FSI_GCR_NC64")) : 8;      // measured: 1 930 -> 1 898 ms per 20 bench steps
+  constexpr int nc64 = 8;      // measured: 1 930 -> 1 898 ms per 20 bench steps
   if (sizeof(QT) == 8 && nc64 == 8) {
     const int ngroups = (m + 7) / 8;
     hipLaunchKernelGGL((k_gcr_dots<QT, 8>), dim3(np, ngroups + 1), dim3(256), 0, st, static_cast<const QT*>(Q), ldq, n, m, w, r, scratch);

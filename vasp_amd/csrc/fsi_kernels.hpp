@@ -96,7 +96,7 @@ void launch_probe(hipStream_t st, int64_t n, const ElemArrays& ea, const int32_t
                   double* out);
 void launch_l2norm(hipStream_t st, int64_t C, const ElemArrays& ea, const double* X, double* part, double* out);
 void launch_jacobian(hipStream_t st, int part, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
-                     const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals, const CellColours& cc);
+                     const double* U1, const int64_t* rowptr, const int64_t* nadj_ptr, double* vals, const CellColours& cc, int jac_waves = 2, int jac_mfma = 0);
 
 void launch_sweep_csr_f64(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const double* vals,
                           const int64_t* diagpos, double c1, double c2, const double* din, double* dout, double* x, double* r);
@@ -189,10 +189,6 @@ void launch_extract_blocks(hipStream_t st, int64_t N2, int64_t V, double ktheta,
                            const int32_t* node_solid, const int64_t* rowptr3, const int64_t* rowptr_vp,
                            const int64_t* rowptr_pv, const int64_t* rowptr_pp, double* Add, double* Adv, double* Avv,
                            double* Avp, double* Apv, double* App);
-void launch_schur_p1(hipStream_t st, int64_t V, const int32_t* vrank, const int64_t* nadj_ptr, const int32_t* nadj,
-                     const int64_t* padj_ptr, const int32_t* padj, const int64_t* rowptr_pv, const double* Apv,
-                     const int64_t* rowptr_pp, const double* App, const int64_t* rowptr_vp, const double* Avp,
-                     const int64_t* diagpos3, const double* Avv, double* S1, int32_t* flags);
 void launch_schur_full(hipStream_t st, int64_t V, const int64_t* s_rowptr, const int32_t* s_cols, const int32_t* vrank,
                        const int64_t* nadj_ptr, const int32_t* nadj, const int64_t* padj_ptr, const int32_t* padj,
                        const int64_t* rowptr_pv, const double* Apv, const int64_t* rowptr_pp, const double* App,
@@ -269,11 +265,6 @@ void launch_residual_rows(hipStream_t st, int64_t nrows, const int32_t* rows, co
                           const int64_t* src, const double* vals, const double* x, const double* b, double* y);
 void launch_spmv_node6(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const double* vals,
                        const double* x, double* y);
-void launch_sweep_csr_f32(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const float* vals,
-                          const float* dinv, float c1, float c2, const float* din, float* dout, float* x, float* r);
-void launch_csr_dinv_f32(hipStream_t st, int64_t n, const int64_t* diagpos, const double* A, float* dinv);
-void launch_cheb_init_plain_f32(hipStream_t st, int64_t n, const double* rhs, const float* dinv, float inv_theta, float* x,
-                                float* r, float* d, float* d2);
 void launch_sweep_csr_mixed(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const float* vals,
                             const int64_t* diagpos, const double* dvals, double c1, double c2, const double* din, double* dout,
                             double* x, double* r);
@@ -281,7 +272,6 @@ int schur_tile_rows();
 void launch_sweep_schur_tiled(hipStream_t st, int64_t n, int max_nu, const int64_t* rowptr, const uint32_t* rec,
                               const int64_t* tile_uptr, const int32_t* ulist, const double* dinv, double c1, double c2,
                               const double* din, double* dout, double* x, double* r);
-void launch_f32_to_f64(hipStream_t st, int64_t n, const float* a, double* b);
 void launch_sbmg_flags(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals, uint8_t* flag);
 void launch_sbmg_rap(hipStream_t st, int64_t nc, const int64_t* chptr, const int32_t* child, const float* chw,
                      const int64_t* sb_ptr, const int32_t* sb_col, const float* vals, const int32_t* snode,

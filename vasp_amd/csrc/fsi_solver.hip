@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void k_spmv_node6(int64_t N2, const int64_t* _
 template <class VT>
 static void spmv_node6_any(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const VT* vals,
                            const double* x, double* y) {
-  static const bool xcd = !(getenv("FSI_SPMV_XCD") && atoi(getenv("FSI_SPMV_XCD")) == 0);
+  constexpr bool xcd = true;        // XCD-aware node mapping: -9 % HBM traffic (round 2)
   int64_t blocks = (N2 + 3) / 4;                                 // one wave per node (see launch_spmv_node6p)
   blocks = (blocks + 7) & ~(int64_t)7;
   if (xcd) hipLaunchKernelGGL((k_spmv_node6<VT, true>), dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, cols, vals, x, y);
@@ -341,10 +341,10 @@ void launch_pad_vals32(hipStream_t st, int64_t N2, int64_t V, const int64_t* row
 // shifted by tail_shift = ptail - rowptr[6 N2])
 void launch_spmv_node6p(hipStream_t st, int64_t N2, int64_t V, const int64_t* p32, const int32_t* cols32, const float* vals,
                         const int64_t* rowptr, const int32_t* cols, int64_t tail_shift, const double* x, double* y) {
-  static const bool xcd = !(getenv("FSI_SPMV_XCD") && atoi(getenv("FSI_SPMV_XCD")) == 0);
+  constexpr bool xcd = true;        // XCD-aware node mapping: -9 % HBM traffic (round 2)
   // one wave per node, no grid-stride loop: measured 1.87 ms per product against 2.23 ms with 8192 workgroups looping
   // (row lengths differ by 3x between edge and vertex nodes; the hardware scheduler balances what a static stride cannot)
-  static const int64_t bmax = getenv("FSI_SPMV_BLOCKS") ? atoi(getenv("FSI_SPMV_BLOCKS")) : (int64_t)1 << 30;
+  constexpr int64_t bmax = (int64_t)1 << 30;      // one wave per node, no grid-stride loop (round 2)
   int64_t blocks = (N2 + 3) / 4;
   if (blocks > bmax) blocks = bmax;
   blocks = (blocks + 7) & ~(int64_t)7;
