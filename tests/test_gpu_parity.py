@@ -467,6 +467,80 @@ def test_properties_at_bench_size(tmp_path):
     hb.close()
 
 
+def test_properties_at_config3_size_with_the_robin_wall(tmp_path):
+    """BASELINE configs[2]: the aneurysm problem file (StVK wall, Robin condition on the outer wall [REF
+    src/vasp/simulations/aneurysm.py:73-76], its own tolerances 1e-10 / 1e-9 [:48-49]) at ~3 M tets in ONE context - the size the
+    config spreads over 4 GPUs - on the synthetic tube (the tutorial mesh is not in the tree).  No oracle run at this size:
+    F(0; 0) = 0, linearity of the product, the Robin term's contribution to residual and matrix (a rigid wall translation d = c
+    loads the outer wall with theta k_s c A; its derivative is the matrix column sum), and two time steps whose Newton residuals
+    fall under the problem's tolerances with the storage the policy picks.  The 288 GB of one MI355X hold it: the HBM in use
+    is printed."""
+    import json
+    import torch
+    from vasp_amd.capi import HipBackend
+    from vasp_amd.mesh import FsiMesh
+    from vasp_amd.meshgen import generate
+    m = generate(3600000)                                # the generator's sizes: 2.60 M or 3.58 M tets; config 3 says ~3 M
+    FsiMesh.from_arrays(m["coords"], m["tets"], m["cell_markers"], m["facets"], m["facet_markers"]).write(tmp_path / "aneurysm.h5")
+    del m
+    (tmp_path / "aneurysm_probe_point.json").write_text(json.dumps([[0.0, 0.0, 0.0], [16.0, 0.0, 0.0]]))
+    case = prepare_case("aneurysm", tmp_path / "aneurysm.h5", tmp_path / "run", dt="0.001", T="0.2", theta="0.501")
+    ns, desc = case[0], case[1]
+    mesh = ns["mesh"]
+    assert mesh.num_cells > 3_000_000 and len(desc["robin_facets"]) > 0
+    hb = HipBackend(desc)
+    free_b, total_b = torch.cuda.mem_get_info()
+    print(f"{mesh.num_cells} tets, {hb.ndof} dofs, matrix entries {int(hb.lib.fsi_matrix_nnz(hb.ctx))}: HBM in use {(total_b - free_b) / 2**30:.0f} GiB "
+          f"of {total_b / 2**30:.0f}, Krylov capacity {hb.timers()['krylov_cap']}")
+    nbc = len(desc["bc_dofs"])
+    hb.set_dirichlet_values(np.zeros(nbc)); hb.set_interface_pressure(0.0)
+    assert hb.assemble_residual() == 0.0
+    # Robin term: with the solid displaced rigidly by c (fluid at rest, no velocity) the only load on the d-rows of the outer
+    # wall... is carried by the v-equation rows: sum over the wall's v_x rows of F = theta k_s c_x A (partition of unity)
+    N2 = mesh.num_nodes
+    wall_nodes = np.unique(np.asarray(desc["robin_facets"]))
+    solid_nodes = np.unique(mesh.tet_nodes[np.asarray(desc["cell_kind"]) == 1])
+    U = np.zeros(hb.ndof)
+    c = 1e-6
+    U[3 * solid_nodes] = c                              # d_x = c on every solid node: zero strain, zero stress
+    hb.set_state("n", U); hb.set_state("n-1", U)
+    hb.assemble_residual()
+    b = hb.get_state("b")
+    x = mesh.coords
+    f = np.asarray(desc["robin_facets"])[:, :3]
+    area = 0.5 * np.linalg.norm(np.cross(x[f[:, 1]] - x[f[:, 0]], x[f[:, 2]] - x[f[:, 0]]), axis=1).sum()
+    k_s = float(np.asarray(desc["robin_k"])[0])
+    bc_set = set(np.asarray(desc["bc_dofs"]).tolist())
+    rows = np.array([3 * N2 + 3 * n for n in wall_nodes if (3 * N2 + 3 * n) not in bc_set])
+    # b = -F; the theta-weighted Robin load k_s (theta d^n + (1 - theta) d^{n-1}) = k_s c on the whole wall
+    total = -b[3 * N2 + 3 * solid_nodes].sum()
+    assert total == pytest.approx(k_s * c * area, rel=2e-2), (total, k_s * c * area)       # (Dirichlet rims of the wall are excluded)
+    assert len(rows) > 0
+    hb.set_state("n", np.zeros(hb.ndof)); hb.set_state("n-1", np.zeros(hb.ndof))
+    g, P = boundary_data(case, 1e-3)
+    hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+    hb.assemble_jacobian()
+    rng = np.random.default_rng(0)
+    xv, yv = rng.standard_normal(hb.ndof), rng.standard_normal(hb.ndof)
+    ax, ay, axy = hb.spmv(xv), hb.spmv(yv), hb.spmv(2 * xv - 3 * yv)
+    assert np.abs(axy - (2 * ax - 3 * ay)).max() <= 1e-12 * np.abs(axy).max()
+    its = []
+    for k in range(2):
+        g, P = boundary_data(case, 1e-3 * (k + 1))
+        hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+        hist = hb.newton_solve(counter=k, first_step_num=0, atol=ns["atol"], rtol=ns["rtol"], max_it=ns["max_it"], lmbda=1.0,
+                               recompute=ns["recompute"], recompute_tstep=ns["recompute_tstep"])
+        hb.shift()
+        assert hist[-1][0] < ns["atol"] or hist[-1][1] < ns["rtol"], hist
+        assert hist[-1][0] < 1e-3 * hist[0][0]
+        its.append([h[3] for h in hist])
+    tm = hb.timers()
+    print("Krylov iterations per Newton iteration:", its, "Q bytes", tm["q_elem_bytes"], "events",
+          {k: int(tm[k]) for k in ("gcr_restarts", "newton_retries", "fp32_fallbacks")})
+    assert tm["newton_retries"] == 0 and np.isfinite(hb.get_state("n")).all()
+    hb.close()
+
+
 def test_error_behaviour(cyl, cylinder_case):
     from vasp_amd.capi import FsiError
     with pytest.raises(FsiError) as e:

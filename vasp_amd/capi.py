@@ -276,6 +276,7 @@ class HipBackend:
             self._check(self.lib.fsi_set_robin_facets(self.ctx, len(rf), _ptr(rf), _ptr(rk), _ptr(rcoef)))
         self._check(self.lib.fsi_solver_setup(self.ctx))
         self.history: List[list] = []
+        self._flow_stats = None
 
     # ---- plumbing ---------------------------------------------------------------------------------
     def _check(self, rc: int):
@@ -306,6 +307,7 @@ class HipBackend:
                              int(first_step_num), self.lin_rtol, self.lin_max_it, self.lin_solver)
         iters = (FsiNewtonIter * int(max_it))()
         n = C.c_int32(0)
+        self._flow_stats = None
         rc = self.lib.fsi_newton_solve(self.ctx, C.byref(opts), iters, C.byref(n))
         hist = []
         for i in range(n.value):
@@ -340,6 +342,7 @@ class HipBackend:
     def set_state(self, which, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         assert x.shape == (self.ndof,)
+        self._flow_stats = None
         self._check(self.lib.fsi_set_state(self.ctx, STATE[which], _ptr(x)))
 
     # ---- pieces of the hot path (tests, benchmarks) ----------------------------------------------------
@@ -392,10 +395,14 @@ class HipBackend:
         return out
 
     def flow_stats(self):
-        """(mean, min, max of the cell-mean |v|, min of the cell-mean det(I + grad d)) of dvp_["n"]."""
-        out = np.empty(4)
-        self._check(self.lib.fsi_flow_stats(self.ctx, _ptr(out)))
-        return tuple(out)
+        """(mean, min, max of the cell-mean |v|, min of the cell-mean det(I + grad d)) of dvp_["n"].  post_solve asks twice
+        per step (flow properties, minimum Jacobian [REF src/vasp/simulations/simulation_common.py:253-348]): the second call of
+        a step returns the first one's numbers (the state changes only through newton_solve / set_state)."""
+        if self._flow_stats is None:
+            out = np.empty(4)
+            self._check(self.lib.fsi_flow_stats(self.ctx, _ptr(out)))
+            self._flow_stats = tuple(out)
+        return self._flow_stats
 
     def stress_strain(self, cells):
         """DG1 Cauchy stress / Green-Lagrange strain / largest principal values on solid ``cells`` of dvp_["n"]."""

@@ -334,6 +334,7 @@ class DistBackend:
         self.on_gpu_wire = dist.get_backend() == "nccl"                       # RCCL moves device buffers directly
         self.control = control
         self._pending_bc = self._pending_P = None
+        self._flow_stats = None
         import os
         # Overlap of the restricted Schwarz preconditioner, in node layers.  Measured on the 1.12 M-tet bench mesh (5 steps from
         # rest, Krylov iterations; one context: 114): 2 ranks 138 / 124 / 118 with 2 / 3 / 4 layers (3.8 / 5.1 / 6.4 % ghost
@@ -559,13 +560,17 @@ class DistBackend:
 
     def flow_stats(self):
         """HipBackend.flow_stats over the whole job: every rank contributes the cells it owns (fsi_flow_stats counts those)."""
+        if self._flow_stats is not None and self.hb._flow_stats is not None:
+            return self._flow_stats            # second request of a step: every driving rank makes the same decision (the state
+                                               # changed on all of them or on none); a worker is only here when rank 0 was not
         self._tell("flow_stats")
         n = self.part.num_owned_cells
         mean, mn, mx, mj = self.hb.flow_stats() if n > 0 else (0.0, np.inf, -np.inf, np.inf)
         tot = self._reduce([mean * n, float(n)], "sum")
         lo = self._reduce([mn, mj], "min")
         hi = self._reduce([mx], "max")
-        return float(tot[0] / max(tot[1], 1.0)), float(lo[0]), float(hi[0]), float(lo[1])
+        self._flow_stats = (float(tot[0] / max(tot[1], 1.0)), float(lo[0]), float(hi[0]), float(lo[1]))
+        return self._flow_stats
 
     def probe(self, cells, bary):
         """HipBackend.probe for global cell ids: the owner of a cell evaluates its points, the rest add zeros."""
@@ -686,6 +691,8 @@ def serve(db: "DistBackend", control: ControlChannel) -> None:
         if op == "close":
             db.close()
             return
+        if op == "flow_stats":
+            db._flow_stats = None              # rank 0 announced the call, so it is making the reductions: take part
         try:
             getattr(db, op)(*args, **kw)
         except Exception as e:            # the library agrees on failures across ranks: rank 0 raises the same error and decides
