@@ -217,6 +217,59 @@ def test_driver_and_worker_ranks_match_single_context(tmp_path):
     assert el >= 1.0 and units == 7.0 and cells_all > cells_global           # rank 0's units only; ghost layers counted twice
 
 
+def _two_device_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from vasp_amd.partition import DistBackend
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    out = {}
+    for mode in ("1", "0"):                                  # the library's own RCCL calls, then the torch.distributed callbacks
+        os.environ["VASPFSI_RCCL"] = mode
+        (ns, desc, bc_values, pressure, hook), dt = _case("cylinder", tempfile.mkdtemp())
+        db = DistBackend(desc, dist, device=rank, lin_rtol=1e-12)
+        hist = _time_steps(db, ns, bc_values, pressure, hook, dt)
+        x = db.get_state("n")
+        tm = db.timers()
+        out[mode] = (x, [[it[0] for it in h] for h in hist], tm["part_allreduces"], tm["krylov_iters"], db.library_rccl)
+        db.close()
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_library_rccl_matches_the_callbacks_on_two_devices():
+    """the library-side RCCL transport (grouped ncclSend / ncclRecv halo, ncclAllReduce on the coefficient vector with
+    the lagged |r|^2 slot, next to torch's own communicator on the same devices) against the torch.distributed callback path,
+    TWO ranks on TWO devices: same fields, same residual histories, same number of reductions inside the Krylov iterations.  Needs
+    a node with at least two GPUs (RCCL refuses two ranks on one device): skipped on the one-GPU boxes of this pool."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_device_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=900)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (x1, h1, red1, it1, lib1), (x0, h0, red0, it0, lib0) = out["1"], out["0"]
+    assert lib1 is True and lib0 is False
+    assert np.abs(x1 - x0).max() <= 1e-10 * np.abs(x0).max()
+    assert len(h1) == len(h0) and all(np.allclose(a[:min(len(a), len(b))], b[:min(len(a), len(b))], rtol=1e-6, atol=1e-14) for a, b in zip(h1, h0))
+    assert abs(it1 - it0) <= 0.05 * it0 + 2 and abs(red1 - red0) <= 0.1 * red0 + 4, (it1, it0, red1, red0)
+
+
 def _failing_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if rank == 1:

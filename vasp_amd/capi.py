@@ -45,7 +45,7 @@ class FsiTuning(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("krylov_fp32", C.c_int32), ("operator_fp32", C.c_int32), ("schur_fp32", C.c_int32),
                 ("sweeps_fp32", C.c_int32), ("sweeps_fp16", C.c_int32), ("solid_fp32", C.c_int32), ("pv_fp32", C.c_int32),
                 ("krylov_capacity", C.c_int32), ("krylov_fp32_floor", C.c_double),
-                ("assembly_atomic", C.c_int32), ("node_order", C.c_int32), ("tiles", C.c_int32), ("jacobian_waves", C.c_int32),
+                ("assembly_atomic", C.c_int32), ("node_order", C.c_int32), ("tiles", C.c_int32), ("tile_nodes", C.c_int32), ("schur_tile_rows", C.c_int32), ("jacobian_waves", C.c_int32),
                 ("jacobian_mfma", C.c_int32),
                 ("newton_forcing", C.c_double), ("newton_forcing_late", C.c_double), ("newton_late_factor", C.c_double),
                 ("f32_cycle_floor", C.c_double), ("f32_verdict_skip_rtol", C.c_double), ("orth_floor32", C.c_double),

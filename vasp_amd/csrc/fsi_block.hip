@@ -574,25 +574,24 @@ __global__ __launch_bounds__(256) void k_spmv_sc_f32(int64_t N2, const int64_t* 
   }
 }
 
-// ---- LDS-tiled variants: a workgroup owns TILE_NODES consecutive nodes; the vector entries of all their neighbours
+// ---- LDS-tiled variants: a workgroup owns TN (128 | 256, per context) consecutive nodes; the vector entries of all their neighbours
 // (a few thousand distinct nodes in mesh order) are gathered ONCE into LDS, the node-pair loop then reads 16-byte
 // entries from LDS through 2-byte local indices.  HBM per pair: value(s) + 2 B instead of value(s) + 4 B + a 16-B
 // gather that the L1/L2 have to serve.
-static constexpr int TILE_NODES = 256;
 static constexpr int TILE_LIMIT = 3584;          // distinct neighbour nodes per tile (56 KB of LDS as float4; + 6 KB static < 64 KB per workgroup)
-template <int NV>     // NV = 1: one ratio per pair (displacement block), NV = 3: component-diagonal values (fluid velocity block)
+template <int NV, int TN>     // NV = 1: one ratio per pair (displacement block), NV = 3: component-diagonal values (fluid velocity block)
 __global__ __launch_bounds__(256) void k_spmv_tiled_f32(int64_t N2, const int64_t* __restrict__ nadj_ptr,
                                                         const float* __restrict__ vals, const uint16_t* __restrict__ ploc,
                                                         const int64_t* __restrict__ tile_uptr, const int32_t* __restrict__ ulist,
                                                         const uint8_t* __restrict__ rowflag, const float* __restrict__ x,
                                                         float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) float4 sx[];   // max over the tiles of their distinct-neighbour count
-  __shared__ __attribute__((aligned(16))) int64_t sptr[TILE_NODES + 2];   // size a multiple of 16 B: keeps the dynamic base aligned
+  __shared__ __attribute__((aligned(16))) int64_t sptr[TN + 2];   // size a multiple of 16 B: keeps the dynamic base aligned
   const int64_t tile = blockIdx.x;
   const int64_t u0 = tile_uptr[tile], nu = tile_uptr[tile + 1] - u0;
   const float4* x4 = reinterpret_cast<const float4*>(x);
-  const int64_t r0 = tile * TILE_NODES;
-  const int nrows = (int)((r0 + TILE_NODES < N2 ? r0 + TILE_NODES : N2) - r0);
+  const int64_t r0 = tile * TN;
+  const int nrows = (int)((r0 + TN < N2 ? r0 + TN : N2) - r0);
   for (int64_t i = threadIdx.x; i < nu; i += 256) sx[i] = x4[ulist[u0 + i]];
   for (int i = threadIdx.x; i <= nrows; i += 256) sptr[i] = nadj_ptr[r0 + i];
   __syncthreads();
@@ -649,21 +648,26 @@ __global__ __launch_bounds__(256) void k_spmv_tiled_f32(int64_t N2, const int64_
     i = ni;
   }
 }
-void launch_spmv_tiled_f32(hipStream_t st, int nv, int64_t N2, int max_nu, const int64_t* nadj_ptr, const float* vals,
+// (the launchers take the context's tile size tn = 128 | 256: FsiTuning.tile_nodes, 0 = by the number of nodes)
+#define TILED_DISPATCH(KERNEL, THREADS, ...)                                                                                     \
+  do {                                                                                                                           \
+    if (nv == 1 && tn == 128) hipLaunchKernelGGL((KERNEL<1, 128>), dim3(tiles), dim3(THREADS), lds, st, __VA_ARGS__);           \
+    else if (nv == 1) hipLaunchKernelGGL((KERNEL<1, 256>), dim3(tiles), dim3(THREADS), lds, st, __VA_ARGS__);                   \
+    else if (tn == 128) hipLaunchKernelGGL((KERNEL<3, 128>), dim3(tiles), dim3(THREADS), lds, st, __VA_ARGS__);                 \
+    else hipLaunchKernelGGL((KERNEL<3, 256>), dim3(tiles), dim3(THREADS), lds, st, __VA_ARGS__);                                \
+  } while (0)
+void launch_spmv_tiled_f32(hipStream_t st, int nv, int tn, int64_t N2, int max_nu, const int64_t* nadj_ptr, const float* vals,
                            const uint16_t* ploc, const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag,
                            const float* x, float* y) {
-  const unsigned tiles = (unsigned)((N2 + TILE_NODES - 1) / TILE_NODES);
+  const unsigned tiles = (unsigned)((N2 + tn - 1) / tn);
   const size_t lds = (size_t)max_nu * sizeof(float4);
-  if (nv == 1)
-    hipLaunchKernelGGL(k_spmv_tiled_f32<1>, dim3(tiles), dim3(256), lds, st, N2, nadj_ptr, vals, ploc, tile_uptr, ulist, rowflag, x, y);
-  else
-    hipLaunchKernelGGL(k_spmv_tiled_f32<3>, dim3(tiles), dim3(256), lds, st, N2, nadj_ptr, vals, ploc, tile_uptr, ulist, rowflag, x, y);
+  TILED_DISPATCH(k_spmv_tiled_f32, 256, N2, nadj_ptr, vals, ploc, tile_uptr, ulist, rowflag, x, y);
 }
 // One Chebyshev sweep on the tiled operator in a single launch (the product never goes through memory):
 //   t = A d_in;  x += d_in;  r -= t;  d_out = c1 d_in + c2 dinv r      (d is ping-ponged: other tiles still gather d_in)
 // Workgroups of up to 1024 threads: the tile's LDS (up to 64 KB) allows two workgroups per CU whatever their size, and the
 // row loop is bound by load latency, so 32 waves per CU instead of 8 is what the kernel is after.
-template <int NV>
+template <int NV, int TN>
 __global__ __launch_bounds__(1024) void k_sweep_tiled_f32(int64_t N2, const int64_t* __restrict__ nadj_ptr,
                                                           const float* __restrict__ vals, const uint16_t* __restrict__ ploc,
                                                           const int64_t* __restrict__ tile_uptr, const int32_t* __restrict__ ulist,
@@ -671,13 +675,13 @@ __global__ __launch_bounds__(1024) void k_sweep_tiled_f32(int64_t N2, const int6
                                                           float c1, float c2, const float* __restrict__ din, float* __restrict__ dout,
                                                           float* __restrict__ x, float* __restrict__ r) {
   extern __shared__ __attribute__((aligned(16))) float4 sx[];
-  __shared__ __attribute__((aligned(16))) int64_t sptr[TILE_NODES + 2];
-  __shared__ __attribute__((aligned(16))) float4 ssum[TILE_NODES];   // the tile's products; the update below reads them coalesced
+  __shared__ __attribute__((aligned(16))) int64_t sptr[TN + 2];
+  __shared__ __attribute__((aligned(16))) float4 ssum[TN];   // the tile's products; the update below reads them coalesced
   const int64_t tile = blockIdx.x;
   const int64_t u0 = tile_uptr[tile], nu = tile_uptr[tile + 1] - u0;
   const float4* d4 = reinterpret_cast<const float4*>(din);
-  const int64_t r0 = tile * TILE_NODES;
-  const int nrows = (int)((r0 + TILE_NODES < N2 ? r0 + TILE_NODES : N2) - r0);
+  const int64_t r0 = tile * TN;
+  const int nrows = (int)((r0 + TN < N2 ? r0 + TN : N2) - r0);
   const int nth = blockDim.x, ngrp = nth >> 4;
   for (int64_t i = threadIdx.x; i < nu; i += 4 * nth) {        // index -> entry is a dependent pair of loads: four pairs in flight
     const int64_t i1 = i + nth, i2 = i + 2 * nth, i3 = i + 3 * nth;
@@ -759,17 +763,13 @@ __global__ __launch_bounds__(1024) void k_sweep_tiled_f32(int64_t N2, const int6
 // (The dynamic LDS is sized for the largest tile; on the 1.12 M-tet mesh the tiles gather 889 distinct neighbours in the
 // median and 1325 at most, 21 KB, so LDS does not limit the occupancy.  Splitting the tiles into two launches by size was
 // measured: slower, 159 against 143 us.)
-void launch_sweep_tiled_f32(hipStream_t st, int nv, int64_t N2, int max_nu, const int64_t* nadj_ptr, const float* vals,
+void launch_sweep_tiled_f32(hipStream_t st, int nv, int tn, int64_t N2, int max_nu, const int64_t* nadj_ptr, const float* vals,
                             const uint16_t* ploc, const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag,
                             const float* dinv, float c1, float c2, const float* din, float* dout, float* x, float* r) {
-  constexpr int threads = 512;      // measured: 1024 no gain over 512 (round 2)
-  const int th = threads >= 1024 ? 1024 : (threads >= 512 ? 512 : 256);
-  const unsigned tiles = (unsigned)((N2 + TILE_NODES - 1) / TILE_NODES);
+  const int th = tn == 128 ? 256 : 512;      // 16 lanes per node, 8 rounds per tile (measured at 256 nodes: 1024 threads no gain over 512)
+  const unsigned tiles = (unsigned)((N2 + tn - 1) / tn);
   const size_t lds = (size_t)max_nu * sizeof(float4);
-  if (nv == 1)
-    hipLaunchKernelGGL(k_sweep_tiled_f32<1>, dim3(tiles), dim3(th), lds, st, N2, nadj_ptr, vals, ploc, tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
-  else
-    hipLaunchKernelGGL(k_sweep_tiled_f32<3>, dim3(tiles), dim3(th), lds, st, N2, nadj_ptr, vals, ploc, tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
+  TILED_DISPATCH(k_sweep_tiled_f32, th, N2, nadj_ptr, vals, ploc, tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
 }
 // ---- FP16 matrix values for the fine-level sweeps ---------------------------------------------------------------------
 // The sweeps are a fixed polynomial in a matrix that only has to resemble the block it preconditions; rounding its VALUES
@@ -808,7 +808,7 @@ template <int NV> struct TileRec;
 template <> struct TileRec<1> { using type = uint32_t; };
 template <> struct TileRec<3> { using type = uint2; };
 // k_sweep_tiled_f32 on the packed records
-template <int NV>
+template <int NV, int TN>
 __global__ __launch_bounds__(1024) void k_sweep_tiled_h(int64_t N2, const int64_t* __restrict__ nadj_ptr,
                                                         const typename TileRec<NV>::type* __restrict__ rec,
                                                         const int64_t* __restrict__ tile_uptr, const int32_t* __restrict__ ulist,
@@ -817,13 +817,13 @@ __global__ __launch_bounds__(1024) void k_sweep_tiled_h(int64_t N2, const int64_
                                                         float* __restrict__ x, float* __restrict__ r) {
   using Rec = typename TileRec<NV>::type;
   extern __shared__ __attribute__((aligned(16))) float4 sx[];
-  __shared__ __attribute__((aligned(16))) int64_t sptr[TILE_NODES + 2];
-  __shared__ __attribute__((aligned(16))) float4 ssum[TILE_NODES];
+  __shared__ __attribute__((aligned(16))) int64_t sptr[TN + 2];
+  __shared__ __attribute__((aligned(16))) float4 ssum[TN];
   const int64_t tile = blockIdx.x;
   const int64_t u0 = tile_uptr[tile], nu = tile_uptr[tile + 1] - u0;
   const float4* d4 = reinterpret_cast<const float4*>(din);
-  const int64_t r0 = tile * TILE_NODES;
-  const int nrows = (int)((r0 + TILE_NODES < N2 ? r0 + TILE_NODES : N2) - r0);
+  const int64_t r0 = tile * TN;
+  const int nrows = (int)((r0 + TN < N2 ? r0 + TN : N2) - r0);
   const int nth = blockDim.x, ngrp = nth >> 4;
   for (int64_t i = threadIdx.x; i < nu; i += 4 * nth) {        // index -> entry is a dependent pair of loads: four pairs in flight
     const int64_t i1 = i + nth, i2 = i + 2 * nth, i3 = i + 3 * nth;
@@ -889,17 +889,20 @@ __global__ __launch_bounds__(1024) void k_sweep_tiled_h(int64_t N2, const int64_
     dout[gi] = comp < 3 ? c1 * di + c2 * ri * (dinv ? dinv[gi] : 1.f) : 0.f;
   }
 }
-void launch_sweep_tiled_h(hipStream_t st, int nv, int64_t N2, int max_nu, const int64_t* nadj_ptr, const void* rec,
+void launch_sweep_tiled_h(hipStream_t st, int nv, int tn, int64_t N2, int max_nu, const int64_t* nadj_ptr, const void* rec,
                           const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag, const float* dinv, float c1,
                           float c2, const float* din, float* dout, float* x, float* r) {
-  constexpr int threads = 512;      // measured: 1024 no gain over 512 (round 2)
-  const int th = threads >= 1024 ? 1024 : (threads >= 512 ? 512 : 256);
-  const unsigned tiles = (unsigned)((N2 + TILE_NODES - 1) / TILE_NODES);
+  const int th = tn == 128 ? 256 : 512;
+  const unsigned tiles = (unsigned)((N2 + tn - 1) / tn);
   const size_t lds = (size_t)max_nu * sizeof(float4);
-  if (nv == 1)
-    hipLaunchKernelGGL(k_sweep_tiled_h<1>, dim3(tiles), dim3(th), lds, st, N2, nadj_ptr, static_cast<const uint32_t*>(rec), tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
+  if (nv == 1 && tn == 128)
+    hipLaunchKernelGGL((k_sweep_tiled_h<1, 128>), dim3(tiles), dim3(th), lds, st, N2, nadj_ptr, static_cast<const uint32_t*>(rec), tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
+  else if (nv == 1)
+    hipLaunchKernelGGL((k_sweep_tiled_h<1, 256>), dim3(tiles), dim3(th), lds, st, N2, nadj_ptr, static_cast<const uint32_t*>(rec), tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
+  else if (tn == 128)
+    hipLaunchKernelGGL((k_sweep_tiled_h<3, 128>), dim3(tiles), dim3(th), lds, st, N2, nadj_ptr, static_cast<const uint2*>(rec), tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
   else
-    hipLaunchKernelGGL(k_sweep_tiled_h<3>, dim3(tiles), dim3(th), lds, st, N2, nadj_ptr, static_cast<const uint2*>(rec), tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
+    hipLaunchKernelGGL((k_sweep_tiled_h<3, 256>), dim3(tiles), dim3(th), lds, st, N2, nadj_ptr, static_cast<const uint2*>(rec), tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
 }
 // k_sweep_sb_b3<0> on the packed 24-byte block records
 __global__ __launch_bounds__(256) void k_sweep_sb_h(int64_t nS, const int64_t* __restrict__ sb_ptr, const uint2* __restrict__ rec,
@@ -997,7 +1000,6 @@ void launch_sweep_sc_f32(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, co
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(k_sweep_sc_f32, dim3((unsigned)blocks), dim3(256), 0, st, N2, nadj_ptr, nadj, chat, rowflag, c1, c2, din, dout, x, r);
 }
-int tile_nodes() { return TILE_NODES; }
 int tile_limit() { return TILE_LIMIT; }
 
 // ---- two-level (P2 -> P1) solve of the displacement block -----------------------------------------------------------
@@ -1568,7 +1570,10 @@ void launch_sweep_csr_f64(hipStream_t st, int64_t n, const int64_t* rowptr, cons
 // The Schur sweep on packed records (FP16 value + 16-bit tile-local column, 4 bytes per entry instead of 8) with the d entries
 // of a 256-row tile's columns staged once in LDS (FP64; the tile of a two-ring pattern sees ~2-3 k distinct columns).
 // Vectors stay FP64 as in k_sweep_csr_mixed; a rounded matrix is still one linear operator.
-static constexpr int SCHUR_TILE = 256;
+// SCHUR_TILE rows per workgroup (64 | 128 | 256, chosen per context from the number of pressure rows: FsiTuning.schur_tile_rows).
+// A sweep is a chain of dependent steps per workgroup - stage the tile's distinct columns, 32 rows per pass, update - and at the
+// per-GPU sizes of a partitioned run (24 k rows: 94 tiles of 256 rows on 256 CUs) its length, not the chip, sets the time.
+template <int SCHUR_TILE>
 __global__ __launch_bounds__(256) void k_sweep_schur_tiled(int64_t n, const int64_t* __restrict__ rowptr,
                                                            const uint32_t* __restrict__ rec, const int64_t* __restrict__ tile_uptr,
                                                            const int32_t* __restrict__ ulist, const double* __restrict__ dinv,
@@ -1614,13 +1619,17 @@ __global__ __launch_bounds__(256) void k_sweep_schur_tiled(int64_t n, const int6
     dout[row] = c1 * di + c2 * ri * dinv[row];
   }
 }
-int schur_tile_rows() { return SCHUR_TILE; }
-void launch_sweep_schur_tiled(hipStream_t st, int64_t n, int max_nu, const int64_t* rowptr, const uint32_t* rec,
+void launch_sweep_schur_tiled(hipStream_t st, int tile_rows, int64_t n, int max_nu, const int64_t* rowptr, const uint32_t* rec,
                               const int64_t* tile_uptr, const int32_t* ulist, const double* dinv, double c1, double c2,
                               const double* din, double* dout, double* x, double* r) {
-  const unsigned tiles = (unsigned)((n + SCHUR_TILE - 1) / SCHUR_TILE);
-  hipLaunchKernelGGL(k_sweep_schur_tiled, dim3(tiles), dim3(256), (size_t)max_nu * sizeof(double), st, n, rowptr, rec, tile_uptr, ulist,
-                     dinv, c1, c2, din, dout, x, r);
+  const unsigned tiles = (unsigned)((n + tile_rows - 1) / tile_rows);
+  const size_t lds = (size_t)max_nu * sizeof(double);
+  if (tile_rows == 64)
+    hipLaunchKernelGGL(k_sweep_schur_tiled<64>, dim3(tiles), dim3(256), lds, st, n, rowptr, rec, tile_uptr, ulist, dinv, c1, c2, din, dout, x, r);
+  else if (tile_rows == 128)
+    hipLaunchKernelGGL(k_sweep_schur_tiled<128>, dim3(tiles), dim3(256), lds, st, n, rowptr, rec, tile_uptr, ulist, dinv, c1, c2, din, dout, x, r);
+  else
+    hipLaunchKernelGGL(k_sweep_schur_tiled<256>, dim3(tiles), dim3(256), lds, st, n, rowptr, rec, tile_uptr, ulist, dinv, c1, c2, din, dout, x, r);
 }
 // One Chebyshev sweep of the solid block in a single launch: t = A d_in (3x3 block-CSR, 16 lanes per node), then on the
 // first three lanes of the group (one component each)  r -= t,  x += d_in,  d_out = c1 d_in + c2 B^-1 r.

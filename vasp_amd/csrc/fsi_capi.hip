@@ -754,7 +754,10 @@ int fsi_create_tuned(const FsiMeshDesc* mesh, const FsiParams* prm, int device, 
     HIPCHK(ctx->dd_chat.alloc(nadj_total));
     HIPCHK(ctx->dd_rowflag.alloc(3 * N2));
     {   // LDS tiles of the node graph: per tile of consecutive nodes the sorted distinct column nodes + local indices
-      const int TN = tile_nodes(), LIM = tile_limit();
+      // nodes per tile: 256 on a full card, 128 when the context is small (more, shorter workgroups; FsiTuning.tile_nodes, 0 = by size)
+      const int TN = (ctx->tune.tile_nodes == 128 || ctx->tune.tile_nodes == 256) ? ctx->tune.tile_nodes : (N2 < 400000 ? 128 : 256);
+      const int LIM = tile_limit();
+      ctx->tile_nodes = TN;
       const int64_t ntiles = (N2 + TN - 1) / TN;
       std::vector<int64_t> uptr(ntiles + 1, 0);
       std::vector<int32_t> ulist;
@@ -951,7 +954,11 @@ int fsi_create_tuned(const FsiMeshDesc* mesh, const FsiParams* prm, int device, 
       FSICHK(upload(ctx, ctx->s_cols, s_cols));
       HIPCHK(ctx->s_vals.alloc(s_cols.size()));
       {   // tiles of the Schur pattern for k_sweep_schur_tiled: per 256 rows the distinct columns and 16-bit local indices
-        const int TR = schur_tile_rows();
+        // rows per tile: 256 on a full card, fewer when the pressure block is small (the per-GPU share of a partitioned run),
+        // so that more, shorter workgroups spread over the chip (FsiTuning.schur_tile_rows; 0 = by size)
+        const int want = ctx->tune.schur_tile_rows;
+        const int TR = (want == 64 || want == 128 || want == 256) ? want : (V < 60000 ? 64 : V < 120000 ? 128 : 256);
+        ctx->schur_tile = TR;
         const int64_t ntiles = (V + TR - 1) / TR;
         std::vector<int64_t> uptr(ntiles + 1, 0);
         std::vector<int32_t> ulist, tmpu;

@@ -185,7 +185,7 @@ struct FsiCtx {
   fsi::DevBuf<double> s_vals;
   fsi::DevBuf<float> s_vals32;                        // FSI_SCHUR_FP32: 1 (default) matrix values in FP16 / FP32, vectors FP64, product fused
   int schur_fp32 = 1;                                 // with the Chebyshev update; 0: FP64 values
-  bool schur_tiled = false; int s_tile_max_nu = 0;   // FP16 records + tile-local columns for the Schur sweep (k_sweep_schur_tiled)
+  bool schur_tiled = false; int s_tile_max_nu = 0; int schur_tile = 256;   // FP16 records + tile-local columns for the Schur sweep (k_sweep_schur_tiled)
   fsi::DevBuf<uint32_t> s_rec; fsi::DevBuf<uint16_t> s_ploc; fsi::DevBuf<int64_t> s_tile_uptr; fsi::DevBuf<int32_t> s_tile_ulist;
   fsi::DevBuf<double> s_dinv;
   fsi::DevBuf<double> dd_db, vv_db;          // component-diagonal node-block copies of A_dd and Avv~ ([pairs][3])
@@ -196,7 +196,7 @@ struct FsiCtx {
   fsi::DevBuf<float> dd_chat, ones32;         // scalar form of the Jacobi-scaled A_dd (one ratio per node pair)
   fsi::DevBuf<uint8_t> dd_rowflag;
   bool dd_is_scalar = false;
-  int tile_max_nu = 0;
+  int tile_max_nu = 0, tile_nodes = 256;
   bool tiled = false;                        // LDS-tiled sweep kernels usable (every tile's neighbour set fits the LDS tile)
   fsi::DevBuf<uint16_t> tile_ploc;           // [pairs] local index of the pair's column node in its tile's list
   fsi::DevBuf<int64_t> tile_uptr;            // [tiles+1]

@@ -216,20 +216,19 @@ void launch_extract_db(hipStream_t st, int64_t N2, int64_t npairs, const int64_t
 void launch_spmv_db(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
                     const double* x, double* y, const uint8_t* rowmask = nullptr);
 void launch_db_rowmask(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const double* db, uint8_t* rowmask);
-void launch_spmv_tiled_f32(hipStream_t st, int nv, int64_t N2, int max_nu, const int64_t* nadj_ptr, const float* vals,
+void launch_spmv_tiled_f32(hipStream_t st, int nv, int tn, int64_t N2, int max_nu, const int64_t* nadj_ptr, const float* vals,
                            const uint16_t* ploc, const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag,
                            const float* x, float* y);
-int tile_nodes();
 int tile_limit();
 void launch_extract_chat(hipStream_t st, int64_t N2, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
                          float* chat, uint8_t* rowflag, int32_t* flags);
-void launch_sweep_tiled_f32(hipStream_t st, int nv, int64_t N2, int max_nu, const int64_t* nadj_ptr, const float* vals,
+void launch_sweep_tiled_f32(hipStream_t st, int nv, int tn, int64_t N2, int max_nu, const int64_t* nadj_ptr, const float* vals,
                             const uint16_t* ploc, const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag,
                             const float* dinv, float c1, float c2, const float* din, float* dout, float* x, float* r);
 void launch_pack_h1(hipStream_t st, int64_t n, const float* v, const uint16_t* loc, uint32_t* rec);
 void launch_pack_h3(hipStream_t st, int64_t n, const float* v, const uint16_t* loc, void* rec);
 void launch_pack_sb(hipStream_t st, int64_t nb, const float* v, const int32_t* col, void* rec);
-void launch_sweep_tiled_h(hipStream_t st, int nv, int64_t N2, int max_nu, const int64_t* nadj_ptr, const void* rec,
+void launch_sweep_tiled_h(hipStream_t st, int nv, int tn, int64_t N2, int max_nu, const int64_t* nadj_ptr, const void* rec,
                           const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag, const float* dinv, float c1,
                           float c2, const float* din, float* dout, float* x, float* r);
 void launch_sweep_sb_h(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const void* rec, const float* binv12, float c1, float c2,
@@ -268,8 +267,7 @@ void launch_spmv_node6(hipStream_t st, int64_t N2, int64_t V, const int64_t* row
 void launch_sweep_csr_mixed(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const float* vals,
                             const int64_t* diagpos, const double* dvals, double c1, double c2, const double* din, double* dout,
                             double* x, double* r);
-int schur_tile_rows();
-void launch_sweep_schur_tiled(hipStream_t st, int64_t n, int max_nu, const int64_t* rowptr, const uint32_t* rec,
+void launch_sweep_schur_tiled(hipStream_t st, int tile_rows, int64_t n, int max_nu, const int64_t* rowptr, const uint32_t* rec,
                               const int64_t* tile_uptr, const int32_t* ulist, const double* dinv, double c1, double c2,
                               const double* din, double* dout, double* x, double* r);
 void launch_sbmg_flags(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals, uint8_t* flag);

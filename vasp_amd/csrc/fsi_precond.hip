@@ -83,10 +83,10 @@ void cheb_db_f32(FsiCtx* ctx, const float* db, const float* dinv, const double* 
       if (timed) (void)hipEventRecord(ctx->db_ev0[ctx->db_samples_pending], st);
       const double rn = 1.0 / (2.0 * sig - rho);
       if (ctx->sweeps_fp16 && db == ctx->vv_db32.p)
-        launch_sweep_tiled_h(st, 3, ctx->N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->vv_rec.p, ctx->tile_uptr.p, ctx->tile_ulist.p, nullptr,
+        launch_sweep_tiled_h(st, 3, ctx->tile_nodes, ctx->N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->vv_rec.p, ctx->tile_uptr.p, ctx->tile_ulist.p, nullptr,
                              dinv, (float)(rn * rho), (float)(2.0 * rn / de), da, db_, fx, fr);
       else
-        launch_sweep_tiled_f32(st, 3, ctx->N2, ctx->tile_max_nu, ctx->nadj_ptr.p, db, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
+        launch_sweep_tiled_f32(st, 3, ctx->tile_nodes, ctx->N2, ctx->tile_max_nu, ctx->nadj_ptr.p, db, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
                                nullptr, dinv, (float)(rn * rho), (float)(2.0 * rn / de), da, db_, fx, fr);
       if (timed) { (void)hipEventRecord(ctx->db_ev1[ctx->db_samples_pending], st); ctx->db_samples_pending += 1; }
       std::swap(da, db_);
@@ -99,7 +99,7 @@ void cheb_db_f32(FsiCtx* ctx, const float* db, const float* dinv, const double* 
     const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->db_ev0[0] && ctx->db_samples_pending < 8;
     if (timed) (void)hipEventRecord(ctx->db_ev0[ctx->db_samples_pending], st);
     if (ctx->tiled)
-      launch_spmv_tiled_f32(st, 3, ctx->N2, ctx->tile_max_nu, ctx->nadj_ptr.p, db, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p, nullptr, fd, ft);
+      launch_spmv_tiled_f32(st, 3, ctx->tile_nodes, ctx->N2, ctx->tile_max_nu, ctx->nadj_ptr.p, db, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p, nullptr, fd, ft);
     else
       launch_spmv_db_f32(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, db, fd, ft);
     if (timed) { (void)hipEventRecord(ctx->db_ev1[ctx->db_samples_pending], st); ctx->db_samples_pending += 1; }
@@ -300,7 +300,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         const bool timed = ctx->sample_budget > 0 && k < 4 && ctx->sch_ev0[0];
         if (timed) (void)hipEventRecord(ctx->sch_ev0[k], st);
         if (tiled16)
-          launch_sweep_schur_tiled(st, V, ctx->s_tile_max_nu, ctx->s_rowptr.p, ctx->s_rec.p, ctx->s_tile_uptr.p, ctx->s_tile_ulist.p,
+          launch_sweep_schur_tiled(st, ctx->schur_tile, V, ctx->s_tile_max_nu, ctx->s_rowptr.p, ctx->s_rec.p, ctx->s_tile_uptr.p, ctx->s_tile_ulist.p,
                                    ctx->s_dinv.p, c1, c2, pa, pb, dp, pr);
         else
         launch_sweep_csr_mixed(st, V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->s_vals32.p, ctx->s_diagpos.p, ctx->s_vals.p, c1,
@@ -368,7 +368,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         const bool timed = ctx->sample_budget > 0 && k_sample >= 0 && k_sample < 4 && ctx->sc_ev0[0];
         if (timed) (void)hipEventRecord(ctx->sc_ev0[k_sample], st);
         if (ctx->tiled)
-          launch_spmv_tiled_f32(st, 1, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_chat.p, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
+          launch_spmv_tiled_f32(st, 1, ctx->tile_nodes, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_chat.p, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
                                 ctx->dd_rowflag.p, fd, ft);
         else
           launch_spmv_sc_f32(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_chat.p, ctx->dd_rowflag.p, fd, ft);
@@ -384,10 +384,10 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         const bool timed = ctx->sample_budget > 0 && k_sample >= 0 && k_sample < 4 && ctx->sc_ev0[0];
         if (timed) (void)hipEventRecord(ctx->sc_ev0[k_sample], st);
         if (ctx->sweeps_fp16)
-          launch_sweep_tiled_h(st, 1, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_rec.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
+          launch_sweep_tiled_h(st, 1, ctx->tile_nodes, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_rec.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
                                ctx->dd_rowflag.p, nullptr, c1, c2, dcur, dnext, fx, fr);
         else
-          launch_sweep_tiled_f32(st, 1, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_chat.p, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
+          launch_sweep_tiled_f32(st, 1, ctx->tile_nodes, N2, ctx->tile_max_nu, ctx->nadj_ptr.p, ctx->dd_chat.p, ctx->tile_ploc.p, ctx->tile_uptr.p, ctx->tile_ulist.p,
                                  ctx->dd_rowflag.p, nullptr, c1, c2, dcur, dnext, fx, fr);
         if (timed) { (void)hipEventRecord(ctx->sc_ev1[k_sample], st); ctx->sc_samples_pending = k_sample + 1; }
         std::swap(dcur, dnext);

@@ -41,6 +41,7 @@ void fsi_tuning_from_env(FsiTuning* t) {
   if (const char* e = getenv("FSI_ASSEMBLY")) t->assembly_atomic = std::string(e) == "atomic";
   if (const char* e = getenv("FSI_ORDER")) t->node_order = (e[0] == 'c' || e[0] == 'C') ? 2 : (e[0] == 'm' || e[0] == 'M') ? 1 : 0;
   if (getenv("FSI_NO_TILES")) t->tiles = 0;
+  I("FSI_SCHUR_TILE", &t->schur_tile_rows); I("FSI_TILE_NODES", &t->tile_nodes);
   if (getenv("FSI_NO_SCALAR_DD")) t->scalar_dd = 0;
   I("FSI_JAC_WAVES", &t->jacobian_waves); I("FSI_JAC_MFMA", &t->jacobian_mfma);
   D("FSI_NEWTON_FORCING", &t->newton_forcing); D("FSI_NEWTON_FORCING_LATE", &t->newton_forcing_late);
