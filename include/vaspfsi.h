@@ -113,8 +113,8 @@ typedef struct FsiTuning {
   int32_t assembly_atomic;     /* 0: bitwise reproducible assembly (per-dof gather, cell colours); 1: unordered atomics            */
   int32_t node_order;          /* 0: Morton curve (default), 1: the mesh's order, 2: multicolour (needed by precond = 1)           */
   int32_t tiles;               /* 1: LDS-tiled sweep kernels                                                                        */
-  int32_t tile_nodes;          /* nodes per workgroup of the tiled displacement / fluid sweeps: 128 | 256; 0: by the number of nodes */
-  int32_t schur_tile_rows;     /* rows per workgroup of the tiled Schur sweep: 64 | 128 | 256; 0: by the number of pressure rows    */
+  int32_t tile_nodes;          /* nodes per workgroup of the tiled displacement / fluid sweeps: 128 | 256; 0 = 256                     */
+  int32_t schur_tile_rows;     /* rows per workgroup of the tiled Schur sweep: 64 | 128 | 256; 0 = 64 (256 in rounds 2-3)               */
   int32_t jacobian_waves;      /* waves per SIMD the refresh kernel's register budget is set for (1 | 2)                           */
   int32_t jacobian_mfma;       /* 1: element contraction of the refresh kernel on v_mfma_f64_16x16x4 (k_jacobian_mfma; measured    */
                                /*    slower in round 4: 103 against 70 ms per refresh at 1.12 M tets)                              */
@@ -129,6 +129,8 @@ typedef struct FsiTuning {
   double gcr_reorth;           /* second Gram-Schmidt pass when |w'| < reorth |w| (0: automatic)                                   */
   /* block preconditioner */
   int32_t prec_streams;        /* 1: two chains of an application side by side on two HIP streams                                  */
+  int32_t experiment;          /* measurement switches of the block factorisation, 0 in production: bit 0       */
+                               /* pressure right-hand side from the fluid predictor only, bit 1 displacement block without velocity   */
   int32_t cheb4;               /* bit 0 / 1 / 2: 4th-kind Chebyshev sweeps in the solid cycle / displacement cycle / Schur solve   */
   int32_t coarse_power;        /* 1: coarse-level Chebyshev intervals from a power iteration (0: Gershgorin bound)                 */
   int32_t solid_mg, dd_mg;     /* two-level (P2 -> P1) cycles of the solid velocity block / the displacement block                 */

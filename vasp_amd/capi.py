@@ -50,7 +50,7 @@ class FsiTuning(C.Structure):
                 ("newton_forcing", C.c_double), ("newton_forcing_late", C.c_double), ("newton_late_factor", C.c_double),
                 ("f32_cycle_floor", C.c_double), ("f32_verdict_skip_rtol", C.c_double), ("orth_floor32", C.c_double),
                 ("orth_floor64", C.c_double), ("gcr_escape", C.c_double), ("gcr_reorth", C.c_double),
-                ("prec_streams", C.c_int32), ("cheb4", C.c_int32), ("coarse_power", C.c_int32), ("solid_mg", C.c_int32),
+                ("prec_streams", C.c_int32), ("experiment", C.c_int32), ("cheb4", C.c_int32), ("coarse_power", C.c_int32), ("solid_mg", C.c_int32),
                 ("dd_mg", C.c_int32), ("mg_keep", C.c_int32), ("solid_block_jacobi", C.c_int32), ("solid_fused", C.c_int32),
                 ("fused_sweeps", C.c_int32), ("scalar_dd", C.c_int32),
                 ("its_solid", C.c_int32), ("its_fluid", C.c_int32), ("its_schur", C.c_int32), ("its_disp", C.c_int32),

@@ -1624,7 +1624,9 @@ void launch_sweep_schur_tiled(hipStream_t st, int tile_rows, int64_t n, int max_
                               const double* din, double* dout, double* x, double* r) {
   const unsigned tiles = (unsigned)((n + tile_rows - 1) / tile_rows);
   const size_t lds = (size_t)max_nu * sizeof(double);
-  if (tile_rows == 64)
+  if (tile_rows == 32)
+    hipLaunchKernelGGL(k_sweep_schur_tiled<32>, dim3(tiles), dim3(256), lds, st, n, rowptr, rec, tile_uptr, ulist, dinv, c1, c2, din, dout, x, r);
+  else if (tile_rows == 64)
     hipLaunchKernelGGL(k_sweep_schur_tiled<64>, dim3(tiles), dim3(256), lds, st, n, rowptr, rec, tile_uptr, ulist, dinv, c1, c2, din, dout, x, r);
   else if (tile_rows == 128)
     hipLaunchKernelGGL(k_sweep_schur_tiled<128>, dim3(tiles), dim3(256), lds, st, n, rowptr, rec, tile_uptr, ulist, dinv, c1, c2, din, dout, x, r);

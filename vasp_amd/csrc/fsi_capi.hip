@@ -754,8 +754,9 @@ int fsi_create_tuned(const FsiMeshDesc* mesh, const FsiParams* prm, int device, 
     HIPCHK(ctx->dd_chat.alloc(nadj_total));
     HIPCHK(ctx->dd_rowflag.alloc(3 * N2));
     {   // LDS tiles of the node graph: per tile of consecutive nodes the sorted distinct column nodes + local indices
-      // nodes per tile: 256 on a full card, 128 when the context is small (more, shorter workgroups; FsiTuning.tile_nodes, 0 = by size)
-      const int TN = (ctx->tune.tile_nodes == 128 || ctx->tune.tile_nodes == 256) ? ctx->tune.tile_nodes : (N2 < 400000 ? 128 : 256);
+      // nodes per tile (FsiTuning.tile_nodes; 0 = 256): 128 makes no difference at 140 k tets (49.7 against 49.9 ms per step) and
+      // costs 1.5 % at 1.12 M tets (round 4 scan, profiles/r04_tile_scan.txt)
+      const int TN = (ctx->tune.tile_nodes == 128 || ctx->tune.tile_nodes == 256) ? ctx->tune.tile_nodes : 256;
       const int LIM = tile_limit();
       ctx->tile_nodes = TN;
       const int64_t ntiles = (N2 + TN - 1) / TN;
@@ -954,10 +955,12 @@ int fsi_create_tuned(const FsiMeshDesc* mesh, const FsiParams* prm, int device, 
       FSICHK(upload(ctx, ctx->s_cols, s_cols));
       HIPCHK(ctx->s_vals.alloc(s_cols.size()));
       {   // tiles of the Schur pattern for k_sweep_schur_tiled: per 256 rows the distinct columns and 16-bit local indices
-        // rows per tile: 256 on a full card, fewer when the pressure block is small (the per-GPU share of a partitioned run),
-        // so that more, shorter workgroups spread over the chip (FsiTuning.schur_tile_rows; 0 = by size)
+        // rows per tile (FsiTuning.schur_tile_rows; 0 = 64).  A sweep is a chain of dependent steps per workgroup (stage the tile's
+        // distinct columns, 32 rows per pass, update) and the data is on die, so shorter chains in more workgroups win: round 4
+        // scan, ms per preconditioner application with 64 / 128 / 256 rows: 1.10 / 1.13 / 1.28 at 140 k tets (24 k rows: 94 tiles
+        // of 256 rows are fewer than the chip has CUs), 3.97 / 4.02 / 3.99 at 1.12 M tets (profiles/r04_tile_scan.txt)
         const int want = ctx->tune.schur_tile_rows;
-        const int TR = (want == 64 || want == 128 || want == 256) ? want : (V < 60000 ? 64 : V < 120000 ? 128 : 256);
+        const int TR = (want == 32 || want == 64 || want == 128 || want == 256) ? want : 64;
         ctx->schur_tile = TR;
         const int64_t ntiles = (V + TR - 1) / TR;
         std::vector<int64_t> uptr(ntiles + 1, 0);

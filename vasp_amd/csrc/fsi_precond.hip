@@ -277,7 +277,8 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   }
   // pressure: S dp = rp - Apv~ vs,  S x = App x - Apv~ D^-1 Avp x
   if (ctx->pv32_ok)
-    launch_pres_rhs32(st, V, ctx->vrank.p, ctx->nadj_ptr.p, ctx->nadj.p, ctx->rowptr_pv.p, ctx->Apv32.p, vs, rp, tp);
+    launch_pres_rhs32(st, V, ctx->vrank.p, ctx->nadj_ptr.p, ctx->nadj.p, ctx->rowptr_pv.p, ctx->Apv32.p,
+                      (ctx->tune.experiment & 1) ? IW + 5 * n3 : vs, rp, tp);      // experiment bit 0: pressure rhs from the FLUID predictor only
   else
     launch_pres_rows(st, V, ctx->rowptr_pp.p, ctx->cols_pp.p, ctx->App.p, nullptr, 0.0, ctx->rowptr_pv.p, ctx->cols_pv.p,
                      ctx->Apv.p, vs, -1.0, rp, 1.0, tp);
@@ -348,8 +349,11 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   if (ctx->adv_is_db) {
     // dd_early: the displacement block sees the solid PREDICTOR instead of the corrected velocity - what it has when its chain
     // runs beside the pressure step instead of after it
+    if (ctx->tune.experiment & 2) launch_copy(st, td, rd, n3);      // experiment bit 1: displacement block without any velocity coupling
+    else {
     launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->adv_db.p, (ctx->dd_early || conc) ? IW + 4 * n3 : dv, w3, ctx->adv_rowmask.p);
     launch_axpby(st, td, 1.0, rd, -1.0, w3, n3);
+    }
   } else {
     launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Adv.p, dv, rd, td);
   }

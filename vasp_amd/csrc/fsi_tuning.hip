@@ -48,7 +48,7 @@ void fsi_tuning_from_env(FsiTuning* t) {
   D("FSI_NEWTON_LATE_FACTOR", &t->newton_late_factor); D("FSI_F32_CYCLE_FLOOR", &t->f32_cycle_floor);
   D("FSI_F32_VERDICT_SKIP", &t->f32_verdict_skip_rtol); D("FSI_ORTH_FLOOR32", &t->orth_floor32); D("FSI_ORTH_FLOOR64", &t->orth_floor64);
   D("FSI_GCR_ESCAPE", &t->gcr_escape); D("FSI_GCR_REORTH", &t->gcr_reorth);
-  I("FSI_PREC_STREAMS", &t->prec_streams); I("FSI_CHEB4", &t->cheb4); I("FSI_COARSE_POWER", &t->coarse_power);
+  I("FSI_PREC_STREAMS", &t->prec_streams); I("FSI_EXPERIMENT", &t->experiment); I("FSI_CHEB4", &t->cheb4); I("FSI_COARSE_POWER", &t->coarse_power);
   I("FSI_SOLID_MG", &t->solid_mg); I("FSI_DD_MG", &t->dd_mg); I("FSI_MG_KEEP", &t->mg_keep); I("FSI_SOLID_BJ", &t->solid_block_jacobi);
   I("FSI_SOLID_FUSED", &t->solid_fused); I("FSI_FUSED_SWEEPS", &t->fused_sweeps);
   I("FSI_CHEB_S", &t->its_solid); I("FSI_CHEB_F", &t->its_fluid); I("FSI_CHEB_P", &t->its_schur); I("FSI_CHEB_D", &t->its_disp);
