@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round 4, final measurements of the committed tree: GPU test-suite, smoke, the default bench line, 140 k tets, then the PMC
+# passes and the kernel trace (tools/gpu_pmc_r4.sh).
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r4final
+mkdir -p $O
+cd $R
+timeout -k 10 1100 python -m pytest tests -m gpu -q -rs > $O/pytest_gpu.log 2>&1
+rc=$?; echo "pytest rc=$rc"; tail -6 $O/pytest_gpu.log
+[ $rc -eq 124 ] && exit 1
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
+t0=$(date +%s)
+timeout -k 10 900 python bench.py > $O/final_bench.json 2> $O/final_bench.err
+rc=$?; t1=$(date +%s); echo "bench.py rc=$rc wall $((t1-t0)) s"
+python tools/show_bench.py $O/final_bench.json | cut -c1-500
+[ $rc -eq 124 ] && exit 1
+timeout -k 10 300 python bench.py --steps 12 --warmup 3 --tets 140000 --no-cpu-baseline --no-fp64-line --profile-host > $O/small_140k_bench.json 2> $O/small_140k_bench.err
+echo "140k rc=$?"; python tools/show_bench.py $O/small_140k_bench.json | cut -c1-400
+bash tools/gpu_pmc_r4.sh

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round 4, eleventh GPU call: Schur sweep count by size.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r4k
+mkdir -p $O
+cd $R
+run() {   # name tets steps warmup env...
+  name=$1; tets=$2; steps=$3; warm=$4; shift 4
+  env "$@" timeout -k 10 400 python bench.py --steps $steps --warmup $warm --tets $tets --no-cpu-baseline --no-fp64-line > $O/$name.json 2> $O/$name.err
+  rc=$?
+  python - <<PY
+import json
+try:
+    d=json.loads([l for l in open("$O/$name.json") if l.startswith("{")][-1])
+    pm=d["phase_ms"]; pc=d["phase_calls"]
+    print("%-26s %8.2f it/s %7.1f ms/step newton %3d krylov %4d precond %.3f ms/app ev %s" % ("$name", d["value"], d["ms_per_step"], d["newton_iterations"], d["krylov_iterations"], pm["precond_ms"]/max(1,pc["precond_calls"]), {k:v for k,v in d["solver_events"].items() if v}))
+except Exception as e:
+    print("$name failed rc=$rc", e)
+PY
+  [ $rc -eq 124 ] && exit 1
+}
+run s140_p30         140000 12 3 A=1
+run s140_p36         140000 12 3 FSI_CHEB_P=36
+run s140_p40         140000 12 3 FSI_CHEB_P=40
+run s140_p40_k150    140000 12 3 FSI_CHEB_P=40 FSI_KAPPA_P=150
+run s350_p30         350000 12 3 A=1
+run s350_p40_k150    350000 12 3 FSI_CHEB_P=40 FSI_KAPPA_P=150
+run m1_p40_k150      1000000 20 5 FSI_CHEB_P=40 FSI_KAPPA_P=150
+run m1_p45_k150      1000000 20 5 FSI_CHEB_P=45 FSI_KAPPA_P=150
+run m1_p50_k200      1000000 20 5 FSI_CHEB_P=50 FSI_KAPPA_P=200
+run m1_p50_k200_100  1000000 100 5 FSI_CHEB_P=50 FSI_KAPPA_P=200
