@@ -465,6 +465,44 @@ __global__ __launch_bounds__(256) void k_spmv_db(int64_t N2, const int64_t* __re
     if (sub == 0) { y[3 * r] = s0; y[3 * r + 1] = s1; y[3 * r + 2] = s2; }
   }
 }
+// y[rows of the listed nodes] -= (db x)[those rows]: the A_dv product of the displacement right-hand side, which has entries in
+// the rows of solid (incl. interface) nodes only - a tenth of the nodes.  Round 3 ran k_spmv_db over ALL nodes (masked rows
+// written as zeros) followed by an axpby over 3 N2 entries: 162 + 22 us per preconditioner application at 1.12 M tets against
+// ~20 us for this kernel.  16 lanes per listed node.
+__global__ __launch_bounds__(256) void k_db_rows_sub(int64_t nl, const int32_t* __restrict__ list, const int64_t* __restrict__ nadj_ptr,
+                                                     const int32_t* __restrict__ nadj, const double* __restrict__ db,
+                                                     const uint8_t* __restrict__ rowmask, const double* __restrict__ x,
+                                                     double* __restrict__ y) {
+  const int sub = threadIdx.x & 15;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t a = grp; a < nl; a += ngrp) {
+    const int64_t r = list[a];
+    if (rowmask && !rowmask[r]) continue;            // uniform over the 16 lanes of the node
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t e = nadj_ptr[r] + sub; e < nadj_ptr[r + 1]; e += 16) {
+      const double* xs = x + 3 * (int64_t)nadj[e];
+      const double* c = db + 3 * e;
+      s0 += c[0] * xs[0]; s1 += c[1] * xs[1]; s2 += c[2] * xs[2];
+    }
+    s0 = group_sum<16>(s0); s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
+    if (sub == 0) { y[3 * r] -= s0; y[3 * r + 1] -= s1; y[3 * r + 2] -= s2; }
+  }
+}
+// flags[0] |= 1 if a node outside the list's set (node_set[r] == 0) has rowmask[r] set
+__global__ void k_mask_outside(int64_t N2, const uint8_t* __restrict__ rowmask, const int32_t* __restrict__ node_set, int32_t* __restrict__ flags) {
+  GS(r, N2) if (rowmask[r] && !node_set[r]) atomicOr(&flags[0], 1);
+}
+void launch_mask_outside(hipStream_t st, int64_t N2, const uint8_t* rowmask, const int32_t* node_set, int32_t* flags) {
+  hipLaunchKernelGGL(k_mask_outside, dim3(gridn(N2)), dim3(256), 0, st, N2, rowmask, node_set, flags);
+}
+void launch_db_rows_sub(hipStream_t st, int64_t nl, const int32_t* list, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
+                        const uint8_t* rowmask, const double* x, double* y) {
+  if (nl <= 0) return;
+  int64_t blocks = (nl + 15) / 16;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_db_rows_sub, dim3((unsigned)blocks), dim3(256), 0, st, nl, list, nadj_ptr, nadj, db, rowmask, x, y);
+}
 // rowmask[r] = 1 iff node r has a non-zero entry in db
 __global__ __launch_bounds__(256) void k_db_rowmask(int64_t N2, const int64_t* __restrict__ nadj_ptr, const double* __restrict__ db,
                                                     uint8_t* __restrict__ rowmask) {
@@ -1436,10 +1474,15 @@ __global__ void k_sbmg_restrict(int64_t nc, const int64_t* __restrict__ chptr, c
                                 const float* __restrict__ chw, const int32_t* __restrict__ snode,
                                 const double* __restrict__ rowscale, const uint8_t* __restrict__ flag,
                                 const uint8_t* __restrict__ cflag, const float* __restrict__ r4, float* __restrict__ rc4) {
-  GS(i, nc) {
+  // 8 lanes per coarse node (round 4; one thread walking its ~20 children through three dependent loads each took 50 us per
+  // application at 1.12 M tets): the children's terms are added in a fixed tree order, so the sum stays reproducible
+  const int sub = threadIdx.x & 7;
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 3;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 3;
+  for (int64_t i = grp; i < nc; i += ngrp) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     if (!cflag[i])
-      for (int64_t k = chptr[i]; k < chptr[i + 1]; ++k) {
+      for (int64_t k = chptr[i] + sub; k < chptr[i + 1]; k += 8) {
         const int32_t a = child[k];
         if (flag[a]) continue;
         const int64_t r = snode[a];
@@ -1447,7 +1490,8 @@ __global__ void k_sbmg_restrict(int64_t nc, const int64_t* __restrict__ chptr, c
         const float4 rv = reinterpret_cast<const float4*>(r4)[a];
         s0 += w * rv.x / (float)rowscale[6 * r + 3]; s1 += w * rv.y / (float)rowscale[6 * r + 4]; s2 += w * rv.z / (float)rowscale[6 * r + 5];
       }
-    reinterpret_cast<float4*>(rc4)[i] = make_float4(s0, s1, s2, 0.f);
+    s0 = group_sum<8>(s0); s1 = group_sum<8>(s1); s2 = group_sum<8>(s2);
+    if (sub == 0) reinterpret_cast<float4*>(rc4)[i] = make_float4(s0, s1, s2, 0.f);
   }
 }
 __global__ void k_sbmg_prolong(int64_t nS, const int32_t* __restrict__ par, const float* __restrict__ pw,
@@ -1482,7 +1526,7 @@ void launch_sbmg_coarse_finish(hipStream_t st, int64_t nc, const int64_t* cptr, 
 void launch_sbmg_restrict(hipStream_t st, int64_t nc, const int64_t* chptr, const int32_t* child, const float* chw,
                           const int32_t* snode, const double* rowscale, const uint8_t* flag, const uint8_t* cflag,
                           const float* r4, float* rc4) {
-  hipLaunchKernelGGL(k_sbmg_restrict, dim3(gridn(nc)), dim3(256), 0, st, nc, chptr, child, chw, snode, rowscale, flag, cflag, r4, rc4);
+  hipLaunchKernelGGL(k_sbmg_restrict, dim3(gridn(8 * nc)), dim3(256), 0, st, nc, chptr, child, chw, snode, rowscale, flag, cflag, r4, rc4);
 }
 void launch_sbmg_prolong(hipStream_t st, int64_t nS, const int32_t* par, const float* pw, const uint8_t* flag, const float* xc4,
                          float* e4) {

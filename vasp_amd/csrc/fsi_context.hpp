@@ -190,7 +190,7 @@ struct FsiCtx {
   fsi::DevBuf<double> s_dinv;
   fsi::DevBuf<double> dd_db, vv_db;          // component-diagonal node-block copies of A_dd and Avv~ ([pairs][3])
   fsi::DevBuf<double> adv_db;
-  bool dd_is_db = false, adv_is_db = false;
+  bool dd_is_db = false, adv_is_db = false, adv_solid_only = false;      // (A_dv has entries in solid rows only: checked at every refresh)
   fsi::DevBuf<float> dd_db32, vv_db32, dd_dinv32, vvf_dinv32;   // FP32 copies for the Chebyshev sweeps
   int sweeps_fp32 = 1;
   fsi::DevBuf<float> dd_chat, ones32;         // scalar form of the Jacobi-scaled A_dd (one ratio per node pair)

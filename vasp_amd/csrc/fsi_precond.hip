@@ -349,11 +349,17 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   if (ctx->adv_is_db) {
     // dd_early: the displacement block sees the solid PREDICTOR instead of the corrected velocity - what it has when its chain
     // runs beside the pressure step instead of after it
-    if (ctx->tune.experiment & 2) launch_copy(st, td, rd, n3);      // experiment bit 1: displacement block without any velocity coupling
+    // r_d - A_dv dv in place in r_d (nothing else reads it after the split): A_dv has entries in the rows of solid nodes only
+    // (adv_solid_only: verified at every refresh)
+    const double* vsrc = (ctx->dd_early || conc) ? IW + 4 * n3 : dv;
+    if (ctx->tune.experiment & 2) {}      // (experiment bit 1: displacement block without any velocity coupling)
+    else if (ctx->adv_solid_only)
+      launch_db_rows_sub(st, ctx->nS, ctx->snode.p, ctx->nadj_ptr.p, ctx->nadj.p, ctx->adv_db.p, ctx->adv_rowmask.p, vsrc, rd);
     else {
-    launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->adv_db.p, (ctx->dd_early || conc) ? IW + 4 * n3 : dv, w3, ctx->adv_rowmask.p);
-    launch_axpby(st, td, 1.0, rd, -1.0, w3, n3);
+      launch_spmv_db(st, N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->adv_db.p, vsrc, w3, ctx->adv_rowmask.p);
+      launch_axpby(st, rd, 1.0, rd, -1.0, w3, n3);
     }
+    td = rd;
   } else {
     launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Adv.p, dv, rd, td);
   }
@@ -594,6 +600,10 @@ int refresh_preconditioner(FsiCtx* ctx) {
       launch_diag_inverse(st, 3 * ctx->N2, ctx->diagpos3.p, ctx->Mvv.vals.p, ctx->vv_dinv.p);
       if (!ctx->adv_rowmask.p) HIPCHK(ctx->adv_rowmask.alloc(ctx->N2));
       launch_db_rowmask(st, ctx->N2, ctx->nadj_ptr.p, ctx->adv_db.p, ctx->adv_rowmask.p);     // A_dv has no entries in fluid rows
+      HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
+      launch_mask_outside(st, ctx->N2, ctx->adv_rowmask.p, ctx->node_solid.p, ctx->iflags.p);      // ... checked, not assumed
+      HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
+      ctx->adv_solid_only = flags[0] == 0;
       HIPCHK(hipMemsetAsync(ctx->iflags.p, 0, 4 * sizeof(int32_t), st));
       launch_extract_chat(st, ctx->N2, ctx->nadj_ptr.p, ctx->nadj.p, ctx->dd_db.p, ctx->dd_chat.p, ctx->dd_rowflag.p, ctx->iflags.p);
       HIPCHK(hipMemcpy(flags, ctx->iflags.p, sizeof flags, hipMemcpyDeviceToHost));
