@@ -552,6 +552,34 @@ __global__ void k_pad_to_f32(int64_t nn, const double* __restrict__ a, const flo
 __global__ void k_unpad_from_f32(int64_t nn, const float* __restrict__ a, double* __restrict__ b) {
   GS(t, 3 * nn) b[t] = (double)a[4 * (t / 3) + t % 3];
 }
+// pad_to_f32 + cheb_init_f32 in one launch: rhs = a (3 doubles per node) [* scale4], x = 0, r = rhs, d = rhs inv_theta dinv4
+__global__ void k_pad_init_f32(int64_t nn, const double* __restrict__ a, const float* __restrict__ scale4, const float* __restrict__ dinv4,
+                               float inv_theta, float* __restrict__ x, float* __restrict__ r, float* __restrict__ d) {
+  GS(t, 4 * nn) {
+    const int64_t nd = t >> 2;
+    const int c = (int)(t & 3);
+    const float ri = c < 3 ? (float)a[3 * nd + c] * (scale4 ? scale4[t] : 1.f) : 0.f;
+    x[t] = 0.f; r[t] = ri; d[t] = ri * inv_theta * dinv4[t];
+  }
+}
+// merge with the displacement part taken straight from the sweeps' float4 result (unpad_from_f32 + merge in one launch)
+__global__ void k_merge_f32d(int64_t N2, int64_t V, const float* __restrict__ xd4, const double* __restrict__ zv,
+                             const double* __restrict__ zp, double* __restrict__ z) {
+  GS(t, 3 * N2) {
+    const int64_t nd = t / 3;
+    const int i = (int)(t % 3);
+    z[6 * nd + i] = (double)xd4[4 * nd + i];
+    z[6 * nd + 3 + i] = zv[t];
+  }
+  GS(q, V) z[6 * N2 + q] = zp[q];
+}
+void launch_pad_init_f32(hipStream_t st, int64_t nn, const double* a, const float* scale4, const float* dinv4, float inv_theta,
+                         float* x, float* r, float* d) {
+  hipLaunchKernelGGL(k_pad_init_f32, dim3(gridn(4 * nn)), dim3(256), 0, st, nn, a, scale4, dinv4, inv_theta, x, r, d);
+}
+void launch_merge_f32d(hipStream_t st, int64_t N2, int64_t V, const float* xd4, const double* zv, const double* zp, double* z) {
+  hipLaunchKernelGGL(k_merge_f32d, dim3(gridn(3 * N2)), dim3(256), 0, st, N2, V, xd4, zv, zp, z);
+}
 // dinv4[4 nd + c] = mask / A[diagpos[3 nd + c]], pad 0  (mask may be null; one4: write 1 instead of the inverse diagonal)
 __global__ void k_dinv_f32(int64_t nn, const double* __restrict__ mask, const int64_t* __restrict__ diagpos,
                            const double* __restrict__ A, float* __restrict__ dinv4) {

@@ -213,6 +213,9 @@ void launch_cheb_step(hipStream_t st, int64_t n, const double* mask, const doubl
                       const double* A, double c1, double c2, double* x, double* r, double* d);
 void launch_extract_db(hipStream_t st, int64_t N2, int64_t npairs, const int64_t* nadj_ptr, const int64_t* rowptr3,
                        const double* vals, double* db, int32_t* flags, int check);
+void launch_pad_init_f32(hipStream_t st, int64_t nn, const double* a, const float* scale4, const float* dinv4, float inv_theta,
+                         float* x, float* r, float* d);
+void launch_merge_f32d(hipStream_t st, int64_t N2, int64_t V, const float* xd4, const double* zv, const double* zp, double* z);
 void launch_mask_outside(hipStream_t st, int64_t N2, const uint8_t* rowmask, const int32_t* node_set, int32_t* flags);
 void launch_db_rows_sub(hipStream_t st, int64_t nl, const int32_t* list, const int64_t* nadj_ptr, const int32_t* nadj, const double* db,
                         const uint8_t* rowmask, const double* x, double* y);

@@ -72,10 +72,10 @@ void cheb_db_f32(FsiCtx* ctx, const float* db, const float* dinv, const double* 
   if (!st) st = ctx->stream;
   float* F = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(W) + 15) & ~uintptr_t(15));   // float4 loads
   float *fr = F, *fd = F + n, *ft = F + 2 * n, *fx = F + 3 * n, *frhs = F + 4 * n;
-  launch_pad_to_f32(st, ctx->N2, rhs, nullptr, frhs);
   const double lmin = lmax / kappa, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
   double rho = 1.0 / sig;
-  launch_cheb_init_f32(st, n, frhs, dinv, (float)(1.0 / th), fx, fr, fd);
+  (void)frhs;
+  launch_pad_init_f32(st, ctx->N2, rhs, nullptr, dinv, (float)(1.0 / th), fx, fr, fd);      // pad + initialise in one launch
   if (ctx->tiled && ctx->fused_sweeps) {
     float *da = fd, *db_ = ft;                   // d is ping-ponged; the product stays in registers
     for (int k = 0; k < its; ++k) {
@@ -363,13 +363,14 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   } else {
     launch_residual_csr(st, n3, ctx->rowptr3.p, ctx->cols3.p, ctx->Adv.p, dv, rd, td);
   }
+  const float* dd_f32 = nullptr;
   if (ctx->cheb_its_d > 0) {
     if (ctx->dd_is_scalar && ctx->sweeps_fp32) {
       // Jacobi-scaled system  (D^-1 A_dd) dd = D^-1 td  with the one-number-per-node-pair operator
       const int64_t n = 4 * N2;
       float* F = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(IW) + 15) & ~uintptr_t(15));   // float4 loads
       float *fr = F, *fd = F + n, *ft = F + 2 * n, *fx = F + 3 * n, *frhs = F + 4 * n;
-      launch_pad_to_f32(st, N2, td, ctx->dd_dinv32.p, frhs);
+      (void)frhs;
       const double lmax = ctx->lmax_d, lmin = lmax / ctx->cheb_kappa_d, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
       double rho = 1.0 / sig;
       const bool fused = ctx->tiled && ctx->fused_sweeps;
@@ -409,7 +410,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         const bool d4 = (ctx->cheb4 & 2) != 0;                 // FSI_CHEB4 bit 1: 4th-kind smoothing sweeps (see the solid block)
         const double dinit = d4 ? 4.0 / (3.0 * lmax) : 1.0 / sth;
         auto d4c = [&](int i, float* c1, float* c2) { *c1 = (float)((2.0 * i - 1.0) / (2.0 * i + 3.0)); *c2 = (float)((8.0 * i + 4.0) / ((2.0 * i + 3.0) * lmax)); };
-        launch_cheb_init_f32(st, n, frhs, ctx->ones32.p, (float)dinit, fx, fr, fd);
+        launch_pad_init_f32(st, N2, td, ctx->dd_dinv32.p, ctx->ones32.p, (float)dinit, fx, fr, fd);      // Jacobi scaling + initialise
         for (int k = 0; k < ctx->mg_pre; ++k) {
           if (d4) { float c1, c2; d4c(k + 1, &c1, &c2); fine_sweep(c1, c2, k); continue; }
           const double rn = 1.0 / (2.0 * ssig - srho);
@@ -448,14 +449,15 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         }
         ctx->inner_its[2] += ctx->mg_pre + 1 + ctx->mg_post - ctx->cheb_its_d;     // counted below as cheb_its_d
       } else {
-        launch_cheb_init_f32(st, n, frhs, ctx->ones32.p, (float)(1.0 / th), fx, fr, fd);
+        launch_pad_init_f32(st, N2, td, ctx->dd_dinv32.p, ctx->ones32.p, (float)(1.0 / th), fx, fr, fd);
         for (int k = 0; k < ctx->cheb_its_d; ++k) {
           const double rn = 1.0 / (2.0 * sig - rho);
           fine_sweep((float)(rn * rho), (float)(2.0 * rn / de), k);
           rho = rn;
         }
       }
-      launch_unpad_from_f32(st, N2, fx, dd);
+      dd_f32 = fx;                                  // the merge below takes the displacement part straight from the sweeps' result
+      if (ctx->debug_prec_apply > 0) launch_unpad_from_f32(st, N2, fx, dd);
     } else if (ctx->dd_is_db && ctx->sweeps_fp32)
       cheb_db_f32(ctx, ctx->dd_db32.p, ctx->dd_dinv32.p, td, dd, IW, ctx->cheb_its_d, ctx->lmax_d, ctx->cheb_kappa_d);
     else if (ctx->dd_is_db)
@@ -467,7 +469,8 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
     ctx->inner_its[2] += ctx->cheb_its_d;
   }
   if (conc) HIPCHK(hipStreamWaitEvent(sA, ctx->ev_b, 0));
-  launch_merge(st, N2, V, dd, dv, dp, z);
+  if (dd_f32) launch_merge_f32d(st, N2, V, dd_f32, dv, dp, z);
+  else launch_merge(st, N2, V, dd, dv, dp, z);
   if (ctx->debug_prec_apply > 0) {                 // FSI_DEBUG_PRECOND=2: non-finite entries of the parts, first applications only
     ctx->debug_prec_apply -= 1;
     auto bad = [&](const double* p, int64_t n) { std::vector<double> h(n); (void)hipMemcpy(h.data(), p, n * sizeof(double), hipMemcpyDeviceToHost);
