@@ -16,4 +16,6 @@ python tools/show_bench.py $O/final_bench.json | cut -c1-500
 [ $rc -eq 124 ] && exit 1
 timeout -k 10 300 python bench.py --steps 12 --warmup 3 --tets 140000 --no-cpu-baseline --no-fp64-line --profile-host > $O/small_140k_bench.json 2> $O/small_140k_bench.err
 echo "140k rc=$?"; python tools/show_bench.py $O/small_140k_bench.json | cut -c1-400
+VASPFSI_DIST_BACKEND=gloo VASPFSI_ONE_GPU=1 timeout -k 10 400 python bench.py --gpus 2 --steps 3 --warmup 1 --tets 100000 --no-cpu-baseline > $O/launch2_driver.json 2> $O/launch2_driver.err
+echo "bench --gpus 2 (driver / worker, gloo, one card) rc=$?"; python tools/show_bench.py $O/launch2_driver.json | cut -c1-300
 bash tools/gpu_pmc_r4.sh
