@@ -245,6 +245,7 @@ def main():
             sc_bytes -= tm["db_pairs"] * 2.0
             dbf_bytes -= tm["db_pairs"] * 6.0
         qb = tm["q_elem_bytes"]
+        skip_rtol = float((hb.hb if hasattr(hb, "hb") else hb).tuning()["f32_verdict_skip_rtol"])
         # orthogonalisation: every launch of k_gcr_dots / k_gcr_axpy streams m columns of Q (ld * qb bytes each) plus
         # w (read, and written by the update) and r; the exact column count is kept by the library
         q_launches = max(1, tm["ortho_q_launches"])
@@ -346,7 +347,7 @@ def main():
                        "storage_precisions": ("state, residual, Jacobian and every accumulation FP64; Krylov basis "
                                               f"FP{8 * qb}" + (" with an FP64 window of 32 columns" if qb == 4 else "")
                                               + f"; {op32} of {int(tm['spmv_calls'])} outer products on an FP32 copy of the Jacobian values, "
-                                              + ("every linear answer asked for below 1e-3 judged on the FP64 residual of the FP64 matrix, looser ones "
+                                              + (f"every linear answer asked for below {skip_rtol:g} judged on the FP64 residual of the FP64 matrix, looser ones "
                                                  "too unless the last verified cycle had recurrence and truth within 1 % of the request "
                                                  f"({int(tm['verdicts_skipped'])} of {int(tm['krylov_solves'])} solves) - Newton's FP64 residual follows; " if qb == 4 else
                                                  "iterations on the FP64 matrix, answers re-judged on b - A x when asked below 1e-8 or when the "

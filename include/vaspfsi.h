@@ -254,6 +254,9 @@ int fsi_set_state(FsiCtx* ctx, int which, const double* in);
 int fsi_get_values(FsiCtx* ctx, int which, int64_t n, const int64_t* dofs, double* out);
 int64_t fsi_num_dofs(const FsiCtx* ctx);
 int64_t fsi_matrix_nnz(const FsiCtx* ctx);
+/* Free and total bytes of the context's device as the HIP runtime of the library sees them (hipMemGetInfo): how much of the
+ * 288 GB one context of a given mesh takes, asked without a second runtime in the process. */
+int fsi_device_memory(FsiCtx* ctx, int64_t* free_bytes, int64_t* total_bytes);
 /* Copies the assembled matrix out in user-layout row/column numbering (CSR, rows sorted).  rowptr [ndof+1],
  * cols/vals [nnz].  Values are the un-equilibrated Jacobian after ident_zeros and bc.apply. */
 int fsi_get_matrix(FsiCtx* ctx, int64_t* rowptr, int64_t* cols, double* vals);

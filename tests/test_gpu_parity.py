@@ -476,7 +476,6 @@ def test_properties_at_config3_size_with_the_robin_wall(tmp_path):
     fall under the problem's tolerances with the storage the policy picks.  The 288 GB of one MI355X hold it: the HBM in use
     is printed."""
     import json
-    import torch
     from vasp_amd.capi import HipBackend
     from vasp_amd.mesh import FsiMesh
     from vasp_amd.meshgen import generate
@@ -489,7 +488,7 @@ def test_properties_at_config3_size_with_the_robin_wall(tmp_path):
     mesh = ns["mesh"]
     assert mesh.num_cells > 3_000_000 and len(desc["robin_facets"]) > 0
     hb = HipBackend(desc)
-    free_b, total_b = torch.cuda.mem_get_info()
+    free_b, total_b = hb.device_memory()
     print(f"{mesh.num_cells} tets, {hb.ndof} dofs, matrix entries {int(hb.lib.fsi_matrix_nnz(hb.ctx))}: HBM in use {(total_b - free_b) / 2**30:.0f} GiB "
           f"of {total_b / 2**30:.0f}, Krylov capacity {hb.timers()['krylov_cap']}")
     nbc = len(desc["bc_dofs"])

@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = (
     "fsi_create", "fsi_destroy", "fsi_last_error", "fsi_set_dirichlet", "fsi_set_dirichlet_values",
     "fsi_set_pressure_facets", "fsi_set_interface_pressure", "fsi_set_robin_facets", "fsi_solver_setup",
     "fsi_assemble_residual", "fsi_assemble_jacobian", "fsi_solve", "fsi_newton_solve", "fsi_shift",
-    "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_get_matrix", "fsi_spmv",
+    "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_device_memory", "fsi_get_matrix", "fsi_spmv",
     "fsi_get_timers", "fsi_get_values", "fsi_stress_strain", "fsi_wall_shear_stress", "fsi_calibration_streams", "fsi_set_newton_forcing", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
     "fsi_rccl_unique_id", "fsi_set_rccl", "fsi_create_tuned", "fsi_get_tuning", "fsi_tuning_defaults", "fsi_tuning_from_env",
 )
@@ -150,6 +150,7 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_num_dofs.restype = i64
     lib.fsi_matrix_nnz.argtypes = [vp]
     lib.fsi_matrix_nnz.restype = i64
+    lib.fsi_device_memory.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     lib.fsi_get_matrix.argtypes = [vp, vp, vp, vp]
     lib.fsi_spmv.argtypes = [vp, vp, vp]
     lib.fsi_get_timers.argtypes = [vp, C.POINTER(FsiTimers), C.c_int]
@@ -360,6 +361,12 @@ class HipBackend:
                                        self.lin_max_it if lin_max_it is None else lin_max_it,
                                        self.lin_solver if lin_solver is None else lin_solver, C.byref(it), C.byref(rr)))
         return it.value, rr.value
+
+    def device_memory(self):
+        """(free, total) bytes of the context's device, from the library's own HIP runtime."""
+        f, t = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.fsi_device_memory(self.ctx, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def matrix(self):
         """The assembled Jacobian (after ident_zeros and bc.apply) as scipy CSR in the user dof layout."""

@@ -146,6 +146,16 @@ const char* fsi_last_error(const FsiCtx* ctx) { return ctx ? ctx->err.c_str() : 
 int64_t fsi_num_dofs(const FsiCtx* ctx) { return ctx ? ctx->ndof : 0; }
 int64_t fsi_matrix_nnz(const FsiCtx* ctx) { return ctx ? ctx->nnz : 0; }
 
+int fsi_device_memory(FsiCtx* ctx, int64_t* free_bytes, int64_t* total_bytes) {
+  if (!ctx || !free_bytes || !total_bytes) return FSI_ERR_INVALID;
+  size_t f = 0, t = 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemGetInfo(&f, &t));
+  *free_bytes = (int64_t)f;
+  *total_bytes = (int64_t)t;
+  return FSI_OK;
+}
+
 int fsi_destroy(FsiCtx* ctx) {
   if (!ctx) return FSI_OK;
   (void)hipSetDevice(ctx->device);
