@@ -263,21 +263,21 @@ def main():
             ("k_sweep_tiled_h<1>" if fp16 else "k_sweep_tiled_f32<1>" if fused else "k_spmv_tiled_f32<1>" if tiled else "k_spmv_sc_f32")
             + f" (displacement block sweeps: one {'FP16' if fp16 else 'FP32'} ratio per node pair"
             + (", neighbour vector entries staged in LDS" if tiled else "") + (", fused with the Chebyshev update" if fused else "")
-            + "; avg from sampled HIP events)":
+            + "; avg from HIP-event pairs around single launches of the first 16 applications, which run as one chain)":
                 (sc_avg * sc_launches, int(sc_launches), sc_bytes),
             ("k_sweep_tiled_h<3>" if fp16 else "k_sweep_tiled_f32<3>" if fused else "k_spmv_tiled_f32<3>" if tiled else "k_spmv_db_f32")
             + f" (fluid velocity block sweeps, {'FP16' if fp16 else 'FP32'} component-diagonal node blocks" + (", fused with the Chebyshev update" if fused else "")
-            + "; avg from sampled HIP events)":
+            + "; avg from HIP-event pairs around single launches of the first 16 applications, which run as one chain)":
                 (db_avg * db_launches, int(db_launches), dbf_bytes),
-            ((("k_sweep_sb_h (solid velocity block, fine level: 3x3 block-CSR with FP16 values in 24-byte records, product fused with the Chebyshev update; avg from sampled HIP events)"
-               if fp16 else "k_sweep_sb_b3<0> (solid velocity block, fine level: FP32 3x3 block-CSR product fused with the Chebyshev update; avg from sampled HIP events)")
-              if solid_fused else "k_spmv_sb (solid velocity block, FP32 3x3 block-CSR, Chebyshev sweeps; avg from sampled HIP events)")
-             if solid_fp32 else "k_spmv<1> (solid velocity block, CSR f64, Chebyshev sweeps; avg from sampled HIP events)"):
+            ((("k_sweep_sb_h (solid velocity block, fine level: 3x3 block-CSR with FP16 values in 24-byte records, product fused with the Chebyshev update; avg from HIP-event pairs around single launches of the first 16 applications, which run as one chain)"
+               if fp16 else "k_sweep_sb_b3<0> (solid velocity block, fine level: FP32 3x3 block-CSR product fused with the Chebyshev update; avg from HIP-event pairs around single launches of the first 16 applications, which run as one chain)")
+              if solid_fused else "k_spmv_sb (solid velocity block, FP32 3x3 block-CSR, Chebyshev sweeps; avg from HIP-event pairs around single launches of the first 16 applications, which run as one chain)")
+             if solid_fp32 else "k_spmv<1> (solid velocity block, CSR f64, Chebyshev sweeps; avg from HIP-event pairs around single launches of the first 16 applications, which run as one chain)"):
                 (ss_avg * sweeps, int(sweeps),
                  (tm["solid_nnz"] / 9 * (24.0 if fp16 and solid_fused else 40.0) + tm["solid_rows"] * 8.0 + (tm["solid_rows"] / 3 + 1) * 8.0
                   + (tm["solid_rows"] / 3 * (5 * 16.0 + 48.0) if solid_fused else 0.0)) if solid_fp32
                  else (tm["solid_nnz"] * 12.0 + tm["solid_rows"] * 16.0 + (tm["solid_rows"] + 1) * 8.0)),
-            "Schur-complement sweep (explicit two-ring pressure matrix: product + Chebyshev update; avg from sampled HIP events)":
+            "Schur-complement sweep (explicit two-ring pressure matrix: product + Chebyshev update; avg from HIP-event pairs around single launches of the first 16 applications, which run as one chain)":
                 (sch_avg * tm["inner_schur_iters"], int(tm["inner_schur_iters"]),
                  tm["schur_nnz"] * (tm["schur_elem_bytes"] + 4.0) + tm["schur_rows"] * 8.0 * 5),
             (f"k_spmv_node6 (monolithic Jacobian, one i32 column per six entries, {op32} of {int(tm['spmv_calls'])} products on the FP32 "

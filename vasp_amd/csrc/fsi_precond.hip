@@ -135,7 +135,9 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   const bool conc = ctx->prec_streams && ctx->stream2 && ctx->solid_fp32 && ctx->solid_block_jacobi && ctx->solid_fused && ctx->sbmg_ready &&
                     ctx->sweeps_fp32 && ctx->tiled && ctx->fused_sweeps && ctx->cheb_its_p > 0 && ctx->schur_fp32 == 1 && ctx->s_vals32.p &&
                     ctx->pv32_ok && ctx->adv_is_db && ctx->cheb_its_d > 0 && ctx->dd_is_scalar && 4 * V <= n3 && ctx->debug_prec_apply == 0;
-  hipStream_t sA = ctx->stream, sB = conc ? ctx->stream2 : ctx->stream;
+  // (the applications whose sweep launches are timed by event pairs issue both chains on the solver stream - the same arithmetic in
+  // the same order per chain, and a pair brackets its kernel alone)
+  hipStream_t sA = ctx->stream, sB = (conc && ctx->sample_budget <= 0) ? ctx->stream2 : ctx->stream;
   launch_split(st, N2, V, r, rd, rv, rp);
   if (conc) { HIPCHK(hipEventRecord(ctx->ev_split, sA)); HIPCHK(hipStreamWaitEvent(sB, ctx->ev_split, 0)); }
   // velocity predictor: block Gauss-Seidel solid (elasticity-dominated, many cheap sweeps) -> fluid interior (mass-dominated)
