@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round 4, sixteenth GPU call: the per-GPU size of an 8-rank run (140 k tets) - kept Krylov directions and coarse-level sweep counts.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r4p
+mkdir -p $O
+cd $R
+run() {   # name tets steps warmup env...
+  name=$1; tets=$2; steps=$3; warm=$4; shift 4
+  env "$@" timeout -k 10 400 python bench.py --steps $steps --warmup $warm --tets $tets --no-cpu-baseline --no-fp64-line > $O/$name.json 2> $O/$name.err
+  rc=$?
+  python - <<PY
+import json
+try:
+    d=json.loads([l for l in open("$O/$name.json") if l.startswith("{")][-1])
+    pm=d["phase_ms"]; pc=d["phase_calls"]; k=max(1,pc["precond_calls"])
+    print("%-22s %7.2f it/s %6.1f ms/step newton %3d krylov %4d precond %.3f ortho %.3f spmv %.3f ms/it ev %s" % ("$name", d["value"], d["ms_per_step"], d["newton_iterations"], d["krylov_iterations"], pm["precond_ms"]/k, pm["ortho_ms"]/k, pm["spmv_ms"]/k, {k:v for k,v in d["solver_events"].items() if v}))
+except Exception as e:
+    print("$name failed rc=$rc", e)
+PY
+  [ $rc -eq 124 ] && exit 1
+}
+run base        140000 20 5 A=1
+run cap200      140000 20 5 FSI_KRYLOV_CAP=200
+run cap300      140000 20 5 FSI_KRYLOV_CAP=300
+run cap400      140000 20 5 FSI_KRYLOV_CAP=400
+run scits60     140000 20 5 FSI_SBMG_CITS=60
+run scits60k2   140000 20 5 FSI_SBMG_CITS=60 FSI_SBMG_CKAPPA=2000
+run scits40k1   140000 20 5 FSI_SBMG_CITS=40 FSI_SBMG_CKAPPA=1000
+run spre12      140000 20 5 FSI_SBMG_PRE=12 FSI_SBMG_POST=12
+run mgc16       140000 20 5 FSI_MG_CITS=16
+run schur20     140000 20 5 FSI_CHEB_P=20
