@@ -260,6 +260,11 @@ int fsi_device_memory(FsiCtx* ctx, int64_t* free_bytes, int64_t* total_bytes);
 /* Copies the assembled matrix out in user-layout row/column numbering (CSR, rows sorted).  rowptr [ndof+1],
  * cols/vals [nnz].  Values are the un-equilibrated Jacobian after ident_zeros and bc.apply. */
 int fsi_get_matrix(FsiCtx* ctx, int64_t* rowptr, int64_t* cols, double* vals);
+/* z = M^-1 r: one application of the active preconditioner (precond 0: the field-split block preconditioner with its fixed
+ * sweep counts - a fixed linear operator; 1: ILU(0)) to a residual in the user layout, as fsi_solve's Krylov method applies
+ * it - the PCApply of a PETSc binding, and what the tests check linearity and the quality of the approximation on.  Single
+ * contexts only. */
+int fsi_apply_preconditioner(FsiCtx* ctx, const double* r, double* z);
 /* y = A x with the device SpMV (user layout in/out). */
 int fsi_spmv(FsiCtx* ctx, const double* x, double* y);
 

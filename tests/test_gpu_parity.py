@@ -703,6 +703,55 @@ def test_two_level_displacement_solve_is_a_preconditioner_only(stenosis_case, mo
     assert its1 <= 1.25 * its0
 
 
+def test_block_preconditioner_is_a_fixed_linear_operator_close_to_the_inverse(stenosis_case):
+    """fsi_apply_preconditioner: one application of the field-split block preconditioner as the Krylov method applies it.  Fixed
+    sweep counts make it a LINEAR operator (what a flexible method would not need, GCR with recycled directions does: the kept
+    pairs q = A M^-1 ... stay pairs only if M^-1 is the same map every time) - to the rounding of its FP32 / FP16 sweeps; and it
+    approximates the inverse: the spectrum of A M^-1 sampled by an Arnoldi process sits around one, the same vector comes back
+    from two calls bit for bit, and an unassembled context refuses."""
+    from vasp_amd.capi import HipBackend
+    ns, desc, bc_values, pressure, hook = stenosis_case
+    hb = HipBackend(desc)
+    with pytest.raises(RuntimeError):
+        hb.apply_preconditioner(np.zeros(hb.ndof))                   # no Jacobian yet
+    g, P = boundary_data(stenosis_case, 0.01)
+    hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+    hb.newton_solve(counter=0, first_step_num=0, atol=1e-6, rtol=1e-6, max_it=50, lmbda=1.0, recompute=20, recompute_tstep=20)
+    hb.shift()
+    g, P = boundary_data(stenosis_case, 0.02)
+    hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+    hb.assemble_jacobian(); hb.assemble_residual()
+    b = hb.get_state("b")
+    rng = np.random.default_rng(3)
+    bc = np.zeros(hb.ndof, bool); bc[np.asarray(desc["bc_dofs"])] = True
+    x = np.where(bc, 0.0, rng.standard_normal(hb.ndof)) * np.abs(b).max()
+    y = np.where(bc, 0.0, rng.standard_normal(hb.ndof)) * np.abs(b).max()
+    mx, my, mb = hb.apply_preconditioner(x), hb.apply_preconditioner(y), hb.apply_preconditioner(b)
+    assert np.array_equal(mx, hb.apply_preconditioner(x))            # the same map, bit for bit
+    mxy = hb.apply_preconditioner(2.0 * x - 3.0 * y + b)
+    lin = 2.0 * mx - 3.0 * my + mb
+    mesh = ns["mesh"]
+    for name, u, v in zip("dvp", mesh.split(mxy), mesh.split(lin)):
+        assert np.linalg.norm(u - v) <= 2e-3 * np.linalg.norm(v), (name, np.linalg.norm(u - v) / np.linalg.norm(v))
+    # Arnoldi on A M^-1 from the right-hand side: Ritz values inside (0, 2) - no outlier a Chebyshev interval missed, no sign change
+    q = [b / np.linalg.norm(b)]
+    K = 12
+    H = np.zeros((K + 1, K))
+    for k in range(K):
+        w = hb.spmv(hb.apply_preconditioner(q[k]))
+        for _ in range(2):
+            for j in range(k + 1):
+                c = q[j] @ w
+                H[j, k] += c
+                w -= c * q[j]
+        H[k + 1, k] = np.linalg.norm(w)
+        q.append(w / H[k + 1, k])
+    ritz = np.linalg.eigvals(H[:K, :K])
+    print("Ritz values of A M^-1:", np.sort_complex(ritz))
+    assert ritz.real.min() > 0.0 and np.abs(ritz).max() < 2.0, ritz
+    hb.close()
+
+
 def test_avf_two_mooney_rivlin_regions_match_oracle(tmp_path):
     """BASELINE config 4's problem file on the HIP path [REF src/vasp/simulations/avf.py:55-84,189-215]: two MooneyRivlin
     regions, Robin condition on both outer walls, the pressure term on both dS(fsi_id[k]).  Residual and Jacobian against

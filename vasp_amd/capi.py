@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = (
     "fsi_create", "fsi_destroy", "fsi_last_error", "fsi_set_dirichlet", "fsi_set_dirichlet_values",
     "fsi_set_pressure_facets", "fsi_set_interface_pressure", "fsi_set_robin_facets", "fsi_solver_setup",
     "fsi_assemble_residual", "fsi_assemble_jacobian", "fsi_solve", "fsi_newton_solve", "fsi_shift",
-    "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_device_memory", "fsi_get_matrix", "fsi_spmv",
+    "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_device_memory", "fsi_apply_preconditioner", "fsi_get_matrix", "fsi_spmv",
     "fsi_get_timers", "fsi_get_values", "fsi_stress_strain", "fsi_wall_shear_stress", "fsi_calibration_streams", "fsi_set_newton_forcing", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
     "fsi_rccl_unique_id", "fsi_set_rccl", "fsi_create_tuned", "fsi_get_tuning", "fsi_tuning_defaults", "fsi_tuning_from_env",
 )
@@ -153,6 +153,7 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_device_memory.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     lib.fsi_get_matrix.argtypes = [vp, vp, vp, vp]
     lib.fsi_spmv.argtypes = [vp, vp, vp]
+    lib.fsi_apply_preconditioner.argtypes = [vp, vp, vp]
     lib.fsi_get_timers.argtypes = [vp, C.POINTER(FsiTimers), C.c_int]
     lib.fsi_set_linear_solver.argtypes = [vp, i32]
     lib.fsi_probe.argtypes = [vp, i64, vp, vp, vp]
@@ -383,6 +384,13 @@ class HipBackend:
         y = np.empty(self.ndof)
         self._check(self.lib.fsi_spmv(self.ctx, _ptr(x), _ptr(y)))
         return y
+
+    def apply_preconditioner(self, r):
+        """z = M^-1 r: one application of the active preconditioner (user layout), as the Krylov method applies it."""
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        z = np.empty(self.ndof)
+        self._check(self.lib.fsi_apply_preconditioner(self.ctx, _ptr(r), _ptr(z)))
+        return z
 
     def set_linear_solver(self, precond: int = 0):
         self._check(self.lib.fsi_set_linear_solver(self.ctx, int(precond)))

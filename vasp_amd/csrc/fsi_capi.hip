@@ -1355,6 +1355,23 @@ int fsi_spmv(FsiCtx* ctx, const double* x, double* y) {
   return FSI_OK;
 }
 
+int fsi_apply_preconditioner(FsiCtx* ctx, const double* r, double* z) {
+  if (!ctx || !r || !z) return FSI_ERR_INVALID;
+  if (!ctx->have_jacobian) { ctx->err = "fsi_apply_preconditioner: no Jacobian assembled"; return FSI_ERR_INVALID; }
+  if (ctx->part) { ctx->err = "fsi_apply_preconditioner: single contexts only (a partitioned one applies its rank-local part inside fsi_solve)"; return FSI_ERR_INVALID; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t n = ctx->ndof;
+  hipStream_t st = ctx->stream;
+  HIPCHK(hipMemcpyAsync(ctx->tmp7.p, r, n * sizeof(double), hipMemcpyHostToDevice, st));
+  launch_scatter(st, ctx->tmp1.p, ctx->tmp7.p, ctx->user2solver.p, n);
+  launch_mul(st, ctx->tmp1.p, ctx->tmp1.p, ctx->rowscale.p, n);      // the solver works on D A x = D b
+  FSICHK(precondition(ctx, ctx->tmp1.p, ctx->tmp2.p));
+  launch_gather(st, ctx->tmp7.p, ctx->tmp2.p, ctx->user2solver.p, n);
+  HIPCHK(hipMemcpyAsync(z, ctx->tmp7.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return FSI_OK;
+}
+
 int fsi_probe(FsiCtx* ctx, int64_t n, const int32_t* cells, const double* bary, double* out) {
   if (!ctx || n < 0 || (n > 0 && (!cells || !bary || !out))) return FSI_ERR_INVALID;
   if (n == 0) return FSI_OK;
