@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # orthogonalisation group holds the FP32 column kernels AND the FP64-window kernels, the outer product both value types.
 KERNEL_GROUPS = {"k_gcr_dots": ["k_gcr_dots<", "k_gcr_axpy<"],
                  "k_gcr_flush": ["k_gcr_flush<"],
-                 "k_spmv_node6": ["k_spmv_node6<", "k_spmv_node6p<", "k_spmv<0,"],
+                 "k_spmv_node6": ["k_spmv_node6<", "k_spmv_node6p<", "k_spmv_prow<", "k_spmv<0,"],
                  "k_spmv_tiled_f32<1>": ["k_spmv_tiled_f32<1>"], "k_spmv_tiled_f32<3>": ["k_spmv_tiled_f32<3>"],
                  "k_sweep_tiled_f32<1>": ["k_sweep_tiled_f32<1>"], "k_sweep_tiled_f32<3>": ["k_sweep_tiled_f32<3>"],
                  "k_sweep_tiled_h<1>": ["k_sweep_tiled_h<1>"], "k_sweep_tiled_h<3>": ["k_sweep_tiled_h<3>"], "k_sweep_sb_h": ["k_sweep_sb_h"],

@@ -20,13 +20,13 @@ for k, v in d["kernels"].items():
     print(f"| {k[:60]} | {v['launches']} | {v['avg_launch_ms'] * 1e3:.1f} | {v['gpu_ms']:.0f} | {v['share_of_timed_region'] * 100:.1f} % | "
           f"{v['algorithmic_bytes_per_launch'] / 1e6:.0f} | {v['achieved_GBps']:.0f} | {v['frac_of_hbm_peak']:.2f} |")
 print("trace [us]: dots/axpy f32", t("k_gcr_dots<float, 8>", "k_gcr_axpy<float>"), "| f64", t("k_gcr_dots<double, 4>", "k_gcr_dots<double, 8>", "k_gcr_axpy<double>"),
-      "| node6p + tail", t("k_spmv_node6p<true>", "k_spmv<0, float>"), "| node6 f64 + tail", t("k_spmv_node6<double, true>", "k_spmv<0, double>"))
+      "| node6p + tail", t("k_spmv_node6p<true>", "k_spmv<0, float>", "k_spmv_prow<float>"), "| node6 f64 + tail", t("k_spmv_node6<double, true>", "k_spmv<0, double>", "k_spmv_prow<double>"))
 names = ["k_sweep_tiled_h<1>", "k_sweep_tiled_h<3>", "k_sweep_tiled_h<1, 256>", "k_sweep_tiled_h<3, 256>", "k_sweep_sb_h", "k_sweep_sb_b3<1>",
          "k_sweep_schur_tiled", "k_sweep_schur_tiled<64>", "k_sweep_sc_f32", "k_gcr_flush<4>", "k_residual<2>", "k_residual_gather",
          "k_jacobian<2, 2>", "k_vel_correct", "k_vel_correct32", "k_pres_rhs32", "k_spmv_db", "k_db_rows_sub", "k_pres_rows"]
 for n in [n for n in names if n in tr or n in pm]:
     print(f"   {n:24s} trace {tr.get(n, float('nan')):9.1f} us   PMC {pm.get(n, float('nan')):9.1f} MB")
-print("   PMC outer product f32", round(p("k_spmv_node6p<true>", "k_spmv<0, float>")), "f64", round(p("k_spmv_node6<double, true>", "k_spmv<0, double>")),
+print("   PMC outer product f32", round(p("k_spmv_node6p<true>", "k_spmv<0, float>", "k_spmv_prow<float>")), "f64", round(p("k_spmv_node6<double, true>", "k_spmv<0, double>", "k_spmv_prow<double>")),
       "ortho f32 dots/axpy", round(pm.get("k_gcr_dots<float, 8>", 0)), round(pm.get("k_gcr_axpy<float>", 0)))
 if "value_fp64_storage" in d:
     f = d["fp64_storage"]

@@ -80,7 +80,7 @@ def main():
             print(f"    {tag:4s} " + "  ".join(f"{k} {v_:.3e}" for k, v_ in shares(vec).items()), flush=True)
 
     rng = np.random.default_rng(0)
-    K = 20
+    K = int(sys.argv[2]) if len(sys.argv) > 2 else 60
     Q = np.zeros((n, 0))
     v = rng.standard_normal(n); v[bc] = 0.0
     Hs = []
@@ -106,7 +106,7 @@ def main():
     order = np.argsort(-np.abs(ev))
     Qm = np.stack(Qs[:K], axis=1)
     names = ("d", "v", "p")
-    for idx in order[:10]:
+    for idx in list(order[:4]) + list(order[-10:]):
         y = (Qm @ S[:, idx]).real
         y /= np.linalg.norm(y)
         # the mode as a right-hand side; and what the preconditioner makes of it

@@ -142,13 +142,18 @@ void launch_robin_residual(hipStream_t st, int64_t nrows, const int32_t* urow, c
                            const double* val, double th0, double th1, const double* U, const double* U1, double* F);
 void launch_add_at(hipStream_t st, double* vals, const int64_t* pos, const double* v, double a, int64_t n);
 enum SpmvTag : int { SPMV_MONOLITHIC = 0, SPMV_SOLID_BLOCK = 1, SPMV_FIELD_BLOCK = 2 };
-void launch_spmv_node6_f32(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const float* vals,
-                           const double* x, double* y);
+// the node graph the pressure rows of the monolithic matrix were laid out from (k_expand_cols): with it the products read one
+// neighbour rank per six entries (k_spmv_prow); all null: the generic CSR kernel
+struct PRowGraph {
+  const int32_t* vrank = nullptr;
+  const int64_t* nadj_ptr = nullptr;
+  const int32_t* nadj = nullptr;
+};
 void launch_pad_cols32(hipStream_t st, int64_t N2, const int64_t* rowptr, const int32_t* cols, const int64_t* p32, int32_t* cols32);
 void launch_pad_vals32(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const double* A, const int64_t* p32,
                        int64_t ptail, int64_t nnz_tail, int64_t tail_src, float* A32);
 void launch_spmv_node6p(hipStream_t st, int64_t N2, int64_t V, const int64_t* p32, const int32_t* cols32, const float* vals,
-                        const int64_t* rowptr, const int32_t* cols, int64_t tail_shift, const double* x, double* y);
+                        const int64_t* rowptr, const int32_t* cols, int64_t tail_shift, const PRowGraph& g, const double* x, double* y);
 void launch_round_to_f32(hipStream_t st, int64_t n, const double* a, float* b);
 void launch_spmv(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const double* vals,
                  const double* x, double* y, int tag = SPMV_FIELD_BLOCK);
@@ -269,7 +274,7 @@ void launch_mg_prolong(hipStream_t st, int64_t N2, const int32_t* par, const flo
 void launch_residual_rows(hipStream_t st, int64_t nrows, const int32_t* rows, const int64_t* ptr, const int32_t* col,
                           const int64_t* src, const double* vals, const double* x, const double* b, double* y);
 void launch_spmv_node6(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const double* vals,
-                       const double* x, double* y);
+                       const PRowGraph& g, const double* x, double* y);
 void launch_sweep_csr_mixed(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const float* vals,
                             const int64_t* diagpos, const double* dvals, double c1, double c2, const double* din, double* dout,
                             double* x, double* r);

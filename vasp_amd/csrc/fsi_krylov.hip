@@ -13,13 +13,14 @@ namespace host {
 // Jacobian's lifetime is kept in FP32 (see solve_gcr); every other product (true residuals, the other solvers) is FP64
 int spmv(FsiCtx* ctx, const double* x, double* y, bool working) {
   Phase ph(ctx, &ctx->t_spmv);
+  const PRowGraph g{ctx->vrank.p, ctx->nadj_ptr.p, ctx->nadj.p};
   if (working && ctx->op32_ok && ctx->kry_fp32) {
     ctx->op32_products += 1;
     launch_spmv_node6p(ctx->stream, ctx->N2, ctx->V, ctx->a32_ptr.p, ctx->a32_cols.p, ctx->A32.p, ctx->rowptr.p, ctx->cols.p,
-                       ctx->a32_ptail - ctx->a32_tail_src, x, y);
+                       ctx->a32_ptail - ctx->a32_tail_src, g, x, y);
     return FSI_OK;
   }
-  launch_spmv_node6(ctx->stream, ctx->N2, ctx->V, ctx->rowptr.p, ctx->cols.p, ctx->A.p, x, y);
+  launch_spmv_node6(ctx->stream, ctx->N2, ctx->V, ctx->rowptr.p, ctx->cols.p, ctx->A.p, g, x, y);
   return FSI_OK;
 }
 

@@ -240,26 +240,58 @@ __global__ __launch_bounds__(256) void k_spmv_node6(int64_t N2, const int64_t* _
     if (lane == 0) { double* o = y + 6 * r; o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5; }
   }
 }
+// Monolithic SpMV, pressure rows.  The row of vertex q (node rank r = vrank[q]) holds, for every neighbour node s of r in
+// ascending order, the six columns 6 s .. 6 s + 5, then the pressure columns (k_expand_cols): a lane takes a neighbour, reads
+// its rank from the node graph (4 bytes instead of six column indices), the six values and the six x entries - 48 contiguous,
+// 16-byte aligned bytes - and the pressure part follows entry by entry.  One wave per row.  (The generic kernel this replaces
+// read 12 bytes per entry and gathered x entry by entry: 222 us of a 1.53 ms product at 1.12 M tets.)
+template <class VT>
+__global__ __launch_bounds__(256) void k_spmv_prow(int64_t V, const int64_t* __restrict__ prowptr, const int32_t* __restrict__ cols,
+                                                   const VT* __restrict__ vals, const int32_t* __restrict__ vrank,
+                                                   const int64_t* __restrict__ nadj_ptr, const int32_t* __restrict__ nadj,
+                                                   const double* __restrict__ x, double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t q = wave; q < V; q += nwaves) {
+    const int64_t s = prowptr[q], e = prowptr[q + 1];
+    const int32_t r = vrank[q];
+    const int64_t a = nadj_ptr[r], deg = nadj_ptr[r + 1] - a;
+    double sum = 0.0;
+    for (int64_t k = lane; k < deg; k += 64) {
+      const double2* xp = reinterpret_cast<const double2*>(x + 6 * (int64_t)nadj[a + k]);
+      const VT* v = vals + s + 6 * k;
+      const double2 x0 = xp[0], x1 = xp[1], x2 = xp[2];
+      sum += ((double)v[0] * x0.x + (double)v[1] * x0.y) + ((double)v[2] * x1.x + (double)v[3] * x1.y) + ((double)v[4] * x2.x + (double)v[5] * x2.y);
+    }
+    for (int64_t t = s + 6 * deg + lane; t < e; t += 64) sum += (double)vals[t] * x[cols[t]];
+    sum = wave_sum(sum);
+    if (lane == 0) y[q] = sum;
+  }
+}
+template <class VT>
+static void spmv_prows(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const VT* vals_rowptr_based,
+                       const PRowGraph& g, const double* x, double* y) {
+  if (V <= 0) return;
+  const int64_t pb = (V + 3) / 4;
+  if (g.vrank && g.nadj_ptr && g.nadj)
+    hipLaunchKernelGGL(k_spmv_prow<VT>, dim3((unsigned)pb), dim3(256), 0, st, V, rowptr + 6 * N2, cols, vals_rowptr_based, g.vrank, g.nadj_ptr, g.nadj, x, y + 6 * N2);
+  else      // no node graph at hand: the generic kernel on the tail of the matrix
+    hipLaunchKernelGGL((k_spmv<SPMV_MONOLITHIC, VT>), dim3((unsigned)pb), dim3(256), 0, st, V, rowptr + 6 * N2, cols, vals_rowptr_based, x, y + 6 * N2);
+}
 template <class VT>
 static void spmv_node6_any(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const VT* vals,
-                           const double* x, double* y) {
+                           const PRowGraph& g, const double* x, double* y) {
   constexpr bool xcd = true;        // XCD-aware node mapping: -9 % HBM traffic (round 2)
   int64_t blocks = (N2 + 3) / 4;                                 // one wave per node (see launch_spmv_node6p)
   blocks = (blocks + 7) & ~(int64_t)7;
   if (xcd) hipLaunchKernelGGL((k_spmv_node6<VT, true>), dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, cols, vals, x, y);
   else hipLaunchKernelGGL((k_spmv_node6<VT, false>), dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, cols, vals, x, y);
-  if (V > 0) {                                                  // pressure rows: the generic kernel on the tail of the matrix
-    int64_t pb = (V + 3) / 4;
-    hipLaunchKernelGGL((k_spmv<SPMV_MONOLITHIC, VT>), dim3((unsigned)pb), dim3(256), 0, st, V, rowptr + 6 * N2, cols, vals, x, y + 6 * N2);
-  }
+  spmv_prows<VT>(st, N2, V, rowptr, cols, vals, g, x, y);      // pressure rows
 }
 void launch_spmv_node6(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const double* vals,
-                       const double* x, double* y) {
-  spmv_node6_any<double>(st, N2, V, rowptr, cols, vals, x, y);
-}
-void launch_spmv_node6_f32(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const float* vals,
-                           const double* x, double* y) {
-  spmv_node6_any<float>(st, N2, V, rowptr, cols, vals, x, y);
+                       const PRowGraph& g, const double* x, double* y) {
+  spmv_node6_any<double>(st, N2, V, rowptr, cols, vals, g, x, y);
 }
 // ---- FP32 copy of the Jacobian in its own layout --------------------------------------------------------------------
 // The copy only serves k_spmv_node6p, so it is laid out for it: the six value rows of a node (and one row of column
@@ -340,7 +372,7 @@ void launch_pad_vals32(hipStream_t st, int64_t N2, int64_t V, const int64_t* row
 // y = A32 x: padded node rows, then the pressure rows (their values at vals + ptail, indexed by the rows' own pointers
 // shifted by tail_shift = ptail - rowptr[6 N2])
 void launch_spmv_node6p(hipStream_t st, int64_t N2, int64_t V, const int64_t* p32, const int32_t* cols32, const float* vals,
-                        const int64_t* rowptr, const int32_t* cols, int64_t tail_shift, const double* x, double* y) {
+                        const int64_t* rowptr, const int32_t* cols, int64_t tail_shift, const PRowGraph& g, const double* x, double* y) {
   constexpr bool xcd = true;        // XCD-aware node mapping: -9 % HBM traffic (round 2)
   // one wave per node, no grid-stride loop: measured 1.87 ms per product against 2.23 ms with 8192 workgroups looping
   // (row lengths differ by 3x between edge and vertex nodes; the hardware scheduler balances what a static stride cannot)
@@ -350,12 +382,9 @@ void launch_spmv_node6p(hipStream_t st, int64_t N2, int64_t V, const int64_t* p3
   blocks = (blocks + 7) & ~(int64_t)7;
   if (xcd) hipLaunchKernelGGL(k_spmv_node6p<true>, dim3((unsigned)blocks), dim3(256), 0, st, N2, p32, cols32, vals, x, y);
   else hipLaunchKernelGGL(k_spmv_node6p<false>, dim3((unsigned)blocks), dim3(256), 0, st, N2, p32, cols32, vals, x, y);
-  if (V > 0) {
-    int64_t pb = (V + 3) / 4;
-    // the generic kernel indexes values and columns with the same pointer: hand it the value array shifted so that
-    // vals32[rowptr[row]] is the row's first value
-    hipLaunchKernelGGL((k_spmv<SPMV_MONOLITHIC, float>), dim3((unsigned)pb), dim3(256), 0, st, V, rowptr + 6 * N2, cols, vals + tail_shift, x, y + 6 * N2);
-  }
+  // the pressure-row kernels index values and columns with the rows' own pointers: hand them the value array shifted so that
+  // vals32[rowptr[row]] is the row's first value
+  spmv_prows<float>(st, N2, V, rowptr, cols, vals + tail_shift, g, x, y);
 }
 __global__ __launch_bounds__(256) void k_round_to_f32(int64_t n, const double* __restrict__ a, float* __restrict__ b) {
   GRID_STRIDE(i, n) b[i] = (float)a[i];
