@@ -116,6 +116,7 @@ def main():
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between the ranks' devices on this driver stack
 
     import torch
     from vasp_amd.dist import aggregate, init_from_env
