@@ -34,23 +34,28 @@ __device__ inline double block_sum256(double v) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-template <class QT> struct Vec4;
-template <> struct Vec4<float> {
-  using type = float4;
-};
-template <> struct Vec4<double> {
-  using type = double4;
-};
-template <class QT>
-__device__ inline void load4(const QT* p, double& a, double& b, double& c, double& d) {
-  const typename Vec4<QT>::type v = *reinterpret_cast<const typename Vec4<QT>::type*>(p);
+// NT: the columns of a large store are read once per launch and never again before the whole store has gone by - non-temporal
+// loads keep them from displacing w (re-read by every column group) and r in L2 / Infinity Cache (measured on the FP32 store
+// of the bench: dots 974 -> 904 us, update 924 -> 840 us per launch).  Not for the FP64 window: its few columns are read by
+// the product kernel and again by the update kernel right behind it, out of the Infinity Cache (213 -> 247 us with NT).
+template <bool NT>
+__device__ inline void load4(const float* p, double& a, double& b, double& c, double& d) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(p)) : *reinterpret_cast<const f4*>(p);
   a = (double)v.x; b = (double)v.y; c = (double)v.z; d = (double)v.w;
+}
+template <bool NT>
+__device__ inline void load4(const double* p, double& a, double& b, double& c, double& d) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const d2* q = reinterpret_cast<const d2*>(p);
+  const d2 u = NT ? __builtin_nontemporal_load(q) : q[0], v = NT ? __builtin_nontemporal_load(q + 1) : q[1];
+  a = u.x; b = u.y; c = v.x; d = v.y;
 }
 
 // part[k * gridDim.x + bx] = partial of Q_k . w (k < m);  k = m: w . w;  k = m + 1: w . r (0 when r == nullptr).
 // blockIdx.y selects NC directions (or, in the last row, the two vector products): one read of w feeds NC products, so
 // the FP32 form takes eight columns per block (w is FP64: with four, re-reading it would add half of Q's bytes again).
-template <class QT, int NC>
+template <class QT, int NC, bool NT>
 __global__ __launch_bounds__(256) void k_gcr_dots(const QT* __restrict__ Q, int64_t ldq, int64_t n, int m,
                                                   const double* __restrict__ w, const double* __restrict__ r,
                                                   double* __restrict__ part) {
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(256) void k_gcr_dots(const QT* __restrict__ Q, int6
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       double a, b, cc, d;
-      load4<QT>(q[c] + i, a, b, cc, d);
+      load4<NT>(q[c] + i, a, b, cc, d);
       s[c] += (a * wa.x + b * wa.y) + (cc * wb.x + d * wb.y);
     }
   }
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256) void k_gcr_sum(const double* __restrict__ part
 }
 
 // w -= sum_k h[k] Q_k;  part[bx] = partial |w'|^2,  part[gridDim.x + bx] = partial w'.r
-template <class QT>
+template <class QT, bool NT>
 __global__ __launch_bounds__(256) void k_gcr_axpy(const QT* __restrict__ Q, int64_t ldq, int64_t n, int m,
                                                   const double* __restrict__ h, double* __restrict__ w,
                                                   const double* __restrict__ r, double* __restrict__ part) {
@@ -125,17 +130,17 @@ __global__ __launch_bounds__(256) void k_gcr_axpy(const QT* __restrict__ Q, int6
     int k = 0;
     for (; k + 4 <= m; k += 4) {            // four independent 16-byte (FP32) / 32-byte (FP64) loads in flight
       double x0, x1, x2, x3, y0, y1, y2, y3, z0, z1, z2, z3, u0, u1, u2, u3;
-      load4<QT>(q + (int64_t)k * ldq, x0, x1, x2, x3);
-      load4<QT>(q + (int64_t)(k + 1) * ldq, y0, y1, y2, y3);
-      load4<QT>(q + (int64_t)(k + 2) * ldq, z0, z1, z2, z3);
-      load4<QT>(q + (int64_t)(k + 3) * ldq, u0, u1, u2, u3);
+      load4<NT>(q + (int64_t)k * ldq, x0, x1, x2, x3);
+      load4<NT>(q + (int64_t)(k + 1) * ldq, y0, y1, y2, y3);
+      load4<NT>(q + (int64_t)(k + 2) * ldq, z0, z1, z2, z3);
+      load4<NT>(q + (int64_t)(k + 3) * ldq, u0, u1, u2, u3);
       const double h0 = h[k], h1 = h[k + 1], h2 = h[k + 2], h3 = h[k + 3];
       a0 += h0 * x0 + h2 * z0; a1 += h0 * x1 + h2 * z1; a2 += h0 * x2 + h2 * z2; a3 += h0 * x3 + h2 * z3;
       b0 += h1 * y0 + h3 * u0; b1 += h1 * y1 + h3 * u1; b2 += h1 * y2 + h3 * u2; b3 += h1 * y3 + h3 * u3;
     }
     for (; k < m; ++k) {
       double x0, x1, x2, x3;
-      load4<QT>(q + (int64_t)k * ldq, x0, x1, x2, x3);
+      load4<NT>(q + (int64_t)k * ldq, x0, x1, x2, x3);
       const double h0 = h[k];
       a0 += h0 * x0; a1 += h0 * x1; a2 += h0 * x2; a3 += h0 * x3;
     }
@@ -228,6 +233,12 @@ __global__ __launch_bounds__(256) void k_gcr_flush(double* __restrict__ Z, int64
   }
 }
 
+// columns that do not fit the Infinity Cache (256 MiB) beside w and r are gone before the next pass comes by: stream them
+template <class QT>
+#ifndef FSI_GCR_STREAM_MIB
+#define FSI_GCR_STREAM_MIB 512.0
+#endif
+inline bool stream_once(int64_t ldq, int m) { return (double)ldq * (double)m * sizeof(QT) > FSI_GCR_STREAM_MIB * 1048576.0; }
 template <class QT>
 void dots_t(hipStream_t st, const void* Q, int64_t ldq, int64_t n, int m, const double* w, const double* r,
             double* scratch, double* out) {
@@ -235,16 +246,13 @@ void dots_t(hipStream_t st, const void* Q, int64_t ldq, int64_t n, int m, const 
   int np = (int)((n + 16383) / 16384);
   if (np < 1) np = 1;
   if (np > npmax) np = npmax;
-  // columns per read of w: 8 for FP32 and (round 3) for FP64 columns: w is re-read for 1/8 instead of 1/4 of Q's bytes; FSI_GCR_NC64=4: round 2
-  constexpr int nc64 = 8;      // measured: 1 930 -> 1 898 ms per 20 bench steps
-  if (sizeof(QT) == 8 && nc64 == 8) {
-    const int ngroups = (m + 7) / 8;
-    hipLaunchKernelGGL((k_gcr_dots<QT, 8>), dim3(np, ngroups + 1), dim3(256), 0, st, static_cast<const QT*>(Q), ldq, n, m, w, r, scratch);
-  } else {
-    constexpr int NC = sizeof(QT) == 4 ? 8 : 4;
-    const int ngroups = (m + NC - 1) / NC;
-    hipLaunchKernelGGL((k_gcr_dots<QT, NC>), dim3(np, ngroups + 1), dim3(256), 0, st, static_cast<const QT*>(Q), ldq, n, m, w, r, scratch);
-  }
+  // eight columns per read of w, FP32 and FP64 columns alike: w is re-read for 1/8 of Q's bytes (FP64 with four: 1 930 -> 1 898 ms per
+  // 20 bench steps)
+  const int ngroups = (m + 7) / 8;
+  if (stream_once<QT>(ldq, m))
+    hipLaunchKernelGGL((k_gcr_dots<QT, 8, true>), dim3(np, ngroups + 1), dim3(256), 0, st, static_cast<const QT*>(Q), ldq, n, m, w, r, scratch);
+  else
+    hipLaunchKernelGGL((k_gcr_dots<QT, 8, false>), dim3(np, ngroups + 1), dim3(256), 0, st, static_cast<const QT*>(Q), ldq, n, m, w, r, scratch);
   hipLaunchKernelGGL(k_gcr_sum, dim3(m + 2), dim3(256), 0, st, scratch, np, out);
 }
 template <class QT>
@@ -253,7 +261,10 @@ void axpy_t(hipStream_t st, const void* Q, int64_t ldq, int64_t n, int m, const 
   int64_t blocks = ((n >> 2) + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;               // 1024 ... 8192 measured: no difference
-  hipLaunchKernelGGL(k_gcr_axpy<QT>, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const QT*>(Q), ldq, n, m, h, w, r, scratch);
+  if (stream_once<QT>(ldq, m))
+    hipLaunchKernelGGL((k_gcr_axpy<QT, true>), dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const QT*>(Q), ldq, n, m, h, w, r, scratch);
+  else
+    hipLaunchKernelGGL((k_gcr_axpy<QT, false>), dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const QT*>(Q), ldq, n, m, h, w, r, scratch);
   hipLaunchKernelGGL(k_gcr_sum, dim3(2), dim3(256), 0, st, scratch, (int)blocks, out2);
 }
 template <class QT>
