@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 4, twenty-eighth GPU call: non-temporal loads for the store columns of the orthogonalisation, A / B / A / B on one box
+# Round 4, GPU call: non-temporal loads A / B / A / B on one box
 # (libvaspfsi_nt0.so = the same tree built with -DFSI_GCR_STREAM_MIB=1e30: never non-temporal).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r4ab
