@@ -7,5 +7,5 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp64-line > $O/trace.json 2> $O/trace.err; echo "trace rc=$?"
 find /tmp/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
-grep -i "gcr_dots\|gcr_axpy\|spmv_node6\|spmv_prow" $O/kernel_stats.csv | cut -c1-220
+grep -i "gcr_flush\|gcr_dots<float\|gcr_axpy<float" $O/kernel_stats.csv | cut -c1-220
 cd $R; python tools/show_bench.py $O/trace.json | cut -c1-300
