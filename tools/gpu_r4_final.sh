@@ -19,3 +19,6 @@ echo "140k rc=$?"; python tools/show_bench.py $O/small_140k_bench.json | cut -c1
 VASPFSI_DIST_BACKEND=gloo VASPFSI_ONE_GPU=1 timeout -k 10 400 python bench.py --gpus 2 --steps 3 --warmup 1 --tets 100000 --no-cpu-baseline > $O/launch2_driver.json 2> $O/launch2_driver.err
 echo "bench --gpus 2 (driver / worker, gloo, one card) rc=$?"; python tools/show_bench.py $O/launch2_driver.json | cut -c1-300
 bash tools/gpu_pmc_r4.sh
+cd $R
+timeout -k 10 600 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-fp64-line > $O/bench_100_steps.json 2> $O/bench_100_steps.err; echo "100 steps rc=$?"; python tools/show_bench.py $O/bench_100_steps.json | cut -c1-300
+timeout -k 10 300 python tools/gpu_aneurysm_case.py 1000000 10 > $O/aneurysm_1m.txt 2>&1; echo "aneurysm rc=$?"; tail -1 $O/aneurysm_1m.txt | cut -c1-200

@@ -46,10 +46,15 @@ __device__ inline void load4(const float* p, double& a, double& b, double& c, do
 }
 template <bool NT>
 __device__ inline void load4(const double* p, double& a, double& b, double& c, double& d) {
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  const d2* q = reinterpret_cast<const d2*>(p);
-  const d2 u = NT ? __builtin_nontemporal_load(q) : q[0], v = NT ? __builtin_nontemporal_load(q + 1) : q[1];
-  a = u.x; b = u.y; c = v.x; d = v.y;
+  if (NT) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2* q = reinterpret_cast<const d2*>(p);
+    const d2 u = __builtin_nontemporal_load(q), v = __builtin_nontemporal_load(q + 1);
+    a = u.x; b = u.y; c = v.x; d = v.y;
+  } else {
+    const double4 v = *reinterpret_cast<const double4*>(p);
+    a = v.x; b = v.y; c = v.z; d = v.w;
+  }
 }
 
 // part[k * gridDim.x + bx] = partial of Q_k . w (k < m);  k = m: w . w;  k = m + 1: w . r (0 when r == nullptr).
@@ -238,7 +243,9 @@ __global__ __launch_bounds__(256) void k_gcr_flush(double* __restrict__ Z, int64
 #define FSI_GCR_STREAM_MIB 512.0
 #endif
 template <class QT>
-inline bool stream_once(int64_t ldq, int m) { return (double)ldq * (double)m * sizeof(QT) > FSI_GCR_STREAM_MIB * 1048576.0; }
+inline bool stream_once(int64_t ldq, int m) {      // (FP32 columns only: an FP64 store came out 8 % slower with them, 1.83 -> 1.98 s of 20 bench steps)
+  return sizeof(QT) == 4 && (double)ldq * (double)m * sizeof(QT) > FSI_GCR_STREAM_MIB * 1048576.0;
+}
 template <class QT>
 void dots_t(hipStream_t st, const void* Q, int64_t ldq, int64_t n, int m, const double* w, const double* r,
             double* scratch, double* out) {
