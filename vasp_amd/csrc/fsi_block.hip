@@ -924,11 +924,16 @@ __global__ __launch_bounds__(1024) void k_sweep_tiled_h(int64_t N2, const int64_
       s0 += h2f(q.x & 0xffffu) * xv.x; s1 += h2f(q.x >> 16) * xv.y; s2 += h2f(q.y & 0xffffu) * xv.z;
     }
   };
+  // The records of TWO rows ahead are in flight while a row is summed: a row is ~28 pairs of 4 - 8 bytes over 16 lanes, and one row
+  // ahead left ~32 KB in flight per CU, which paced the one-ratio form at ~3.7 TB/s (119.9 -> 112.1 us per displacement sweep at
+  // 1.12 M tets, A / B on one box; the 8-byte records of the fluid block: 144 us either way).
   int i = g;
+  Rec n2[KS];
   if (i < nrows) prefetch(i, cr);
+  if (i + ngrp < nrows) prefetch(i + ngrp, nr);
   while (i < nrows) {
     const int ni = i + ngrp;
-    if (ni < nrows) prefetch(ni, nr);
+    if (ni + ngrp < nrows) prefetch(ni + ngrp, n2);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     fma3(cr[0], s0, s1, s2);
     fma3(cr[1], s0, s1, s2);
@@ -938,7 +943,7 @@ __global__ __launch_bounds__(1024) void k_sweep_tiled_h(int64_t N2, const int64_
     s0 = group_sum<16>(s0); s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
     if (sub == 0) ssum[i] = make_float4(s0, s1, s2, 0.f);
 #pragma unroll
-    for (int k = 0; k < KS; ++k) cr[k] = nr[k];
+    for (int k = 0; k < KS; ++k) { cr[k] = nr[k]; nr[k] = n2[k]; }
     i = ni;
   }
   __syncthreads();
