@@ -975,33 +975,44 @@ void launch_sweep_tiled_h(hipStream_t st, int nv, int tn, int64_t N2, int max_nu
   else
     hipLaunchKernelGGL((k_sweep_tiled_h<3, 256>), dim3(tiles), dim3(th), lds, st, N2, nadj_ptr, static_cast<const uint2*>(rec), tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
 }
-// k_sweep_sb_b3<0> on the packed 24-byte block records
+// k_sweep_sb_b3<0> on the packed 24-byte block records.  LPR lanes per row with 32 / LPR blocks in flight per lane: the sweep is a chain
+// of three dependent loads (row pointer -> record -> gathered d) per round of resident waves, and 150 k rows of 16 lanes are 4.6 rounds;
+// 8 lanes per row are half the rounds with twice the loads in flight per lane (measured at 1.12 M tets, A / B on one box: 16 lanes
+// 25.7 us per sweep - 28.4 before the loads of a strip were issued together -, 8 lanes 23.8 us, 4 lanes 33.4 us).
+template <int LPR>
 __global__ __launch_bounds__(256) void k_sweep_sb_h(int64_t nS, const int64_t* __restrict__ sb_ptr, const uint2* __restrict__ rec,
                                                     const float* __restrict__ binv12, float c1, float c2,
                                                     const float* __restrict__ din, float* __restrict__ dout,
                                                     float* __restrict__ x, float* __restrict__ r) {
-  const int sub = threadIdx.x & 15;
-  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
-  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  constexpr int NB = 32 / LPR;                               // blocks in flight per lane
+  const int sub = threadIdx.x & (LPR - 1);
+  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / LPR;
+  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) / LPR;
+  const float4* d4 = reinterpret_cast<const float4*>(din);
   for (int64_t i = grp; i < nS; i += ngrp) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     const int64_t bend = sb_ptr[i + 1];
-    for (int64_t b = sb_ptr[i] + sub; b < bend; b += 32) {
-      const bool p1 = b + 16 < bend;
-      const int64_t b1 = p1 ? b + 16 : b;
-      const uint2 a0 = rec[3 * b], a1 = rec[3 * b + 1], a2 = rec[3 * b + 2];
-      const uint2 q0 = rec[3 * b1], q1 = rec[3 * b1 + 1], q2 = rec[3 * b1 + 2];
-      const float4 xv = reinterpret_cast<const float4*>(din)[a2.y];
-      float4 yv = reinterpret_cast<const float4*>(din)[q2.y];
-      if (!p1) yv = make_float4(0.f, 0.f, 0.f, 0.f);
-      s0 += (h2f(a0.x & 0xffffu) * xv.x + h2f(a0.x >> 16) * xv.y + h2f(a0.y & 0xffffu) * xv.z) +
-            (h2f(q0.x & 0xffffu) * yv.x + h2f(q0.x >> 16) * yv.y + h2f(q0.y & 0xffffu) * yv.z);
-      s1 += (h2f(a0.y >> 16) * xv.x + h2f(a1.x & 0xffffu) * xv.y + h2f(a1.x >> 16) * xv.z) +
-            (h2f(q0.y >> 16) * yv.x + h2f(q1.x & 0xffffu) * yv.y + h2f(q1.x >> 16) * yv.z);
-      s2 += (h2f(a1.y & 0xffffu) * xv.x + h2f(a1.y >> 16) * xv.y + h2f(a2.x & 0xffffu) * xv.z) +
-            (h2f(q1.y & 0xffffu) * yv.x + h2f(q1.y >> 16) * yv.y + h2f(q2.x & 0xffffu) * yv.z);
+    for (int64_t b = sb_ptr[i] + sub; b < bend; b += NB * LPR) {
+      uint2 a0[NB], a1[NB], a2[NB];
+      bool live[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {                          // a strip past the end re-reads the first one with its d zeroed
+        live[u] = b + u * LPR < bend;
+        const int64_t bu = live[u] ? b + u * LPR : b;
+        a0[u] = rec[3 * bu]; a1[u] = rec[3 * bu + 1]; a2[u] = rec[3 * bu + 2];
+      }
+      float4 xv[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) xv[u] = d4[a2[u].y];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const float4 v = live[u] ? xv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s0 += h2f(a0[u].x & 0xffffu) * v.x + h2f(a0[u].x >> 16) * v.y + h2f(a0[u].y & 0xffffu) * v.z;
+        s1 += h2f(a0[u].y >> 16) * v.x + h2f(a1[u].x & 0xffffu) * v.y + h2f(a1[u].x >> 16) * v.z;
+        s2 += h2f(a1[u].y & 0xffffu) * v.x + h2f(a1[u].y >> 16) * v.y + h2f(a2[u].x & 0xffffu) * v.z;
+      }
     }
-    s0 = group_sum<16>(s0); s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
+    s0 = group_sum<LPR>(s0); s1 = group_sum<LPR>(s1); s2 = group_sum<LPR>(s2);
     float rc = 0.f, dc = 0.f;
     if (sub < 3) {
       dc = din[4 * i + sub];
@@ -1018,8 +1029,9 @@ __global__ __launch_bounds__(256) void k_sweep_sb_h(int64_t nS, const int64_t* _
 }
 void launch_sweep_sb_h(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const void* rec, const float* binv12, float c1, float c2,
                        const float* din, float* dout, float* x, float* r) {
-  int64_t blocks = (nS + 15) / 16;
-  hipLaunchKernelGGL(k_sweep_sb_h, dim3((unsigned)blocks), dim3(256), 0, st, nS, sb_ptr, static_cast<const uint2*>(rec), binv12, c1, c2, din, dout, x, r);
+  constexpr int LPR = 8;
+  int64_t blocks = (nS * LPR + 255) / 256;
+  hipLaunchKernelGGL(k_sweep_sb_h<LPR>, dim3((unsigned)blocks), dim3(256), 0, st, nS, sb_ptr, static_cast<const uint2*>(rec), binv12, c1, c2, din, dout, x, r);
 }
 
 // The same fused sweep without tiles (coarse level of the displacement block: the vertex graph, L2-resident)
