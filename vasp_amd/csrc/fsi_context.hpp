@@ -167,6 +167,7 @@ struct FsiCtx {
   int64_t rccl_allreduces = 0, rccl_halos = 0;
   bool ras = false;                          // restricted additive Schwarz on the overlap: agreed by all ranks in fsi_set_partition
   bool debug_gcr = false;
+  int64_t dbg_droppable = 0, dbg_drop_cols = 0;
   int64_t dbg_cols = 0, dbg_sig6 = 0, dbg_sig9 = 0, dbg_sig12 = 0;   // FSI_DEBUG_GCR: how many Gram-Schmidt coefficients matter
 
   // field blocks for the block preconditioner (fsi_block.hip)

@@ -346,6 +346,15 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
             if (a > 1e-12 * wref) ctx->dbg_sig12 += 1;
           }
         }
+        if (ctx->debug_gcr && pass == 0 && h2[0] > 0.0) {
+          // how many columns could have been left out of this pass with their part of w staying below 1 % of |w'| (1e-4 of |w'|^2)?
+          std::vector<double> a2(m);
+          for (int j = 0; j < m; ++j) a2[j] = hh[j] * hh[j];
+          std::sort(a2.begin(), a2.end());
+          double acc = 0.0; int drop = 0;
+          for (int j = 0; j < m; ++j) { if (acc + a2[j] > 1e-4 * h2[0]) break; acc += a2[j]; drop += 1; }
+          ctx->dbg_droppable += drop; ctx->dbg_drop_cols += m;
+        }
         ctx->ortho_q_cols += 2 * (int64_t)m; ctx->ortho_q_launches += 2;
         wn = std::sqrt(std::max(h2[0], 0.0));
         wr = h2[1];
@@ -441,6 +450,7 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
       fprintf(stderr, "[gcr] it %d |r| %.3e target %.3e m %d  |h_j| > 1e-6/1e-9/1e-12 |w|: %.2f %.2f %.2f of the columns\n", *iters, rnorm, target, m,
               (double)ctx->dbg_sig6 / std::max<int64_t>(1, ctx->dbg_cols), (double)ctx->dbg_sig9 / std::max<int64_t>(1, ctx->dbg_cols),
               (double)ctx->dbg_sig12 / std::max<int64_t>(1, ctx->dbg_cols));
+      fprintf(stderr, "[gcr]   columns whose coefficients together stay below 1 %% of |w'|: %.3f of the kept ones\n", (double)ctx->dbg_droppable / std::max<int64_t>(1, ctx->dbg_drop_cols));
       fflush(stderr);
     }
     if (!std::isfinite(rnorm)) { ctx->err = "GCR diverged (non-finite residual)"; return FSI_ERR_LINEAR; }
