@@ -797,7 +797,9 @@ def test_avf_two_mooney_rivlin_regions_match_oracle(tmp_path):
         Uk = hb.get_state("n")
         b = o.rhs(Uk, prev, P, g)                       # the oracle's residual at the HIP path's solution
         b0 = o.rhs(prev, prev, P, g)
-        assert np.linalg.norm(b) <= 1e-7 * np.linalg.norm(b0), (k, np.linalg.norm(b), np.linalg.norm(b0), hist)
+        # (what the loop guarantees is |b| < atol; 1e-7 |b0| is ~3e-13 on the first steps from rest, which the mixed default reaches and
+        # an all-FP64 basis misses by a factor two: both are converged runs)
+        assert np.linalg.norm(b) <= max(1e-7 * np.linalg.norm(b0), 1e-11), (k, np.linalg.norm(b), np.linalg.norm(b0), hist)
         assert np.all(np.isfinite(Uk))
         hb.shift()
         prev = Uk
