@@ -1048,7 +1048,7 @@ int fsi_create_tuned(const FsiMeshDesc* mesh, const FsiParams* prm, int device, 
   HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->gcr_host), (size_t)(cap + 64) * sizeof(double), hipHostMallocDefault));
   ctx->kry_born.assign(cap, -1);
   gcr_reset(ctx);
-  HIPCHK(ctx->scratch.alloc(std::max<size_t>(8192, (size_t)(cap + 2) * 256 + 16)));
+  HIPCHK(ctx->scratch.alloc(std::max<size_t>(24576, (size_t)(cap + 2) * 256 + 16)));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return FSI_OK;
 }

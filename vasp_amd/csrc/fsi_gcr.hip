@@ -249,8 +249,11 @@ inline bool stream_once(int64_t ldq, int m) {      // (FP32 columns only: an FP6
 template <class QT>
 void dots_t(hipStream_t st, const void* Q, int64_t ldq, int64_t n, int m, const double* w, const double* r,
             double* scratch, double* out) {
-  constexpr int npmax = 128;      // 128: 3 000 workgroups at m = 180 (64: 4 % slower, 256: same)
-  int np = (int)((n + 16383) / 16384);
+  // row parts: 128 at a full store (3 000 workgroups at m = 180; 64: 4 % slower, 256: same) and more when there are few columns - the
+  // FP64 window's 1 - 8 columns were 256 workgroups on 256 CUs (212 us for 0.4 GB) - so that the grid has ~2 000 workgroups either way
+  const int ngroups0 = (m + 7) / 8 + 1;
+  int npmax = std::min(1024, std::max(128, (2048 + ngroups0 - 1) / ngroups0));
+  int np = (int)((n + 4095) / 4096);      // at least 4 096 rows per part
   if (np < 1) np = 1;
   if (np > npmax) np = npmax;
   // eight columns per read of w, FP32 and FP64 columns alike: w is re-read for 1/8 of Q's bytes (FP64 with four: 1 930 -> 1 898 ms per
