@@ -21,7 +21,7 @@ __device__ inline double dpp_d(double v) {
 template <int LANES>
 __device__ inline float group_sum(float v) {
   v += dpp_f<0xB1>(v);                          // quad_perm [1,0,3,2]
-  v += dpp_f<0x4E>(v);                          // quad_perm [2,3,0,1]
+  if (LANES >= 4) v += dpp_f<0x4E>(v);          // quad_perm [2,3,0,1]
   if (LANES >= 8) v += dpp_f<0x141>(v);         // row_half_mirror: the other quad of the half row (quads are uniform by now)
   if (LANES >= 16) v += dpp_f<0x140>(v);        // row_mirror: the other half row
   return v;
@@ -29,7 +29,7 @@ __device__ inline float group_sum(float v) {
 template <int LANES>
 __device__ inline double group_sum(double v) {
   v += dpp_d<0xB1>(v);
-  v += dpp_d<0x4E>(v);
+  if (LANES >= 4) v += dpp_d<0x4E>(v);
   if (LANES >= 8) v += dpp_d<0x141>(v);
   if (LANES >= 16) v += dpp_d<0x140>(v);
   return v;
