@@ -95,7 +95,9 @@ typedef struct FsiNewtonIter {
  * only); fsi_create_tuned takes the struct as given.  The reference has no counterpart: its linear solver is
  * `linear_solver="mumps"` [REF src/vasp/simulations/offset_stenosis.py:45]. */
 typedef struct FsiTuning {
-  int32_t struct_size;         /* sizeof(FsiTuning) of the caller: a library built with a longer struct fills the rest with defaults */
+  int32_t struct_size;         /* in / out in every call that takes an FsiTuning*: set it to the caller's sizeof(FsiTuning) (0 = this
+                                * header's).  fsi_tuning_defaults / _from_env / fsi_get_tuning write at most that many bytes and store
+                                * the number written; fsi_create_tuned reads that many and takes the defaults for the rest. */
   /* storage precisions (all arithmetic on the Newton level and every linear-solve verdict is FP64 whatever these say) */
   int32_t krylov_fp32;         /* Krylov basis Q: 0 FP64, 1 FP32, 2 decided per Jacobian lifetime from the tolerances asked for    */
   int32_t operator_fp32;       /* 1: products inside Krylov iterations on an FP32 copy of the Jacobian values (with an FP32 basis) */
@@ -144,6 +146,8 @@ typedef struct FsiTuning {
   double mg_alpha, mg_ckappa;
 } FsiTuning;
 void fsi_tuning_defaults(FsiTuning* t);
+/* (internal helper of fsi_get_tuning, exported so that the ABI test can exercise the size rule without a device) */
+void fsi_tuning_copy_out(const FsiTuning* full, FsiTuning* out);
 /* the defaults with the FSI_<NAME> variables of the environment applied (what fsi_create uses) */
 void fsi_tuning_from_env(FsiTuning* t);
 
@@ -353,6 +357,11 @@ typedef struct FsiTimers {
   int64_t newton_late_solves;                        /* Newton iterations solved with the late (tighter) forcing term        */
 } FsiTimers;
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
+/* Run totals of the linear solver's events since fsi_create - out[0] newton_retries, out[1] fp32_fallbacks, out[2] gcr_restarts
+ * (the FsiTimers fields of the same names count since the last reset) - without resolving the phase timers: no device
+ * synchronisation, safe to call every time step, unaffected by fsi_get_timers(reset = 1).  What the product driver prints as
+ * "Linear solver events so far". */
+int fsi_get_solver_events(const FsiCtx* ctx, int64_t out[3]);
 /* Measurement aid: streams `bytes` of the (idle) Krylov store once per kernel with 4-, 8-, 16- and 32-byte loads and
  * 4-, 8-, 16-byte stores per lane (kernels k_cal_read<...> / k_cal_write<...>), so that a rocprofv3 --pmc FETCH_SIZE /
  * WRITE_SIZE pass can be calibrated against known byte counts at the access widths the solver kernels use.  Discards

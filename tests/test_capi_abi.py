@@ -69,6 +69,28 @@ def test_tuning_defaults_and_environment_overrides(monkeypatch):
             assert m.group(1).startswith("FSI_DEBUG") or m.group(1) == "FSI_RCCL_HOST_REDUCE", (src.name, m.group(1))
 
 
+def test_tuning_struct_size_is_honoured_in_both_directions():
+    """a caller compiled against a shorter (older) FsiTuning announces its sizeof in struct_size; the three functions
+    that fill a caller's buffer write at most that many bytes and report how many they wrote."""
+    lib = capi.load_library()
+    full = ctypes.sizeof(capi.FsiTuning)
+    short = capi.FsiTuning.krylov_capacity.offset + 4          # an "old" struct that ends behind krylov_capacity
+    for fill in (lib.fsi_tuning_defaults, lib.fsi_tuning_from_env,
+                 lambda p: lib.fsi_tuning_copy_out(ctypes.byref(ref), p)):
+        ref = capi.FsiTuning()
+        lib.fsi_tuning_defaults(ctypes.byref(ref))
+        buf = (ctypes.c_ubyte * full)(*([0xAB] * full))
+        t = ctypes.cast(buf, ctypes.POINTER(capi.FsiTuning))
+        t.contents.struct_size = short
+        fill(t)
+        assert t.contents.struct_size == short and t.contents.krylov_fp32 == 2 and t.contents.krylov_capacity == 600
+        assert bytes(buf[short:]) == bytes([0xAB] * (full - short))          # nothing behind the caller's struct was touched
+        for bad in (0, -5, full + 64):                                        # "this header's size"
+            t.contents.struct_size = bad
+            fill(t)
+            assert t.contents.struct_size == full and t.contents.mg_cits == 24
+
+
 def test_error_codes_match_header():
     for code, name in capi.ERROR_NAMES.items():
         assert re.search(r"#define %s %d\b" % (name, code), HEADER)

@@ -310,8 +310,11 @@ def test_solver_events_show_up_in_the_product_log(tmp_path):
     from vasp_amd import monolithic
 
     class Eventful(_StubBackend):
-        def timers(self, reset=False):
-            return dict(newton_retries=1 if self.steps >= 2 else 0, fp32_fallbacks=0, gcr_restarts=0, krylov_iters=7)
+        def solver_events(self):               # run totals (fsi_get_solver_events): cheap, not affected by timer resets
+            return dict(newton_retries=1 if self.steps >= 2 else 0, fp32_fallbacks=0, gcr_restarts=0)
+
+        def timers(self, reset=False):         #  the driver must not resolve the phase timers every step
+            raise AssertionError("monolithic.run read the phase timers for its event line")
 
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
@@ -322,7 +325,7 @@ def test_solver_events_show_up_in_the_product_log(tmp_path):
     assert out.count("Linear solver events so far: newton_retries = 1, fp32_fallbacks = 0, gcr_restarts = 0") == 1
     assert out.index("Linear solver events") > out.index("Solved for timestep 1,")          # raised in step 2, reported once
     assert ns["solver_events"]["newton_retries"] == 1
-    _, quiet = _run_cylinder(tmp_path / "q", T="0.002")                                        # a backend without timers: no line
+    _, quiet = _run_cylinder(tmp_path / "q", T="0.002")                                        # a backend without event counters: no line
     assert "Linear solver events" not in quiet
 
 

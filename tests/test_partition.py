@@ -302,3 +302,72 @@ def test_parts_and_announcements_travel_over_gloo():
     assert kw0 == kw1 == dict(lin_rtol=1e-9)
     assert [e[0] for e in log1] == ["newton_solve", "probe", "close"]
     assert log1[0][1:3] == (["atol", "counter"], ["P", "bc"]) and log1[1][3] == [(3,), (3, 4)]
+
+
+class _FakeWorkerBackend:
+    """What ``serve`` needs of a DistBackend, without a device: the calls are recorded, two of them fail."""
+    rank = 1
+
+    def __init__(self, path):
+        self.path, self.hb = path, self
+
+    def _note(self, what):
+        with open(self.path, "a") as f:
+            f.write(what + "\n")
+
+    def set_dirichlet_values(self, v):
+        self._note("bc")
+
+    def set_interface_pressure(self, P):
+        self._note("P")
+
+    def newton_solve(self, **kw):
+        from vasp_amd.capi import FsiError
+        self._note("newton_solve")
+        raise FsiError(3, "agreed linear failure")          # every rank gets this one from the library: keep listening
+
+    def shift(self):
+        self._note("shift")
+
+    def probe(self, cells, bary):
+        self._note("probe")
+        raise ValueError("rank-local failure")              # rank 0 would wait in the matching all-reduce for ever
+
+    def close(self):
+        self._note("close")
+
+
+def _serve_with_failures(rank, world, port, log_path):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from vasp_amd.partition import ControlChannel, serve
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    control = ControlChannel(dist)
+    if rank == 0:
+        control.tell(("newton_solve", (), {}, {"bc": np.arange(3.0), "P": 1.0}))
+        control.tell(("shift", (), {}, {}))
+        control.tell(("probe", (np.array([0]), np.eye(4)[:1]), {}, {}))
+        return                                               # (no collective follows: the worker is gone by then)
+    serve(_FakeWorkerBackend(log_path), control)
+    raise AssertionError("serve returned after a rank-local failure")
+
+
+def test_worker_leaves_the_job_on_a_rank_local_failure(tmp_path):
+    """``serve`` swallows only the failures the library agrees on across ranks; anything else ends the worker
+    process with a non-zero status (the launcher then tears the job down) instead of leaving rank 0 blocked in a collective."""
+    import torch.multiprocessing as mp
+    from vasp_amd.partition import WORKER_EXIT_CODE
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    log = tmp_path / "calls.txt"
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_serve_with_failures, args=(r, 2, port, str(log))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert procs[0].exitcode == 0
+    assert procs[1].exitcode == WORKER_EXIT_CODE
+    # the agreed FsiError did not end the loop (shift and probe were still served); the backend was closed before the exit
+    assert log.read_text().split() == ["bc", "P", "newton_solve", "shift", "probe", "close"]

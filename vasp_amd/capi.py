@@ -21,8 +21,8 @@ EXPORTED_SYMBOLS = (
     "fsi_set_pressure_facets", "fsi_set_interface_pressure", "fsi_set_robin_facets", "fsi_solver_setup",
     "fsi_assemble_residual", "fsi_assemble_jacobian", "fsi_solve", "fsi_newton_solve", "fsi_shift",
     "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_device_memory", "fsi_apply_preconditioner", "fsi_get_matrix", "fsi_spmv",
-    "fsi_get_timers", "fsi_get_values", "fsi_stress_strain", "fsi_wall_shear_stress", "fsi_calibration_streams", "fsi_set_newton_forcing", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
-    "fsi_rccl_unique_id", "fsi_set_rccl", "fsi_create_tuned", "fsi_get_tuning", "fsi_tuning_defaults", "fsi_tuning_from_env",
+    "fsi_get_timers", "fsi_get_solver_events", "fsi_get_values", "fsi_stress_strain", "fsi_wall_shear_stress", "fsi_calibration_streams", "fsi_set_newton_forcing", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
+    "fsi_rccl_unique_id", "fsi_set_rccl", "fsi_create_tuned", "fsi_get_tuning", "fsi_tuning_defaults", "fsi_tuning_from_env", "fsi_tuning_copy_out",
 )
 
 
@@ -125,6 +125,7 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_get_tuning.argtypes = [vp, C.POINTER(FsiTuning)]
     lib.fsi_tuning_defaults.argtypes = [C.POINTER(FsiTuning)]
     lib.fsi_tuning_from_env.argtypes = [C.POINTER(FsiTuning)]
+    lib.fsi_tuning_copy_out.argtypes = [C.POINTER(FsiTuning), C.POINTER(FsiTuning)]
     lib.fsi_destroy.argtypes = [vp]
     lib.fsi_last_error.argtypes = [vp]
     lib.fsi_last_error.restype = C.c_char_p
@@ -155,6 +156,7 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_spmv.argtypes = [vp, vp, vp]
     lib.fsi_apply_preconditioner.argtypes = [vp, vp, vp]
     lib.fsi_get_timers.argtypes = [vp, C.POINTER(FsiTimers), C.c_int]
+    lib.fsi_get_solver_events.argtypes = [vp, vp]
     lib.fsi_set_linear_solver.argtypes = [vp, i32]
     lib.fsi_probe.argtypes = [vp, i64, vp, vp, vp]
     lib.fsi_flow_stats.argtypes = [vp, vp]
@@ -164,7 +166,7 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_set_rccl.argtypes = [vp, C.c_char_p, i32, i32, vp, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
-        if name in ("fsi_tuning_defaults", "fsi_tuning_from_env"):
+        if name in ("fsi_tuning_defaults", "fsi_tuning_from_env", "fsi_tuning_copy_out"):
             fn.restype = None
         elif name not in ("fsi_last_error", "fsi_num_dofs", "fsi_matrix_nnz"):
             fn.restype = C.c_int
@@ -440,6 +442,13 @@ class HipBackend:
         t = FsiTuning()
         self._check(self.lib.fsi_get_tuning(self.ctx, C.byref(t)))
         return t.as_dict()
+
+    def solver_events(self) -> dict:
+        """Run totals (since the context was created; timer resets do not touch them) of what the linear solver had to do beyond
+        iterating - a cheap read: no device synchronisation, unlike ``timers()``."""
+        out = np.zeros(3, dtype=np.int64)
+        self._check(self.lib.fsi_get_solver_events(self.ctx, _ptr(out)))
+        return {"newton_retries": int(out[0]), "fp32_fallbacks": int(out[1]), "gcr_restarts": int(out[2])}
 
     def timers(self, reset=False) -> dict:
         t = FsiTimers()

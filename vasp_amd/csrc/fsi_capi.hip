@@ -224,7 +224,7 @@ int fsi_create(const FsiMeshDesc* mesh, const FsiParams* prm, int device, FsiCtx
 
 int fsi_get_tuning(const FsiCtx* ctx, FsiTuning* out) {
   if (!ctx || !out) return FSI_ERR_INVALID;
-  *out = ctx->tune;
+  fsi_tuning_copy_out(&ctx->tune, out);      // out->struct_size is in / out: at most that many bytes are written
   return FSI_OK;
 }
 
@@ -1489,6 +1489,14 @@ int fsi_wall_shear_stress(FsiCtx* ctx, int64_t nf, const int32_t* facet_cells, c
   return FSI_OK;
 }
 
+int fsi_get_solver_events(const FsiCtx* ctx, int64_t out[3]) {
+  if (!ctx || !out) return FSI_ERR_INVALID;
+  out[0] = ctx->ev_base[0] + ctx->newton_retries;
+  out[1] = ctx->ev_base[1] + ctx->kry_fp32_failures_total;
+  out[2] = ctx->ev_base[2] + ctx->gcr_restarts;
+  return FSI_OK;
+}
+
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
   if (!ctx || !out) return FSI_ERR_INVALID;
   HIPCHK(hipSetDevice(ctx->device));
@@ -1523,6 +1531,7 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
     ctx->inner_calls = 0;
     ctx->ortho_q_cols = ctx->ortho_q_launches = ctx->ortho_z_cols = ctx->ortho_z_launches = 0;
     ctx->part_allreduces = 0;
+    ctx->ev_base[0] += ctx->newton_retries; ctx->ev_base[1] += ctx->kry_fp32_failures_total; ctx->ev_base[2] += ctx->gcr_restarts;   // run totals survive
     ctx->gcr_arnoldi_steps = ctx->gcr_restarts = ctx->newton_retries = ctx->kry_fp32_failures_total = 0;
     ctx->verdicts_skipped = ctx->gcr_reorth_forced = 0;
     ctx->dd_cache_hits = ctx->newton_late_solves = 0;

@@ -290,6 +290,7 @@ struct FsiCtx {
   int64_t verdicts_skipped = 0;
   bool in_newton = false;                    // the running fsi_solve was called by fsi_newton_solve (an FP64 Newton residual follows)
   bool f64_suspect = false;                  // FP64 basis: a verdict of the present store differed from its recurrence (see solve_gcr)
+  int64_t ev_base[3] = {0, 0, 0};            // newton_retries / fp32 fall-backs / gcr_restarts counted before the last timer reset (fsi_get_solver_events)
   int64_t newton_retries = 0;                // Newton iterations whose linear solve failed on a stale Jacobian and succeeded after a refresh
   double orth_floor32 = 3e-7, orth_floor64 = 1e-9;   // estimated orthogonality error of a new column above which a second Gram-Schmidt pass is made
   int64_t gcr_reorth_forced = 0;

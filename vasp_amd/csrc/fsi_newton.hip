@@ -145,6 +145,10 @@ int fsi_newton_solve(FsiCtx* ctx, const FsiNewtonOpts* o, FsiNewtonIter* iters, 
     ctx->tol_hint = o->lin_rtol;
     if (ctx->bnorm_max > 0.0 && o->atol > 0.0 && ctx->newton_forcing > 0.0)
       ctx->tol_hint = std::max(o->lin_rtol, std::min(1e-2, ctx->newton_forcing * o->atol / ctx->bnorm_max));
+    // in_newton / tol_hint hold for the two solves below and for nothing else: the guard clears them on EVERY way out of this
+    // iteration (the early return of the refresh-and-retry path included), so that a later direct fsi_solve on this context is
+    // never taken for a solve inside Newton - it would skip the FP64 verdict and choose the basis precision from a stale hint
+    struct NewtonScope { FsiCtx* c; ~NewtonScope() { c->tol_hint = 0.0; c->in_newton = false; } } newton_scope{ctx};
     ctx->in_newton = true;
     int src = fsi_solve(ctx, eta, o->lin_max_it, o->lin_solver, &lit, &lrr);
     bool rec_retry = false;

@@ -12,8 +12,52 @@
 
 extern "C" {
 
+}  // extern "C"
+
+namespace {
+// struct_size is in / out (include/vaspfsi.h): a caller built against a shorter, older FsiTuning announces its sizeof there
+// and only that many bytes of its buffer are written; 0 (a zeroed struct) or anything outside (0, sizeof] means "this header".
+size_t caller_bytes(const FsiTuning* t) {
+  const int32_t sz = t->struct_size;
+  return (sz >= (int32_t)sizeof(int32_t) && sz <= (int32_t)sizeof(FsiTuning)) ? (size_t)sz : sizeof(FsiTuning);
+}
+void hand_out(const FsiTuning& full, FsiTuning* t, size_t n) {
+  std::memcpy(t, &full, n);
+  t->struct_size = (int32_t)n;
+}
+void defaults(FsiTuning* t);
+void from_env(FsiTuning* t);
+}  // namespace
+
+extern "C" {
+
 void fsi_tuning_defaults(FsiTuning* t) {
   if (!t) return;
+  const size_t n = caller_bytes(t);
+  FsiTuning full;
+  defaults(&full);
+  hand_out(full, t, n);
+}
+
+void fsi_tuning_from_env(FsiTuning* t) {
+  if (!t) return;
+  const size_t n = caller_bytes(t);
+  FsiTuning full;
+  from_env(&full);
+  hand_out(full, t, n);
+}
+
+// fsi_get_tuning (fsi_capi.hip) hands the context's struct out through this, under the same rule
+void fsi_tuning_copy_out(const FsiTuning* full, FsiTuning* out) {
+  if (!full || !out) return;
+  hand_out(*full, out, caller_bytes(out));
+}
+
+}  // extern "C"
+
+namespace {
+
+void defaults(FsiTuning* t) {
   std::memset(t, 0, sizeof *t);
   t->struct_size = (int32_t)sizeof(FsiTuning);
   t->krylov_fp32 = 2; t->operator_fp32 = 1; t->schur_fp32 = 1; t->sweeps_fp32 = 1; t->sweeps_fp16 = 1; t->solid_fp32 = 1; t->pv_fp32 = 1;
@@ -30,9 +74,8 @@ void fsi_tuning_defaults(FsiTuning* t) {
   t->mg_pre = 3; t->mg_post = 5; t->mg_cits = 24; t->mg_alpha = 20.0; t->mg_ckappa = 250.0;
 }
 
-void fsi_tuning_from_env(FsiTuning* t) {
-  if (!t) return;
-  fsi_tuning_defaults(t);
+void from_env(FsiTuning* t) {
+  defaults(t);
   auto I = [](const char* name, int32_t* v) { if (const char* e = getenv(name)) *v = (int32_t)atoi(e); };
   auto D = [](const char* name, double* v) { if (const char* e = getenv(name)) *v = atof(e); };
   I("FSI_KRYLOV_FP32", &t->krylov_fp32); I("FSI_OPERATOR_FP32", &t->operator_fp32); I("FSI_SCHUR_FP32", &t->schur_fp32);
@@ -59,4 +102,4 @@ void fsi_tuning_from_env(FsiTuning* t) {
   D("FSI_MG_ALPHA", &t->mg_alpha); D("FSI_MG_CKAPPA", &t->mg_ckappa);
 }
 
-}  // extern "C"
+}  // namespace

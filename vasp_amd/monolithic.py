@@ -350,11 +350,11 @@ def solver_events(backend) -> Dict[str, int]:
     (`newton_retries` - such an iteration is logged as "Compute Jacobian matrix"), Jacobian lifetimes that lost the FP32
     Krylov basis (`fp32_fallbacks`), solves that dropped the recycled directions (`gcr_restarts`).  Empty for a backend
     without timers (the oracle backend of the CPU tests)."""
-    timers = getattr(backend, "timers", None)
-    if timers is None:
+    events = getattr(backend, "solver_events", None)
+    if events is None:
         return {}
-    tm = timers()
-    return {k: int(tm[k]) for k in SOLVER_EVENT_KEYS if k in tm}
+    ev = events()              # fsi_get_solver_events: run totals, no timer is resolved and a timer reset does not zero them (ADVICE r4)
+    return {k: int(ev[k]) for k in SOLVER_EVENT_KEYS if k in ev}
 
 
 def _rank() -> int:

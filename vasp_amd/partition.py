@@ -26,6 +26,7 @@ with host staging only for rehearsals with several ranks on one card).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -335,7 +336,7 @@ class DistBackend:
         self.control = control
         self._pending_bc = self._pending_P = None
         self._flow_stats = None
-        import os
+        self._flow_stats_valid = False           # DistBackend's own: cleared by newton_solve / set_state / shift, set by flow_stats
         # Overlap of the restricted Schwarz preconditioner, in node layers.  Measured on the 1.12 M-tet bench mesh (5 steps from
         # rest, Krylov iterations; one context: 114): 2 ranks 138 / 124 / 118 with 2 / 3 / 4 layers (3.8 / 5.1 / 6.4 % ghost
         # cells), 4 ranks 140 / 127 / 120 / 115 with 2 / 3 / 4 / 6 layers (11 / 14 / 18 / 27 %): four layers keep the count within
@@ -483,6 +484,7 @@ class DistBackend:
         self.hb.set_interface_pressure(P)
 
     def newton_solve(self, **kw):
+        self._flow_stats_valid = False
         self._tell("newton_solve", **{k: v for k, v in kw.items() if k != "log"})       # (the log callable stays on rank 0)
         try:
             return self.hb.newton_solve(**kw)
@@ -493,6 +495,7 @@ class DistBackend:
             raise
 
     def shift(self):
+        self._flow_stats_valid = False
         self._tell("shift")
         self.hb.shift()
 
@@ -511,6 +514,9 @@ class DistBackend:
     def set_chebyshev(self, **kw):
         self._tell("set_chebyshev", **kw)
         self.hb.set_chebyshev(**kw)
+
+    def solver_events(self):
+        return self.hb.solver_events()         # the library agrees on these events across ranks: rank 0's counts are the job's
 
     def timers(self, reset=False):
         if reset:
@@ -560,9 +566,9 @@ class DistBackend:
 
     def flow_stats(self):
         """HipBackend.flow_stats over the whole job: every rank contributes the cells it owns (fsi_flow_stats counts those)."""
-        if self._flow_stats is not None and self.hb._flow_stats is not None:
-            return self._flow_stats            # second request of a step: every driving rank makes the same decision (the state
-                                               # changed on all of them or on none); a worker is only here when rank 0 was not
+        if self._flow_stats_valid:             # second request of a step.  The flag is DistBackend's own (cleared by newton_solve /
+            return self._flow_stats            # set_state / shift, set after the reductions): a rank without owned cells never
+                                               # calls hb.flow_stats(), so hb's cache says nothing about it (ADVICE r4)
         self._tell("flow_stats")
         n = self.part.num_owned_cells
         mean, mn, mx, mj = self.hb.flow_stats() if n > 0 else (0.0, np.inf, -np.inf, np.inf)
@@ -570,6 +576,7 @@ class DistBackend:
         lo = self._reduce([mn, mj], "min")
         hi = self._reduce([mx], "max")
         self._flow_stats = (float(tot[0] / max(tot[1], 1.0)), float(lo[0]), float(hi[0]), float(lo[1]))
+        self._flow_stats_valid = True
         return self._flow_stats
 
     def probe(self, cells, bary):
@@ -601,6 +608,7 @@ class DistBackend:
         return self._reduce(out, "sum")
 
     def set_state(self, which, x_global):
+        self._flow_stats_valid = False
         self._tell("set_state", which, x_global)
         self.hb.set_state(which, self.part.restrict(x_global))
 
@@ -680,21 +688,54 @@ def run_worker(dist, device: int = 0) -> None:
     serve(db, control)
 
 
+# Backend calls whose FsiError the library agrees on across the ranks (a linear or Newton failure is all-reduced before any rank
+# returns, fsi_set_partition / test_a_rank_local_failure_is_raised_on_every_rank_instead_of_hanging): rank 0 raises the same error
+# from the same call and decides what happens next, so a worker may keep listening after one of these - and after nothing else.
+AGREED_FAILURES = ("newton_solve", "solve", "assemble_jacobian")
+
+
 def serve(db: "DistBackend", control: ControlChannel) -> None:
-    last_error = None
+    """The worker's loop.  An FsiError from one of AGREED_FAILURES is rank 0's to handle (it sees the same one).  ANY other
+    exception is rank-local - a Python error in probe / get_values / set_state, an out-of-memory while a message is unpickled, an
+    FsiError from a call that is not collective inside the library - and rank 0 is then blocked in the matching all-reduce,
+    all-gather or RCCL call for ever: the worker logs it, closes its backend and leaves the process with a non-zero status, so
+    that the launcher (torch.distributed.run) tears the whole job down instead of letting it hang."""
+    from .capi import FsiError
     while True:
-        op, args, kw, pending = control.listen()
-        if "bc" in pending:
-            db.set_dirichlet_values(pending["bc"])
-        if "P" in pending:
-            db.set_interface_pressure(pending["P"])
-        if op == "close":
-            db.close()
-            return
-        if op == "flow_stats":
-            db._flow_stats = None              # rank 0 announced the call, so it is making the reductions: take part
+        op = "listen"
         try:
+            op, args, kw, pending = control.listen()
+            if "bc" in pending:
+                db.set_dirichlet_values(pending["bc"])
+            if "P" in pending:
+                db.set_interface_pressure(pending["P"])
+            if op == "close":
+                db.close()
+                return
+            if op == "flow_stats":
+                db._flow_stats_valid = False   # rank 0 announced the call, so it is making the reductions: take part
             getattr(db, op)(*args, **kw)
-        except Exception as e:            # the library agrees on failures across ranks: rank 0 raises the same error and decides
-            last_error = e
-    return last_error
+        except FsiError as e:
+            if op in AGREED_FAILURES:          # every rank got it; rank 0 decides (refresh and retry, stop, re-raise)
+                continue
+            _worker_abort(db, op, e)
+        except Exception as e:                 # noqa: BLE001 - anything rank-local ends this process
+            _worker_abort(db, op, e)
+
+
+def _worker_abort(db: "DistBackend", op: str, e: BaseException) -> None:
+    import sys
+    import traceback
+    print(f"vasp_amd.partition: worker rank {db.rank} failed in '{op}': {type(e).__name__}: {e}; leaving the job "
+          f"(the launcher ends the other ranks)", file=sys.stderr, flush=True)
+    traceback.print_exc()
+    try:
+        db.hb.close()
+    except Exception:                          # noqa: BLE001 - the context may be what failed
+        pass
+    sys.stderr.flush()
+    os._exit(WORKER_EXIT_CODE)                 # a plain exit of THIS process (no re-exec); skips the process group's teardown,
+                                               # which would wait for the ranks that are blocked in a collective
+
+
+WORKER_EXIT_CODE = 17
