@@ -16,6 +16,15 @@ the cells of the nodes it owns, one owner->ghost halo exchange and a few scalar 
 RCCL; total work is fixed, so `scaling` is "strong" and `value` is the Newton rate of the one job.
 (VASPFSI_DIST_BACKEND=gloo VASPFSI_ONE_GPU=1 rehearses N ranks on a single card with host-staged exchanges.)
 
+Storage precisions.  BASELINE.json configs[1] reads "FP64": the HEADLINE run (``--storage fp64``, the default) keeps every array
+of the solver in FP64 (Krylov basis, the Jacobian in every product, Schur sweeps; FP32 only where the preconditioner's sweeps ran
+in FP32 from round 1) and reports ``dtype: "f64"``.  The mixed-storage mode the library selects by itself (FP32 Krylov basis and
+Jacobian copy inside the iterations, FP16 preconditioner records; Newton residual, Jacobian, every accumulation and every
+linear-solve verdict FP64) is the same 20 steps once more in a child process: ``value_mixed_storage`` (``--storage mixed`` makes
+it the main run, with ``dtype`` saying so).
+
+``--tets-per-gpu T`` (BASELINE.json configs[4]: 10 M tets on 8 GPUs): the mesh grows with the number of ranks, ``scaling: "weak"``.
+
 Output: ONE JSON line on rank 0: metric, value, `roofline` of the kernel group with the largest share of GPU time in the
 timed region (orthogonalisation kernels included, their bytes exact from the number of columns streamed), `kernels` (the
 whole table the choice was made from), `cpu_baseline`.
@@ -61,19 +70,20 @@ def self_launch(args) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()),
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--tets", str(args.tets),
-           "--dt", str(args.dt), "--storage", args.storage] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+           "--dt", str(args.dt), "--storage", args.storage] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []) \
+          + (["--tets-per-gpu", str(args.tets_per_gpu)] if args.tets_per_gpu else [])
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
 
 
-def fp64_storage_run(args) -> dict:
-    """The same workload once more in a fresh child process with every storage-precision choice switched off
-    (FP64_STORAGE_ENV): BASELINE.json configs[1] says "FP64", and the headline run keeps the Krylov basis, the Jacobian
-    copy of the inner products and the preconditioner matrices in FP32 / FP16 storage (all arithmetic on the Newton level
-    and every linear-solve verdict is FP64 in both).  This process has released its context before the child starts."""
+def other_storage_run(args, storage: str) -> dict:
+    """The same workload once more in a fresh child process in the OTHER storage mode ("mixed" beside the FP64 headline, "fp64"
+    beside a mixed main run): all arithmetic on the Newton level and every linear-solve verdict is FP64 in both; what differs is
+    the storage of the Krylov basis, of the Jacobian copy used inside the iterations and of the preconditioner's matrices.  This
+    process has released its context before the child starts."""
     cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--tets", str(args.tets), "--dt", str(args.dt), "--no-cpu-baseline", "--storage", "fp64", "--no-fp64-line"]
+           "--tets", str(args.tets), "--dt", str(args.dt), "--no-cpu-baseline", "--storage", storage, "--no-side-line"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     t0 = time.perf_counter()
     res = subprocess.run(cmd, env=env, capture_output=True, text=True)
@@ -82,18 +92,32 @@ def fp64_storage_run(args) -> dict:
         return {"error": f"child exited with {res.returncode}", "stderr_tail": res.stderr[-400:]}
     j = json.loads(line)
     return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "newton_iterations": j["newton_iterations"],
-            "krylov_iterations": j["krylov_iterations"], "phase_ms": j["phase_ms"], "env": FP64_STORAGE_ENV,
+            "krylov_iterations": j["krylov_iterations"], "phase_ms": j["phase_ms"], "dtype": j["dtype"],
+            "env": FP64_STORAGE_ENV if storage == "fp64" else {},
             "storage_precisions": j["config"]["storage_precisions"], "roofline": j["roofline"], "wall_s": time.perf_counter() - t0}
 
 
-def cpu_baseline(budget_s: float = 25.0):
-    """The CPU port of the same algorithm (oracle/cpu_port.py) timed on the host cores on a bounded sample of the bench
-    workload: the offset-stenosis problem on a 48 000-tet mesh of the same generator ("assembly + SpMV +
-    Krylov" for config 2's CPU leg) - C element routines and the monolithic SpMV under OpenMP on all cores, the HIP path's
-    field-split preconditioner with scipy's incomplete LU as inner solver, recycled GCR; the refresh step and ``budget_s`` of
-    steady steps of one Jacobian lifetime."""
-    from oracle.cpu_port import timed_krylov_run
-    return timed_krylov_run(budget_s, tets=int(os.environ.get("VASPFSI_CPU_BASELINE_TETS", 48000)))
+def cpu_baseline(desc, gpu: dict, budget_s: float = 25.0):
+    """The CPU port of the same algorithm (oracle/cpu_port.py) timed on the host cores, two legs:
+    (i) ``kernels``: residual assembly, Jacobian element arithmetic and the monolithic CSR product ON THE BENCH MESH ITSELF
+    (``desc``: the 1.12 M-tet mesh the GPU run just used), C under OpenMP on all cores, seconds each, in tets/s and GB/s with the
+    GPU kernels' figures of this run beside them; (ii) the whole quasi-Newton loop with the HIP path's field-split preconditioner
+    (scipy incomplete LU as inner solves) and recycled GCR on a SMALL mesh of the same generator (``krylov_sample_tets``) - its
+    serial inner solves do not fit the bench mesh into a bench run.  `value` is leg (ii)'s Newton rate (the metric's unit)."""
+    from oracle.cpu_port import full_mesh_kernels, timed_krylov_run
+    sample = int(os.environ.get("VASPFSI_CPU_BASELINE_TETS", 48000))
+    out = timed_krylov_run(budget_s, tets=sample)
+    out["krylov_sample_tets"] = out.pop("tets")
+    out["krylov_sample_dofs"] = out.pop("dofs")
+    if not os.environ.get("VASPFSI_NO_CPU_KERNEL_LEG"):
+        k = full_mesh_kernels(desc, budget_s=float(os.environ.get("VASPFSI_CPU_KERNEL_BUDGET_S", 15.0)))
+        k["gpu_same_run"] = gpu            # the GPU kernels of this run on the same mesh, same units
+        out["kernels"] = k
+        out["sample"] = (f"(i) kernels: the bench mesh itself, {k['tets']} tets - residual assembly {k['residual_assembly']['assemblies']}x "
+                         f"whole mesh, Jacobian element arithmetic on {k['jacobian_elements']['tets']} consecutive tets, "
+                         + (f"CSR product {k['spmv']['products']}x on the mesh's own {k['spmv']['nnz']}-entry pattern" if "nnz" in k["spmv"] else "CSR product skipped")
+                         + f", {k['cores']} threads; (ii) Newton loop: " + out["sample"])
+    return out
 
 
 def main():
@@ -104,13 +128,22 @@ def main():
     ap.add_argument("--tets", type=int, default=int(os.environ.get("VASPFSI_BENCH_TETS", 1000000)))
     ap.add_argument("--dt", type=float, default=1e-3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--storage", choices=("default", "fp64"), default="default",
-                    help="fp64: every storage-precision choice off (FP64 Krylov basis, FP64 Jacobian in every product, FP64 "
-                         "Schur sweeps, FP32 instead of FP16 sweep matrices) - BASELINE.json configs[1] read literally")
-    ap.add_argument("--no-fp64-line", action="store_true", help="skip the second run that fills value_fp64_storage")
+    ap.add_argument("--storage", choices=("fp64", "mixed", "default"), default="fp64",
+                    help="fp64 (the headline: BASELINE.json configs[1] says FP64): every storage-precision choice off - FP64 Krylov "
+                         "basis, FP64 Jacobian in every product, FP64 Schur sweeps, FP32 instead of FP16 sweep matrices; mixed "
+                         "(= default, the library's own policy): FP32 basis and Jacobian copy inside the iterations, FP16 records")
+    ap.add_argument("--no-side-line", "--no-fp64-line", dest="no_side_line", action="store_true",
+                    help="skip the second run in the other storage mode (value_mixed_storage / value_fp64_storage)")
+    ap.add_argument("--tets-per-gpu", type=int, default=0,
+                    help="weak scaling (BASELINE.json configs[4]: 10 M tets on 8 GPUs = 1 250 000 per GPU): the mesh has about "
+                         "this many tets per rank, `scaling` is \"weak\"")
     ap.add_argument("--profile-host", action="store_true", help="wall time of pre_solve / boundary data / Newton solve / shift / "
                                                                 "post_solve per step in the JSON line (host_ms_per_step)")
     args = ap.parse_args()
+    if args.storage == "default":
+        args.storage = "mixed"
+    if args.tets_per_gpu:
+        args.tets = args.tets_per_gpu * max(1, args.gpus)
     if args.storage == "fp64":           # read by fsi_create (getenv), so set before the library is touched
         os.environ.update(FP64_STORAGE_ENV)
 
@@ -310,7 +343,9 @@ def main():
         # launch sets are identical).  Their ratio is what the counters say about wasted traffic; `traffic` below is that ratio
         # applied to this run's algorithmic bytes per launch, i.e. on the basis of `algorithmic_bytes_per_launch`.
         traffic, traffic_source, traffic_ratio = None, None, None
-        pmc = next((q for q in (ROOT / "profiles" / "r04_pmc_traffic.json",) if q.exists()), None)
+        # (a profile of the same storage mode only: r05_pmc_traffic_<mode>.json; round 4's file was a mixed-storage run)
+        cands = [ROOT / "profiles" / f"r05_pmc_traffic_{args.storage}.json"] + ([ROOT / "profiles" / "r04_pmc_traffic.json"] if args.storage == "mixed" else [])
+        pmc = next((q for q in cands if q.exists()), None)
         if pmc is not None and world == 1:
             with contextlib.suppress(Exception):
                 pj = json.loads(pmc.read_text())
@@ -333,11 +368,20 @@ def main():
             "metric": "Newton-iterations/sec (offset_stenosis, monolithic ALE-FSI step)",
             "value": total_newton / elapsed, "unit": "Newton-iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong",       # one problem of fixed size, partitioned over the N ranks
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            # one problem partitioned over the N ranks: of fixed size ("strong": the north star's >= 5x at 8 GPUs), or - with
+            # --tets-per-gpu - of a size that grows with N ("weak": BASELINE.json configs[4])
+            "scaling": "weak" if args.tets_per_gpu else "strong",
+            "vs_baseline": None,
+            # what ran: "f64" only when every array of the solver is stored in FP64 (the headline); the mixed mode computes its
+            # Newton residual, Jacobian, accumulations and verdicts in FP64 on FP32 / FP16 STORAGE of the Krylov basis, the Jacobian
+            # copy of the inner products and the preconditioner's records, and says so
+            "dtype": "f64" if args.storage == "fp64" else "f64 (Newton residual, Jacobian, accumulations, verdicts) / f32 Krylov-basis and Jacobian-copy storage / f16 preconditioner records",
+            "data": "synthetic",
             "config": {"workload": f"offset_stenosis synthetic mesh, {C} tets, {ndof} dofs, dt={args.dt}, theta=0.501, "
                                    f"quasi-Newton atol=rtol=1e-6 recompute_tstep={ns['recompute_tstep']}, "
-                                   f"per step: pre_solve, Newton solve, shift, post_solve (no file output)",
+                                   f"per step: pre_solve, Newton solve, shift, post_solve (no file output); storage: "
+                                   + ("all-FP64 (BASELINE.json configs[1])" if args.storage == "fp64" else "mixed (FP32 Krylov basis / Jacobian copy, FP16 preconditioner records)")
+                                   + (f"; weak scaling, {args.tets_per_gpu} tets per GPU asked for" if args.tets_per_gpu else ""),
                        "tets": C, "dofs": ndof, "matrix_nnz": nnz, "parallelism": (f"element partition over {world} ranks (node slabs, ghost-layer cells {C_all / C - 1:.1%}), "
                                        f"halo + all-reduce over {dist.get_backend()}") if partitioned else "1 GPU",
                        "rank0_matrix_nnz": nnz,
@@ -383,13 +427,24 @@ def main():
     hb.close()                 # the context's HBM (Krylov store, matrices) is free again before anything else runs
     if rank == 0:
         out["config"]["storage"] = args.storage
-        if world == 1 and args.storage == "default" and not args.no_fp64_line:
-            f64 = fp64_storage_run(args)
-            out["value_fp64_storage"] = f64.get("value")        # Newton-iterations/s of the same 20 steps, all-FP64 storage
-            out["ms_per_step_fp64_storage"] = f64.get("ms_per_step")
-            out["fp64_storage"] = f64
+        if world == 1 and not args.no_side_line:      # the same steps once more in the other storage mode
+            other = "mixed" if args.storage == "fp64" else "fp64"
+            side = other_storage_run(args, other)
+            out[f"value_{other}_storage"] = side.get("value")        # Newton-iterations/s of the same 20 steps
+            out[f"ms_per_step_{other}_storage"] = side.get("ms_per_step")
+            out[f"{other}_storage"] = side
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            res_k = next(v for k, v in table.items() if k.startswith("k_residual"))
+            jac_k = next(v for k, v in table.items() if k.startswith("k_jacobian"))
+            spmv_k = next(v for k, v in table.items() if k.startswith("k_spmv"))
+            gpu = {"residual_assembly": {"tets_per_s": C / (res_k["avg_launch_ms"] * 1e-3) if res_k["launches"] else None,
+                                         "GBps_algorithmic": res_k["achieved_GBps"], "seconds_per_assembly": res_k["avg_launch_ms"] * 1e-3},
+                   "jacobian_assembly": {"tets_per_s": C / (jac_k["avg_launch_ms"] * 1e-3) if jac_k["launches"] else None,
+                                         "seconds_per_assembly": jac_k["avg_launch_ms"] * 1e-3,
+                                         "note": "k_jacobian incl. the scatter into the CSR matrix and the matrix finish"},
+                   "spmv": {"GBps_algorithmic": spmv_k["achieved_GBps"], "seconds_per_product": spmv_k["avg_launch_ms"] * 1e-3,
+                            "note": "k_spmv_node6: one i32 column per six entries (8.67 B per entry against the CPU port's 12)"}}
+            out["cpu_baseline"] = cpu_baseline(desc, gpu)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

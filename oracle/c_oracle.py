@@ -47,6 +47,15 @@ def load(build_if_missing: bool = True):
     lib.fsi_c_spmv.argtypes = [i64, vp, vp, vp, vp, vp]
     lib.fsi_c_spmv.restype = None
     lib.fsi_c_num_threads.restype = C.c_int
+    full = [i64, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, dbl, dbl, dbl, vp, vp, vp, vp, vp, vp, vp]
+    lib.fsi_c_assemble_residual.argtypes = full
+    lib.fsi_c_assemble_residual.restype = None
+    lib.fsi_c_jacobian_elements.argtypes = full
+    lib.fsi_c_jacobian_elements.restype = None
+    lib.fsi_c_node_graph.argtypes = [i64, vp, vp, vp, vp, vp, vp]
+    lib.fsi_c_node_graph.restype = None
+    lib.fsi_c_monolithic_pattern.argtypes = [i64, i64, vp, vp, vp, vp, vp]
+    lib.fsi_c_monolithic_pattern.restype = None
     _lib = lib
     return lib
 

@@ -310,3 +310,149 @@ def timed_krylov_run(budget_s: float = 30.0, tets: int = 48000, max_steps: int =
             "phase_s": phase, "setup_s": t_setup, "krylov_iterations": kry_total, "preconditioner_applications": ks.applies,
             "lifetime_steps": max_steps, "tets": int(len(o.tets)), "dofs": int(o.ndof),
             "dof_updates_per_s": life_its / life_s * o.ndof, "host_cpus": os.cpu_count()}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Kernel legs on the bench mesh ITSELF (round 5): residual assembly, Jacobian element arithmetic and the
+# monolithic SpMV of the CPU port at config 2's size, all host cores, seconds
+# ---------------------------------------------------------------------------------------------------------------------
+class FullMeshKernels:
+    """The C/OpenMP element routines and the CSR product on a mesh of any size without FsiOracle's per-cell tables (its
+    physical-gradient array alone is 6.5 GB at 1.12 M tets): states are gathered cell by cell inside the C loops
+    (oracle/fsi_oracle_c.c: fsi_c_assemble_residual / fsi_c_jacobian_elements), and the monolithic matrix's sparsity pattern is
+    built from the P2 node graph in C (fsi_c_node_graph / fsi_c_monolithic_pattern) - the same pattern ``CElements.pattern``
+    builds with scipy for the small cases (tests/test_oracle_c.py holds the two together)."""
+
+    def __init__(self, desc):
+        from . import c_oracle
+        from .fsi_oracle import DELTA, keast24, tabulate_p2
+        self.lib = c_oracle.load()
+        if self.lib is None:
+            raise RuntimeError("oracle/libfsi_oracle_c.so is missing (make -C oracle)")
+        self._p = c_oracle._p
+        self.coords = np.ascontiguousarray(desc["coords"], dtype=np.float64)
+        self.tets = np.ascontiguousarray(desc["tets"], dtype=np.int32)
+        self.tn = np.ascontiguousarray(desc["tet_nodes"], dtype=np.int32)
+        self.N2, self.V, self.C = int(desc["num_nodes"]), len(self.coords), len(self.tets)
+        self.ndof = 6 * self.N2 + self.V
+        self.kind = np.ascontiguousarray(desc["cell_kind"], dtype=np.int32)
+        self.region = np.ascontiguousarray(desc["cell_region"], dtype=np.int32)
+        self.fprops = np.ascontiguousarray(np.asarray(desc["fluid_props"], dtype=np.float64).reshape(-1, 2))
+        rows = [tuple(r) + (0.0,) * (6 - len(r)) for r in desc["solid_props"]]
+        self.sprops = np.ascontiguousarray(np.asarray(rows, dtype=np.float64).reshape(-1, 6))
+        self.smodels = np.ascontiguousarray(desc.get("solid_models", [0] * len(rows)), dtype=np.int32)
+        self.dt, self.theta, self.delta = float(desc["dt"]), float(desc["theta"]), float(DELTA)
+        qp, qw = keast24()
+        N, dN, L, _ = tabulate_p2(qp)
+        self.tab = [np.ascontiguousarray(a) for a in (N, dN, L, qw)]
+
+    def _args(self, c0, c1, U, U1, out):
+        p = self._p
+        return (c0, c1, p(self.coords), p(self.tets), p(self.tn), self.N2, p(self.kind), p(self.region), p(self.fprops), p(self.sprops),
+                p(self.smodels), self.dt, self.theta, self.delta, *[p(a) for a in self.tab], p(U), p(U1), p(out))
+
+    def assemble_residual(self, U, U1, F=None, cells=None):
+        """F += sum over the cells [c0, c1) of (Rl + Rn) scattered to the dofs: the volume part of assemble(F)."""
+        c0, c1 = cells if cells is not None else (0, self.C)
+        F = np.zeros(self.ndof) if F is None else F
+        self.lib.fsi_c_assemble_residual(*self._args(c0, c1, U, U1, F))
+        return F
+
+    def jacobian_elements(self, U, U1, c0, c1):
+        """Complex-step element Jacobians (both parts of the split) of the cells [c0, c1); returns one checksum per cell."""
+        out = np.empty(c1 - c0)
+        self.lib.fsi_c_jacobian_elements(*self._args(c0, c1, U, U1, out))
+        return out
+
+    def pattern(self):
+        """(indptr, indices, data) of the monolithic CSR matrix on the mesh's own sparsity pattern; ``data`` holds deterministic
+        stand-in values (the product's time does not depend on them), first touched by the threads that stream them."""
+        p = self._p
+        flat = self.tn.ravel()
+        order = np.argsort(flat, kind="stable")
+        inc = (order // 10).astype(np.int32)
+        inc_ptr = np.zeros(self.N2 + 1, dtype=np.int64)
+        np.cumsum(np.bincount(flat, minlength=self.N2), out=inc_ptr[1:])
+        deg = np.empty(self.N2, dtype=np.int32)
+        self.lib.fsi_c_node_graph(self.N2, p(self.tn), p(inc_ptr), p(inc), None, None, p(deg))
+        g_ptr = np.zeros(self.N2 + 1, dtype=np.int64)
+        np.cumsum(deg, out=g_ptr[1:])
+        g_idx = np.empty(int(g_ptr[-1]), dtype=np.int32)
+        self.lib.fsi_c_node_graph(self.N2, p(self.tn), p(inc_ptr), p(inc), p(g_ptr), p(g_idx), None)
+        degv = np.add.reduceat((g_idx < self.V).astype(np.int64), g_ptr[:-1])          # vertex neighbours of every node
+        rowlen_node = 6 * deg.astype(np.int64) + degv
+        rowlen = np.concatenate([np.repeat(rowlen_node, 3), np.repeat(rowlen_node, 3), rowlen_node[:self.V]])
+        indptr = np.zeros(self.ndof + 1, dtype=np.int64)
+        np.cumsum(rowlen, out=indptr[1:])
+        nnz = int(indptr[-1])
+        indices, data = np.empty(nnz, dtype=np.int32), np.empty(nnz)
+        self.lib.fsi_c_monolithic_pattern(self.N2, self.V, p(g_ptr), p(g_idx), p(indptr), p(indices), p(data))
+        return indptr, indices, data
+
+    def spmv(self, indptr, indices, data, x, y):
+        p = self._p
+        self.lib.fsi_c_spmv(self.ndof, p(indptr), p(indices), p(data), p(x), p(y))
+        return y
+
+
+def full_mesh_kernels(desc, budget_s: float = 12.0, max_nnz: float = 2.5e9) -> dict:
+    """Residual assembly (whole mesh), Jacobian element arithmetic (a bounded run of consecutive cells of the same mesh) and the
+    monolithic CSR product (whole matrix pattern) of the CPU port on ``desc``'s mesh - bench.py passes the 1.12 M-tet bench mesh.
+    Rates in the units the GPU kernels are reported in: tets/s and GB/s of algorithmic bytes (12 B per entry +
+    20 B per row for CSR f64 + i32)."""
+    t_all = time.perf_counter()
+    k = FullMeshKernels(desc)
+    cores = k.lib.fsi_c_num_threads()
+    rng = np.random.default_rng(0)
+    h = float(np.abs(k.coords[k.tets[0, 1]] - k.coords[k.tets[0, 0]]).max())
+    U, U1 = np.zeros(k.ndof), np.zeros(k.ndof)                       # a small smooth-ish state: no cell is degenerate, no term vanishes
+    U[:3 * k.N2] = 1e-3 * h * rng.standard_normal(3 * k.N2)
+    U1[:3 * k.N2] = 0.9 * U[:3 * k.N2]
+    U[3 * k.N2:6 * k.N2] = 0.1 * rng.standard_normal(3 * k.N2)
+    U1[3 * k.N2:6 * k.N2] = 0.9 * U[3 * k.N2:6 * k.N2]
+    U[6 * k.N2:] = rng.standard_normal(k.V)
+    out = {"cores": int(cores), "tets": int(k.C), "dofs": int(k.ndof), "host_cpus": os.cpu_count()}
+    # residual assembly: whole mesh, repeated while the budget lasts (at least once)
+    F = np.zeros(k.ndof)
+    k.assemble_residual(U, U1, F, cells=(0, min(k.C, 4096)))            # page in the tables / code
+    t0, reps = time.perf_counter(), 0
+    while reps < 1 or (time.perf_counter() - t0 < budget_s / 3 and reps < 5):
+        F[:] = 0.0
+        k.assemble_residual(U, U1, F)
+        reps += 1
+    dt_res = (time.perf_counter() - t0) / reps
+    out["residual_assembly"] = {"seconds_per_assembly": dt_res, "tets_per_s": k.C / dt_res, "assemblies": reps,
+                                "GBps_algorithmic": k.C * 1676.0 / dt_res / 1e9, "checksum": float(np.abs(F).sum())}
+    # Jacobian element arithmetic: consecutive chunks from the middle of the mesh until a third of the budget is used
+    chunk, c0 = max(cores * 16, 1024), k.C // 2
+    t0, done = time.perf_counter(), 0
+    while done == 0 or (time.perf_counter() - t0 < budget_s / 3 and c0 + chunk <= k.C):
+        k.jacobian_elements(U, U1, c0, min(k.C, c0 + chunk))
+        done += min(k.C, c0 + chunk) - c0
+        c0 += chunk
+    dt_jac = time.perf_counter() - t0
+    out["jacobian_elements"] = {"tets": int(done), "seconds": dt_jac, "tets_per_s": done / dt_jac,
+                                "seconds_for_the_whole_mesh_at_this_rate": k.C / (done / dt_jac),
+                                "note": "complex-step element Jacobians of both parts of the split (64 complex residual evaluations "
+                                        "per cell), no scatter into the CSR matrix"}
+    # monolithic product on the mesh's own pattern
+    est_nnz = 1530.0 * k.C
+    if est_nnz <= max_nnz:
+        t0 = time.perf_counter()
+        indptr, indices, data = k.pattern()
+        t_pat = time.perf_counter() - t0
+        x, y = np.ones(k.ndof), np.empty(k.ndof)
+        k.spmv(indptr, indices, data, x, y)
+        t0, reps = time.perf_counter(), 0
+        while reps < 2 or (time.perf_counter() - t0 < budget_s / 3 and reps < 20):
+            k.spmv(indptr, indices, data, x, y)
+            reps += 1
+        dt_spmv = (time.perf_counter() - t0) / reps
+        nnz = int(indptr[-1])
+        out["spmv"] = {"nnz": nnz, "seconds_per_product": dt_spmv, "products": reps,
+                       "GBps_algorithmic": (nnz * 12.0 + k.ndof * 20.0) / dt_spmv / 1e9, "pattern_build_s": t_pat,
+                       "note": "CSR f64 + i32 on the bench mesh's own sparsity pattern (values: stand-ins, first touched in parallel)"}
+    else:
+        out["spmv"] = {"skipped": f"estimated {est_nnz:.2e} entries exceed the host-memory bound of this leg ({max_nnz:.1e})"}
+    out["wall_s"] = time.perf_counter() - t_all
+    return out

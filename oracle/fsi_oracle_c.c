@@ -165,3 +165,121 @@ int fsi_c_num_threads(void) {
   return 1;
 #endif
 }
+
+/* ---- bench.py's CPU leg on the full bench mesh (oracle/cpu_port.py: full_mesh_kernels) ---------------------------------
+ * The monolithic matrix's sparsity pattern straight from the P2 node graph, without scipy: DOLFIN's dofmap-based pattern
+ * couples every field over the node graph (rows d / v of node a: the six d and v dofs of every neighbour node b and the
+ * pressure dof of every neighbour VERTEX; pressure row of vertex a: the same columns).  Layout of FsiOracle: [d: 3 N2 | v:
+ * 3 N2 | p: V], component-minor; vertices are the first V nodes. */
+
+/* node graph: neighbours of node a = all nodes of the cells around a (a itself included), ascending.  inc_ptr / inc: cells
+ * around each node.  Pass 1 (g_idx == NULL): deg[a].  Pass 2: g_idx filled at g_ptr[a]. */
+void fsi_c_node_graph(int64_t N2, const int32_t* tn, const int64_t* inc_ptr, const int32_t* inc, const int64_t* g_ptr,
+                      int32_t* g_idx, int32_t* deg) {
+#pragma omp parallel
+  {
+    int32_t* buf = (int32_t*)malloc(4096 * sizeof(int32_t));
+    int64_t cap = 4096;
+#pragma omp for schedule(dynamic, 1024)
+    for (int64_t a = 0; a < N2; ++a) {
+      const int64_t nc = inc_ptr[a + 1] - inc_ptr[a];
+      if (10 * nc > cap) { cap = 20 * nc; buf = (int32_t*)realloc(buf, cap * sizeof(int32_t)); }
+      int64_t m = 0;
+      for (int64_t t = inc_ptr[a]; t < inc_ptr[a + 1]; ++t)
+        for (int k = 0; k < 10; ++k) buf[m++] = tn[10 * (int64_t)inc[t] + k];
+      for (int64_t i = 1; i < m; ++i) {          /* insertion sort: ~250 entries, mostly runs */
+        const int32_t v = buf[i];
+        int64_t j = i - 1;
+        while (j >= 0 && buf[j] > v) { buf[j + 1] = buf[j]; --j; }
+        buf[j + 1] = v;
+      }
+      int64_t u = 0;
+      for (int64_t i = 0; i < m; ++i)
+        if (i == 0 || buf[i] != buf[i - 1]) buf[u++] = buf[i];
+      if (g_idx) memcpy(g_idx + g_ptr[a], buf, u * sizeof(int32_t));
+      else deg[a] = (int32_t)u;
+    }
+    free(buf);
+  }
+}
+
+/* column indices (and deterministic stand-in values, first touched by the thread that will stream them) of the monolithic
+ * CSR matrix on that pattern; indptr from the caller (row lengths 6 deg(a) + degV(a)). */
+void fsi_c_monolithic_pattern(int64_t N2, int64_t V, const int64_t* g_ptr, const int32_t* g_idx, const int64_t* indptr,
+                              int32_t* indices, double* data) {
+  const int64_t n3 = 3 * N2, nrows = 6 * N2 + V;
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < nrows; ++r) {
+    const int64_t a = r < 2 * n3 ? (r % n3) / 3 : r - 2 * n3;
+    int64_t t = indptr[r];
+    for (int blk = 0; blk < 2; ++blk)
+      for (int64_t s = g_ptr[a]; s < g_ptr[a + 1]; ++s)
+        for (int c = 0; c < 3; ++c) indices[t++] = (int32_t)(blk * n3 + 3 * (int64_t)g_idx[s] + c);
+    for (int64_t s = g_ptr[a]; s < g_ptr[a + 1]; ++s)
+      if (g_idx[s] < V) indices[t++] = (int32_t)(2 * n3 + g_idx[s]);
+    for (int64_t s = indptr[r]; s < t; ++s) data[s] = 1.0 / (double)(1 + ((s * 2654435761u) & 1023));
+  }
+}
+
+/* element residuals of a RANGE of cells with the gather U[cell_dofs] done here (the full-mesh leg does not hold [C][64]
+ * copies of the states) and the scatter-add of Rl + Rn into F: one residual assembly as the port performs it. */
+void fsi_c_assemble_residual(int64_t c0, int64_t c1, const double* coords, const int32_t* tets, const int32_t* tn, int64_t N2,
+                             const int32_t* kind, const int32_t* region, const double* fluid_props, const double* solid_props,
+                             const int32_t* solid_models, double dt, double theta, double delta, const double* N,
+                             const double* dNref, const double* L, const double* qw, const double* U, const double* U1, double* F) {
+  const OracleTables T = {N, dNref, L, qw};
+#pragma omp parallel for schedule(static)
+  for (int64_t c = c0; c < c1; ++c) {
+    int64_t dofs[64];
+    double xc[12], loc[64], loc1[64], rl[64], rn[64];
+    for (int f = 0; f < 2; ++f)
+      for (int k = 0; k < 3; ++k)
+        for (int a = 0; a < 10; ++a) dofs[30 * f + 10 * k + a] = f * 3 * N2 + 3 * (int64_t)tn[10 * c + a] + k;
+    for (int a = 0; a < 4; ++a) dofs[60 + a] = 6 * N2 + tets[4 * c + a];
+    for (int a = 0; a < 4; ++a)
+      for (int k = 0; k < 3; ++k) xc[3 * a + k] = coords[3 * (int64_t)tets[4 * c + a] + k];
+    for (int a = 0; a < 64; ++a) { loc[a] = U[dofs[a]]; loc1[a] = U1[dofs[a]]; }
+    const int model = kind[c] == 1 ? solid_models[region[c]] : 0;
+    r_element(xc, kind[c], cell_props(kind[c], region[c], fluid_props, solid_props), model, dt, theta, delta, &T, loc, loc1, rl, rn);
+    for (int a = 0; a < 64; ++a) {
+#pragma omp atomic
+      F[dofs[a]] += rl[a] + rn[a];
+    }
+  }
+}
+
+/* element Jacobians (complex step, both parts) of a RANGE of cells with the same in-place gather; the 64 x 64 matrices are
+ * reduced to a checksum per cell (sum of the entries) instead of being stored: the element arithmetic of a Jacobian
+ * assembly without its scatter. */
+void fsi_c_jacobian_elements(int64_t c0, int64_t c1, const double* coords, const int32_t* tets, const int32_t* tn, int64_t N2,
+                             const int32_t* kind, const int32_t* region, const double* fluid_props, const double* solid_props,
+                             const int32_t* solid_models, double dt, double theta, double delta, const double* N,
+                             const double* dNref, const double* L, const double* qw, const double* U, const double* U1,
+                             double* checksum) {
+  const OracleTables T = {N, dNref, L, qw};
+  const double h = 1e-30;
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int64_t c = c0; c < c1; ++c) {
+    int64_t dofs[64];
+    double xc[12], loc1[64];
+    double complex z[64], rl[64], rn[64];
+    for (int f = 0; f < 2; ++f)
+      for (int k = 0; k < 3; ++k)
+        for (int a = 0; a < 10; ++a) dofs[30 * f + 10 * k + a] = f * 3 * N2 + 3 * (int64_t)tn[10 * c + a] + k;
+    for (int a = 0; a < 4; ++a) dofs[60 + a] = 6 * N2 + tets[4 * c + a];
+    for (int a = 0; a < 4; ++a)
+      for (int k = 0; k < 3; ++k) xc[3 * a + k] = coords[3 * (int64_t)tets[4 * c + a] + k];
+    for (int a = 0; a < 64; ++a) { z[a] = U[dofs[a]]; loc1[a] = U1[dofs[a]]; }
+    const int model = kind[c] == 1 ? solid_models[region[c]] : 0;
+    const double* props = cell_props(kind[c], region[c], fluid_props, solid_props);
+    double acc = 0.0;
+    for (int j = 0; j < 64; ++j) {
+      const double complex keep = z[j];
+      z[j] = keep + h * I;
+      c_element(xc, kind[c], props, model, dt, theta, delta, &T, z, loc1, rl, rn);
+      z[j] = keep;
+      for (int a = 0; a < 64; ++a) acc += (cimag(rl[a]) + cimag(rn[a])) / h;
+    }
+    checksum[c - c0] = acc;
+  }
+}

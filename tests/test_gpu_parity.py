@@ -604,6 +604,49 @@ def test_mooney_rivlin_matches_oracle(tmp_path):
     hb.close()
 
 
+@pytest.mark.parametrize("case_name", ["cylinder", "mooney_rivlin", "robin"])
+def test_mfma_jacobian_kernel_matches_the_complex_step_oracle(case_name, tmp_path):
+    """Row N1 under the driver's eyes: the context is created through ``fsi_create_tuned`` with
+    ``FsiTuning.jacobian_mfma = 1``, so the refresh runs ``k_jacobian_mfma`` (v-equation contraction on
+    ``v_mfma_f64_16x16x4_f64``), and the ASSEMBLED MATRIX is compared entry by entry with the oracle's complex-step Jacobian at
+    the bound of ``test_jacobian_spmv_and_solve_match_oracle`` - on the cylinder (StVK), the predeform problem (MooneyRivlin +
+    Robin, theta = 1) and the cylinder with an aneurysm-style Robin wall; the vector-pipe kernel of a second context must give
+    the same matrix to round-off."""
+    from oracle.fsi_oracle import FsiOracle
+    from vasp_amd.capi import HipBackend
+    if case_name == "mooney_rivlin":
+        case = prepare_case("predeform", GOLDEN / "cylinder" / "cylinder.h5", tmp_path, dt="0.01", T="0.02", theta="1.0")
+    else:
+        case = prepare_case("cylinder", GOLDEN / "cylinder" / "cylinder.h5", tmp_path)
+    ns, desc = case[0], dict(case[1])
+    mesh = ns["mesh"]
+    if case_name == "robin":
+        fids = np.nonzero(ns["boundaries"] == 33)[0]
+        desc["robin_facets"] = mesh.facet_nodes[fids]
+        desc["robin_k"] = np.full(len(fids), 1e5)
+        desc["robin_c"] = np.full(len(fids), 10.0)
+    o = FsiOracle(desc)
+    U, U1 = random_state(mesh, o.ndof, seed=11)
+    g, P = boundary_data(case, 0.05)
+    o.solver_setup(np.zeros(o.ndof), np.zeros(o.ndof))
+    A_ref = o.jacobian(U, U1)
+    rowmax = np.maximum(np.abs(A_ref).max(axis=1).toarray().ravel(), 1e-300)
+    mats = {}
+    for mfma in (1, 0):
+        hb = HipBackend(desc, tuning=dict(jacobian_mfma=mfma))
+        assert hb.tuning()["jacobian_mfma"] == mfma                        # the context really runs the kernel asked for
+        hb.set_state("n", U); hb.set_state("n-1", U1); hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+        hb.assemble_residual()
+        hb.assemble_jacobian()
+        mats[mfma] = hb.matrix()
+        hb.close()
+    rel = np.abs(mats[1] - A_ref).max(axis=1).toarray().ravel() / rowmax
+    bound = 1e-10 if case_name == "mooney_rivlin" else 1e-11                # (the product-level bounds of the tests above)
+    assert rel.max() < bound, (case_name, rel.max())
+    both = np.abs(mats[1] - mats[0]).max(axis=1).toarray().ravel() / rowmax
+    assert both.max() < 1e-13, (case_name, both.max())                     # two summation orders of the same contraction
+
+
 def test_predeform_runs(tmp_path):
     """REF tests/test_simulations.py:60-77: the predeform problem runs a few steps; printed flow properties are sane."""
     import re

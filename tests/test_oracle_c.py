@@ -66,3 +66,33 @@ def test_c_elements_match_numpy_mooney_rivlin(tmp_path, c_lib):
     sc, sn = FsiOracle(d2), FsiOracle(d2, impl="numpy")
     for a, b in zip(sc.element_jacobians(U, U1), sn.element_jacobians(U, U1)):
         assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max()
+
+
+def test_full_mesh_kernels_of_the_cpu_baseline_match_the_oracle(tmp_path, c_lib):
+    """bench.py's CPU leg on the bench mesh itself (oracle/cpu_port.py: FullMeshKernels - in-place gathers, the sparsity pattern
+    from the node graph in C) against the oracle's own routines on the cylinder fixture: the assembled volume residual to
+    round-off, the monolithic pattern index for index, the complex-step element Jacobians through their checksums."""
+    from oracle.cpu_port import FullMeshKernels, full_mesh_kernels
+    from oracle.fsi_oracle import FsiOracle
+    ns, desc, *_ = prepare_case("cylinder", GOLDEN / "cylinder" / "cylinder.h5", tmp_path)
+    o = FsiOracle(desc)
+    k = FullMeshKernels(desc)
+    U, U1 = _states(o, ns["mesh"], seed=5)
+    Rl, Rn = o.c.residuals(U, U1)
+    F_ref = o.c.assemble_vector(Rl + Rn)
+    F = k.assemble_residual(U, U1)
+    assert np.abs(F - F_ref).max() <= 1e-13 * np.abs(F_ref).max()
+    indptr, indices, data = k.pattern()
+    rp, ri = o.c.pattern()
+    assert np.array_equal(indptr, rp) and np.array_equal(indices, ri) and np.all(data > 0.0)
+    Jl, Jn = o.c.jacobians(U, U1)
+    cs = k.jacobian_elements(U, U1, 200, 232)
+    ref = (Jl + Jn)[200:232].sum(axis=(1, 2))
+    assert np.abs(cs - ref).max() <= 1e-10 * np.abs(ref).max()
+    x = np.random.default_rng(0).standard_normal(k.ndof)
+    import scipy.sparse as sp
+    A = sp.csr_matrix((data, indices, indptr), shape=(k.ndof, k.ndof))
+    assert np.abs(k.spmv(indptr, indices, data, x, np.empty(k.ndof)) - A @ x).max() <= 1e-12 * np.abs(A @ x).max()
+    r = full_mesh_kernels(desc, budget_s=0.6)
+    assert r["tets"] == 1647 and r["spmv"]["nnz"] == len(indices) and r["residual_assembly"]["tets_per_s"] > 0
+    assert r["jacobian_elements"]["tets"] > 0

@@ -10,6 +10,15 @@ the driver first streams a known number of bytes with 4-, 8-, 16- and 32-byte lo
 """
 import csv, json, sys
 
+if len(sys.argv) > 2 and sys.argv[1] == "--show":          # one line per kernel group of a file this script wrote
+    j = json.load(open(sys.argv[2]))
+    for k, g in j.get("groups", {}).items():
+        if isinstance(g, dict):
+            print("%-22s launches %6d (trace %6d)  PMC %9.1f MB / launch  algorithmic %9.1f MB  ratio %.2f" % (
+                k, g["launches"], g["trace_launches"], g["pmc_bytes_per_launch"] / 1e6, g["algorithmic_bytes_per_launch"] / 1e6,
+                g["traffic_over_algorithmic"]))
+    sys.exit(0)
+
 def load(path):
     out = {}
     for row in csv.DictReader(open(path)):
@@ -24,7 +33,8 @@ workload = {}
 if len(sys.argv) > 6:
     try:
         j = json.loads(open(sys.argv[6]).read().strip().splitlines()[-1])
-        workload = {"tets": j["config"]["tets"], "dofs": j["config"]["dofs"], "steps": j["steps"], "warmup": j["warmup"]}
+        workload = {"tets": j["config"]["tets"], "dofs": j["config"]["dofs"], "steps": j["steps"], "warmup": j["warmup"],
+                    "storage": j["config"].get("storage", "mixed")}
     except Exception as e:                      # the counters are still valid; only the tag is missing
         workload = {"workload_error": str(e)}
 def factor(table, kern, typ):
