@@ -85,6 +85,8 @@ def other_storage_run(args, storage: str) -> dict:
     cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--tets", str(args.tets), "--dt", str(args.dt), "--no-cpu-baseline", "--storage", storage, "--no-side-line"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    if storage == "mixed":          # this process exported the all-FP64 switches for its own context: the child must not inherit them
+        env = {k: v for k, v in env.items() if k not in FP64_STORAGE_ENV}
     t0 = time.perf_counter()
     res = subprocess.run(cmd, env=env, capture_output=True, text=True)
     line = next((ln for ln in reversed(res.stdout.splitlines()) if ln.startswith("{")), None)

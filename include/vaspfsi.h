@@ -144,6 +144,11 @@ typedef struct FsiTuning {
   double sbmg_alpha, sbmg_ckappa;                             /* ... smoothing interval [lmax / alpha, lmax], coarse kappa         */
   int32_t mg_pre, mg_post, mg_cits;                           /* displacement cycle                                                */
   double mg_alpha, mg_ckappa;
+  /* round 5 (fields are appended: struct_size tells an older caller's struct from this one) */
+  int32_t solid_coarse_exact;  /* 1: the solid cycle's coarse level is solved exactly - block cyclic reduction over breadth-first levels of
+                                * the solid vertices, operators refreshed with the Jacobian (csrc/fsi_bcr.hip) - instead of sbmg_cits sweeps */
+  int32_t reserved0;
+  double bcr_shift;            /* ... of A_c + bcr_shift * blockdiag(A_c): the floor below which the level's modes are damped, not inverted */
 } FsiTuning;
 void fsi_tuning_defaults(FsiTuning* t);
 /* (internal helper of fsi_get_tuning, exported so that the ABI test can exercise the size rule without a device) */
@@ -356,6 +361,19 @@ typedef struct FsiTimers {
                                                         checksums) and kept its coarse operator and eigenvalue estimate      */
   int64_t newton_late_solves;                        /* Newton iterations solved with the late (tighter) forcing term        */
 } FsiTimers;
+/* ---- the solid cycle's exact coarse solve (round 5, csrc/fsi_bcr.hip): test and planning hooks ---------------------------- */
+/* Host-only dry run of the planner on any symmetric vertex graph (no device): stats_out[8] = usable, blocks (BFS levels), largest
+ * block [unknowns], reduction levels, operator bytes (FP32), set-up arena bytes (FP64), set-up flops, launches per solve; pos_out /
+ * level_out (may be NULL): [nc] position in BFS-level order / BFS level of every node. */
+int fsi_bcr_plan_graph(int64_t nc, const int64_t* cptr, const int32_t* ccol, int64_t* stats_out, int32_t* pos_out, int32_t* level_out);
+/* out[12]: coarse nodes, 3x3 blocks, planned, ready (operators of the current Jacobian), BFS blocks, reduction levels, operator
+ * bytes, launches per solve, largest block, solves so far, set-up flops per refresh, two-level cycle ready */
+int fsi_solid_coarse_info(const FsiCtx* ctx, int64_t* out);
+/* the coarse level's block-CSR operator as the sweeps / the reduction see it: cptr[nc + 1], ccol[nblk], cvals[9 nblk] */
+int fsi_solid_coarse_matrix(FsiCtx* ctx, int64_t* cptr, int32_t* ccol, float* cvals);
+/* x = A_c^-1 rhs by the production kernels (3 doubles per coarse node) */
+int fsi_solid_coarse_solve(FsiCtx* ctx, const double* rhs, double* x);
+
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
 /* Run totals of the linear solver's events since fsi_create - out[0] newton_retries, out[1] fp32_fallbacks, out[2] gcr_restarts
  * (the FsiTimers fields of the same names count since the last reset) - without resolving the phase timers: no device

@@ -429,6 +429,62 @@ def test_properties_on_generated_mesh(tmp_path):
     hb.close()
 
 
+@pytest.mark.parametrize("which", ["fixture", "generated"])
+def test_exact_coarse_solve_matches_a_dense_factorisation(which, stenosis_case, tmp_path):
+    """The solid cycle's coarse level solved by block cyclic reduction (csrc/fsi_bcr.hip; round 5) against a sparse LU of the
+    same operator, read back from the device: offset-stenosis fixture (an unstructured wall) and a generated 50 k-tet mesh.
+    Operators are FP32, vectors FP64: the residual of the answer sits at FP32 round-off times the level's condition number."""
+    import scipy.sparse.linalg as spla
+    from vasp_amd.capi import HipBackend
+    if which == "fixture":
+        case = stenosis_case
+    else:
+        from vasp_amd.meshgen import write_mesh
+        write_mesh(tmp_path / "s.h5", 50000)
+        case = prepare_case("offset_stenosis", tmp_path / "s.h5", tmp_path / "run", dt="0.001", T="0.002")
+    desc = case[1]
+    hb = HipBackend(desc)
+    g, P = boundary_data(case, 0.01 if which == "fixture" else 1e-3)
+    hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+    hb.assemble_residual()
+    hb.assemble_jacobian()
+    info = hb.solid_coarse_info()
+    assert info["cycle_ready"] == 1 and info["planned"] == 1 and info["ready"] == 1, info
+    assert info["levels"] == int(np.ceil(np.log2(info["bfs_blocks"]))) and info["launches_per_solve"] == 2 * info["levels"] + 3
+    A, cptr, ccol = hb.solid_coarse_matrix()
+    n = A.shape[0]
+    rng = np.random.default_rng(0)
+    lu = spla.splu(A.tocsc())
+    for trial in range(3):
+        rhs = rng.standard_normal(n)
+        if trial == 2:                                   # a smooth right-hand side: the low modes the level exists for
+            rhs = A @ np.ones(n)
+        x = hb.solid_coarse_solve(rhs)
+        x_ref = lu.solve(rhs)
+        res = np.linalg.norm(A @ x - rhs) / np.linalg.norm(rhs)
+        err = np.linalg.norm(x - x_ref) / np.linalg.norm(x_ref)
+        assert res < 2e-4 and err < 2e-2, (which, trial, res, err)
+    # linear and repeatable: the same operator at every call (what the outer Krylov method relies on)
+    a, b = rng.standard_normal(n), rng.standard_normal(n)
+    xa, xb, xab = hb.solid_coarse_solve(a), hb.solid_coarse_solve(b), hb.solid_coarse_solve(2 * a - 3 * b)
+    assert np.abs(xab - (2 * xa - 3 * xb)).max() <= 1e-5 * np.abs(xab).max()
+    assert np.array_equal(hb.solid_coarse_solve(a), xa)
+    # and it is what an application of the preconditioner runs
+    before = hb.solid_coarse_info()["solves"]
+    hb.apply_preconditioner(rng.standard_normal(hb.ndof))
+    assert hb.solid_coarse_info()["solves"] == before + 1
+    hb.close()
+    # FsiTuning.solid_coarse_exact = 0 keeps the sweeps
+    hb = HipBackend(desc, tuning=dict(solid_coarse_exact=0))
+    hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+    hb.assemble_residual()
+    hb.assemble_jacobian()
+    assert hb.solid_coarse_info()["planned"] == 0
+    hb.apply_preconditioner(rng.standard_normal(hb.ndof))
+    assert hb.solid_coarse_info()["solves"] == 0
+    hb.close()
+
+
 def test_properties_at_bench_size(tmp_path):
     """BASELINE config 2 size (the 1.12 M-tet mesh bench.py times; no oracle run at this size): size-independent properties
     through the C-ABI - F(0; 0) = 0, linearity and reproducibility of the outer product, the FP32 working copy of the Jacobian

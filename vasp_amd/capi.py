@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "fsi_set_pressure_facets", "fsi_set_interface_pressure", "fsi_set_robin_facets", "fsi_solver_setup",
     "fsi_assemble_residual", "fsi_assemble_jacobian", "fsi_solve", "fsi_newton_solve", "fsi_shift",
     "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_device_memory", "fsi_apply_preconditioner", "fsi_get_matrix", "fsi_spmv",
-    "fsi_get_timers", "fsi_get_solver_events", "fsi_get_values", "fsi_stress_strain", "fsi_wall_shear_stress", "fsi_calibration_streams", "fsi_set_newton_forcing", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
+    "fsi_get_timers", "fsi_get_solver_events", "fsi_bcr_plan_graph", "fsi_solid_coarse_info", "fsi_solid_coarse_matrix", "fsi_solid_coarse_solve", "fsi_get_values", "fsi_stress_strain", "fsi_wall_shear_stress", "fsi_calibration_streams", "fsi_set_newton_forcing", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
     "fsi_rccl_unique_id", "fsi_set_rccl", "fsi_create_tuned", "fsi_get_tuning", "fsi_tuning_defaults", "fsi_tuning_from_env", "fsi_tuning_copy_out",
 )
 
@@ -57,7 +57,8 @@ class FsiTuning(C.Structure):
                 ("kappa_solid", C.c_double), ("kappa_fluid", C.c_double), ("kappa_schur", C.c_double), ("kappa_disp", C.c_double),
                 ("sbmg_pre", C.c_int32), ("sbmg_post", C.c_int32), ("sbmg_cits", C.c_int32), ("sbmg_alpha", C.c_double),
                 ("sbmg_ckappa", C.c_double),
-                ("mg_pre", C.c_int32), ("mg_post", C.c_int32), ("mg_cits", C.c_int32), ("mg_alpha", C.c_double), ("mg_ckappa", C.c_double)]
+                ("mg_pre", C.c_int32), ("mg_post", C.c_int32), ("mg_cits", C.c_int32), ("mg_alpha", C.c_double), ("mg_ckappa", C.c_double),
+                ("solid_coarse_exact", C.c_int32), ("reserved0", C.c_int32), ("bcr_shift", C.c_double)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -157,6 +158,10 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_apply_preconditioner.argtypes = [vp, vp, vp]
     lib.fsi_get_timers.argtypes = [vp, C.POINTER(FsiTimers), C.c_int]
     lib.fsi_get_solver_events.argtypes = [vp, vp]
+    lib.fsi_bcr_plan_graph.argtypes = [i64, vp, vp, vp, vp, vp]
+    lib.fsi_solid_coarse_info.argtypes = [vp, vp]
+    lib.fsi_solid_coarse_matrix.argtypes = [vp, vp, vp, vp]
+    lib.fsi_solid_coarse_solve.argtypes = [vp, vp, vp]
     lib.fsi_set_linear_solver.argtypes = [vp, i32]
     lib.fsi_probe.argtypes = [vp, i64, vp, vp, vp]
     lib.fsi_flow_stats.argtypes = [vp, vp]
@@ -442,6 +447,29 @@ class HipBackend:
         t = FsiTuning()
         self._check(self.lib.fsi_get_tuning(self.ctx, C.byref(t)))
         return t.as_dict()
+
+    # ---- the solid cycle's coarse level (test hooks of the exact solve, csrc/fsi_bcr.hip) ---------------------------------
+    def solid_coarse_info(self) -> dict:
+        out = np.zeros(12, dtype=np.int64)
+        self._check(self.lib.fsi_solid_coarse_info(self.ctx, _ptr(out)))
+        keys = ("nodes", "blocks3x3", "planned", "ready", "bfs_blocks", "levels", "operator_bytes", "launches_per_solve", "max_block",
+                "solves", "setup_flops", "cycle_ready")
+        return {k: int(v) for k, v in zip(keys, out)}
+
+    def solid_coarse_matrix(self):
+        """The coarse operator as scipy CSR (3 unknowns per coarse node)."""
+        import scipy.sparse as sp
+        info = self.solid_coarse_info()
+        nc, nb = info["nodes"], info["blocks3x3"]
+        cptr, ccol, cvals = np.empty(nc + 1, dtype=np.int64), np.empty(nb, dtype=np.int32), np.empty(9 * nb, dtype=np.float32)
+        self._check(self.lib.fsi_solid_coarse_matrix(self.ctx, _ptr(cptr), _ptr(ccol), _ptr(cvals)))
+        return sp.bsr_matrix((cvals.reshape(nb, 3, 3).astype(np.float64), ccol, cptr), shape=(3 * nc, 3 * nc)).tocsr(), cptr, ccol
+
+    def solid_coarse_solve(self, rhs):
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        x = np.empty_like(rhs)
+        self._check(self.lib.fsi_solid_coarse_solve(self.ctx, _ptr(rhs), _ptr(x)))
+        return x
 
     def solver_events(self) -> dict:
         """Run totals (since the context was created; timer resets do not touch them) of what the linear solver had to do beyond

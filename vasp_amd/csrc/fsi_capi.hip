@@ -180,6 +180,7 @@ int fsi_destroy(FsiCtx* ctx) {
   ctx->sbmg_chw.release(); ctx->sbmg_cvals.release(); ctx->sbmg_cbinv12.release(); ctx->sbmg_work.release(); ctx->sbmg_cptr.release();
   ctx->sbmg_chptr.release(); ctx->sbmg_flag.release(); ctx->sbmg_cflag.release();
   rccl_destroy(ctx);
+  bcr_free(ctx);
   ctx->s_vals32.release(); ctx->s_rec.release(); ctx->s_dinv.release();
   ctx->s_ploc.release(); ctx->s_tile_uptr.release(); ctx->s_tile_ulist.release();
   ctx->fs_rows.release(); ctx->fs_col.release(); ctx->fs_ptr.release(); ctx->fs_src.release();
@@ -242,6 +243,7 @@ static void apply_tuning(FsiCtx* ctx, const FsiTuning& t) {
   ctx->solid_block_jacobi = t.solid_block_jacobi; ctx->solid_fused = t.solid_fused;
   ctx->cheb_its_s = t.its_solid; ctx->cheb_its_f = t.its_fluid; ctx->cheb_its_p = t.its_schur; ctx->cheb_its_d = t.its_disp;
   ctx->cheb_kappa_s = t.kappa_solid; ctx->cheb_kappa_f = t.kappa_fluid; ctx->cheb_kappa_p = t.kappa_schur; ctx->cheb_kappa_d = t.kappa_disp;
+  ctx->solid_coarse_exact = t.solid_coarse_exact;
   ctx->sbmg_pre = t.sbmg_pre; ctx->sbmg_post = t.sbmg_post; ctx->sbmg_cits = t.sbmg_cits; ctx->sbmg_alpha = t.sbmg_alpha; ctx->sbmg_ckappa = t.sbmg_ckappa;
   ctx->mg_pre = t.mg_pre; ctx->mg_post = t.mg_post; ctx->mg_cits = t.mg_cits; ctx->mg_alpha = t.mg_alpha; ctx->mg_ckappa = t.mg_ckappa;
 }
@@ -923,6 +925,7 @@ int fsi_create_tuned(const FsiMeshDesc* mesh, const FsiParams* prm, int device, 
             HIPCHK(ctx->sbmg_flag.alloc(nS));
             HIPCHK(ctx->sbmg_cflag.alloc(nsc));
             HIPCHK(ctx->sbmg_work.alloc(5 * 4 * nsc));
+            if (ctx->solid_coarse_exact) FSICHK(bcr_plan(ctx, nsc, scptr, sccol, nullptr));     // (leaves ctx->bcr null when the level does not suit it)
           } else {
             ctx->solid_mg = 0;
           }

@@ -11,6 +11,7 @@
 #include "fsi_element.hpp"
 
 namespace fsi {
+struct BcrData;               // exact solve of the solid cycle's coarse level by block cyclic reduction (fsi_bcr.hip)
 
 constexpr int NQ = 24;        // Keast degree-6 rule
 constexpr int NLOC = 64;      // local dofs per tet: 30 (d) + 30 (v) + 4 (p)
@@ -236,6 +237,9 @@ struct FsiCtx {
   fsi::DevBuf<float> sbmg_pw, sbmg_chw, sbmg_cvals, sbmg_cbinv12, sbmg_work;
   fsi::DevBuf<int64_t> sbmg_cptr, sbmg_chptr;
   fsi::DevBuf<uint8_t> sbmg_flag, sbmg_cflag;
+  fsi::BcrData* bcr = nullptr;               // exact coarse solve (block cyclic reduction over BFS levels of the solid vertices), or null
+  int solid_coarse_exact = 1;                // FSI_SOLID_COARSE_EXACT=0: the coarse level keeps its sbmg_cits Chebyshev sweeps
+  int64_t bcr_solves = 0;
   int sbmg_pre = 16, sbmg_post = 16, sbmg_cits = 90;      // round 2: 200 coarse sweeps on an interval that ended at 2.2x the largest eigenvalue
   double sbmg_alpha = 200.0, sbmg_ckappa = 4000.0, sbmg_clmax = 2.0;
   int64_t nfs = 0;                           // fluid-interior velocity rows with solid columns (coupling of the predictor)

@@ -84,6 +84,18 @@ int rebuild_matrix_bc(FsiCtx* ctx);
 int precondition(FsiCtx* ctx, const double* r, double* z);
 int precondition_block(FsiCtx* ctx, const double* r, double* z);
 int refresh_preconditioner(FsiCtx* ctx);
+// fsi_bcr.hip: exact solve of the solid cycle's coarse level (block cyclic reduction)
+struct BcrPlanStats {
+  int64_t blocks = 0, levels = 0, bytes32 = 0, bytes64 = 0, setup_flops = 0;
+  int max_block = 0, launches = 0, usable = 0, plan_only = 0;
+  int32_t* pos_out = nullptr;      // plan_only: [nc] position of every node in BFS-level order
+  int32_t* level_out = nullptr;    // plan_only: [nc] BFS level of every node
+};
+int bcr_plan(FsiCtx* ctx, int64_t nc, const std::vector<int64_t>& cptr, const std::vector<int32_t>& ccol, BcrPlanStats* stats);
+int bcr_refresh(FsiCtx* ctx);
+int bcr_solve(FsiCtx* ctx, const float* rc4, float* xc4, hipStream_t st);
+bool bcr_ready(const FsiCtx* ctx);
+void bcr_free(FsiCtx* ctx);
 // fsi_krylov.hip
 int spmv(FsiCtx* ctx, const double* x, double* y, bool working = false);
 void gcr_reset(FsiCtx* ctx);

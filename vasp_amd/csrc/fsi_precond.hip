@@ -191,7 +191,12 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         float *cr = ctx->sbmg_work.p, *cd = cr + n4c, *cd2 = cr + 2 * n4c, *cx = cr + 3 * n4c, *crhs = cr + 4 * n4c;
         launch_sbmg_restrict(st, nc, ctx->sbmg_chptr.p, ctx->sbmg_child.p, ctx->sbmg_chw.p, ctx->snode.p, ctx->rowscale.p,
                              ctx->sbmg_flag.p, ctx->sbmg_cflag.p, fr, crhs);
-        {
+        if (bcr_ready(ctx)) {
+          // the coarse level solved exactly: block cyclic reduction over the breadth-first levels of the solid vertices, operators
+          // precomputed at the Jacobian refresh (fsi_bcr.hip) - 2 log2(blocks) + 3 launches instead of sbmg_cits dependent sweeps
+          FSICHK(bcr_solve(ctx, crhs, cx, st));
+          ctx->bcr_solves += 1;
+        } else {
           const double cl = ctx->sbmg_clmax, clmin = cl / ctx->sbmg_ckappa, cth = 0.5 * (cl + clmin), cde = 0.5 * (cl - clmin), csig = cth / cde;
           double crho = 1.0 / csig;
           launch_cheb_init_b3(st, nc, crhs, ctx->sbmg_cbinv12.p, (float)(1.0 / cth), cx, cr, cd);
@@ -697,7 +702,8 @@ int refresh_preconditioner(FsiCtx* ctx) {
       std::memcpy(&rowmax, &flags[2], sizeof rowmax);
       ctx->sbmg_ready = !(flags[1] & 64) && std::isfinite(rowmax) && rowmax > 0.f;
       ctx->sbmg_clmax = ctx->sbmg_gersh = rowmax;
-      if (ctx->sbmg_ready && ctx->coarse_power) {
+      if (ctx->sbmg_ready && ctx->bcr && ctx->solid_coarse_exact) FSICHK(bcr_refresh(ctx));      // exact coarse solve: operators of the new matrix
+      if (ctx->sbmg_ready && ctx->coarse_power && !bcr_ready(ctx)) {
         double lam = rowmax;
         FSICHK(coarse_power_lmax(ctx, ctx->sbmg_nc, ctx->sbmg_work.p,
                                  [&](const float* din, float* dout, float* x, float* r) {
