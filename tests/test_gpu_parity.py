@@ -443,14 +443,32 @@ def test_exact_coarse_solve_matches_a_dense_factorisation(which, stenosis_case, 
         write_mesh(tmp_path / "s.h5", 50000)
         case = prepare_case("offset_stenosis", tmp_path / "s.h5", tmp_path / "run", dt="0.001", T="0.002")
     desc = case[1]
-    hb = HipBackend(desc)
     g, P = boundary_data(case, 0.01 if which == "fixture" else 1e-3)
+    # what ships solves A_c + shift * blockdiag(A_c) (FsiTuning.bcr_shift: the lowest modes are damped, not inverted): held to
+    # the sparse LU of THAT operator first, on one right-hand side
+    import scipy.sparse as sp
+    hb = HipBackend(desc)
+    shift = hb.tuning()["bcr_shift"]
+    assert 0.0 < shift < 1e-3
+    hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+    hb.assemble_residual()
+    hb.assemble_jacobian()
+    A, cptr, ccol = hb.solid_coarse_matrix()
+    nc = A.shape[0] // 3
+    diag = sp.block_diag([A[3 * i:3 * i + 3, 3 * i:3 * i + 3] for i in range(nc)], format="csr")
+    rhs = np.random.default_rng(5).standard_normal(A.shape[0])
+    x_ref = spla.splu((A + shift * diag).tocsc()).solve(rhs)
+    x = hb.solid_coarse_solve(rhs)
+    assert np.linalg.norm(x - x_ref) < 2e-2 * np.linalg.norm(x_ref)
+    hb.close()
+    # the rest with shift = 0: the level itself
+    hb = HipBackend(desc, tuning=dict(bcr_shift=0.0))
     hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
     hb.assemble_residual()
     hb.assemble_jacobian()
     info = hb.solid_coarse_info()
     assert info["cycle_ready"] == 1 and info["planned"] == 1 and info["ready"] == 1, info
-    assert info["levels"] == int(np.ceil(np.log2(info["bfs_blocks"]))) and info["launches_per_solve"] == 2 * info["levels"] + 3
+    assert info["levels"] == int(np.ceil(np.log2(info["bfs_blocks"]))) and info["launches_per_solve"] == 2 * info["levels"] + 1
     A, cptr, ccol = hb.solid_coarse_matrix()
     n = A.shape[0]
     rng = np.random.default_rng(0)

@@ -394,3 +394,63 @@ def test_reference_tolerance_holds_for_the_displacement_pins_and_the_first_veloc
     from vasp_amd.mesh import FsiMesh
     x0 = FsiMesh.read(GOLDEN / "cylinder" / "cylinder.h5").coords[0]
     assert np.allclose(x0 - S[2, :3], PIN_PRE, atol=1e-10)
+
+
+# ---- item 10 (round 5, the last bounded attempt): ALL knobs at once ---------------------------------------------------------
+def _pin_fit():
+    z = np.load(GOLDEN / "pin_fit.npz")
+    y = np.concatenate([z["cylinder_y0"], z["stenosis_y0"]])               # (value - pin) / (atol + 1e-5 |pin|): |.| <= 1 passes the reference
+    A = np.vstack([z["cylinder_cols"], z["stenosis_cols"]])
+    return [str(p) for p in z["params"]], y, A, float(z["cylinder_linearity"]), float(z["stenosis_linearity"])
+
+
+def test_joint_fit_of_all_parameters_and_time_level_weights():
+    """VERDICT r4 item 1.  tests/golden/make_pin_fit.py differentiated the SIXTEEN pinned numbers (cylinder: v_x, d_x at vertex 0
+    for three steps + the predeformed vertex; stenosis after five steps: probe velocity, pressure, solid-probe displacement) with
+    respect to thirteen knobs moved one at a time around the restated equations - rho_f, mu_f, rho_s, mu_s, lambda_s, the
+    interface load, the inlet amplitude, delta, theta, dt of the solid's d-v row, and three time-level weights (interface load
+    lagged towards t^{n-1}, Laplace lifting term on a theta-mix of d^n and d^{n-1}, fluid pressure theta-weighted) - in units of
+    the reference's own tolerance.  The response is linear to < 1e-3 of a column, so the joint question is a bounded least-squares
+    problem.  What it says:
+      * the structural hypotheses (weights = 1 - theta, i.e. a theta-weighted load / pressure) are ruled out by size, and a
+        theta-weighted Laplace term is invisible (moves nothing by more than two tolerances and fixes nothing);
+      * no one, two or three knobs bring all sixteen numbers inside the reference's tolerances (best triple: 1.10);
+      * all thirteen together do (0.45) - with changes of the PROBLEM FILES' constants (rho_s, delta at -2 %, mu_s, lambda_s, the
+        load at -0.4 %) that are not free in a restatement, along a direction the data cannot identify: six of the sixteen numbers
+        sit inside the tolerance whatever is moved (the cylinder displacements: 2e-5 of 1e-8 against atol 1e-10), which leaves ten
+        informative numbers for thirteen unknowns: ANY one of the thirteen can be left out and the other twelve still fit.
+    No combination is a restatement of turtleFSI, so nothing is adopted: the strict xfails stay, the study is closed."""
+    from itertools import combinations
+    from scipy.optimize import lsq_linear
+    P, y, A, lin_c, lin_s = _pin_fit()
+    assert lin_c < 1e-3 and lin_s < 1e-3
+    assert len(P) == 13 and A.shape == (16, 13)
+    # where the restatement stands, in the reference's own units: cylinder v_x steps 2, 3 at 3 tolerances, stenosis v_x 2.4, p 70
+    assert np.allclose(y[[0, 1, 2, 9, 12]], [-0.63, -2.96, -3.12, 2.44, 70.3], atol=0.06)
+    informative = np.abs(y) > 0.02
+    assert informative.sum() == 10
+    k = {p: i for i, p in enumerate(P)}
+    theta1 = 1.0 - THETA
+    for name, lo, hi in (("load_lag", 1e3, np.inf), ("pressure_lag", 1e3, np.inf), ("laplace_lag", 0.0, 2.5)):
+        moved = np.abs(A[:, k[name]] * theta1).max()
+        assert lo <= moved <= hi, (name, moved)                              # theta-weighting: thousands of tolerances, or nothing
+    assert np.abs(y + A[:, k["laplace_lag"]] * theta1).max() > 60            # ... and the invisible one fixes nothing
+    lb = np.array([-5e-2] * 10 + [-0.5] * 3)                                 # parameters within 5 %, weights within a full theta-mix
+
+    def fit(idx):
+        idx = list(idx)
+        b = lsq_linear(A[:, idx], -y, bounds=(lb[idx], -lb[idx]))
+        return np.abs(y + A[:, idx] @ b.x).max(), b.x
+
+    best = {n: min(fit(c)[0] for c in combinations(range(13), n)) for n in (1, 2, 3)}
+    assert best[1] > 3.0 and best[2] > 1.2 and 1.05 < best[3] < 1.2, best     # singles: pressure_lag 3.1; best triple 1.10
+    lb2 = np.array([-2e-2] * 10 + [-0.5] * 3)
+    full = lsq_linear(A, -y, bounds=(lb2, -lb2))
+    r_full = np.abs(y + A @ full.x).max()
+    assert r_full < 0.6                                                        # thirteen unknowns, ten informative numbers
+    x = dict(zip(P, full.x))
+    assert x["rho_s"] < -0.015 and x["delta"] < -0.015 and abs(x["load"]) > 2e-3      # ... by moving what the problem files fix
+    loo = {P[i]: lsq_linear(A[:, [j for j in range(13) if j != i]], -y,
+                            bounds=(np.delete(lb2, i), -np.delete(lb2, i))) for i in range(13)}
+    worst = {p: np.abs(y + np.delete(A, P.index(p), axis=1) @ b.x).max() for p, b in loo.items()}
+    assert all(v < 0.7 for v in worst.values()), worst                          # no knob is needed: the data do not identify the fit

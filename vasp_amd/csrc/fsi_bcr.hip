@@ -38,11 +38,15 @@ struct BcrGemm {                                             // C = beta C + alp
   double alpha, beta;
 };
 struct BcrGemmTile { int32_t task, ti, tj; };                // 64 x 64 tile of C: one workgroup
-struct BcrInv { int64_t a, o32; int32_t m, ld, ld32; };      // in-place inverse of an m x m block (+ FP32 copy)
+struct BcrInv {                                              // in-place inverse of an m x m block (+ FP32 copy)
+  int64_t a, o32, cb, rb;                                    // cb [m][32], rb [32][m]: column / row panel scratch of the blocked Gauss-Jordan
+  int32_t m, ld, ld32;
+};
+constexpr int BCR_PANEL = 32;
 
 struct BcrRange { int64_t first = 0, count = 0; };
 struct BcrLevelHost {
-  BcrRange inv, gemm1, gemm2, fwd, bwd;
+  BcrRange inv, invupd, gemm1, gemm2, fwd, bwd;            // invupd: tiles of the rank-32 updates A += -Cb Rb of the inverses
   int inv_maxm = 0, fwd_maxld = 0, bwd_maxld = 0;
 };
 
@@ -63,7 +67,7 @@ struct BcrData {
   DevBuf<BcrInv> invs;
   DevBuf<int32_t> flag;                                      // device: bit 0 = a pivot vanished / was not finite
   std::vector<BcrLevelHost> levels;
-  BcrRange top_inv, top_task;
+  BcrRange top_inv, top_invupd, top_task;
   int top_m = 0, top_ld = 0;
   int64_t bytes32 = 0, bytes64 = 0, setup_flops = 0;
   int launches_per_solve = 0;
@@ -99,95 +103,95 @@ __global__ void k_bcr_scatter(int64_t nc, const int32_t* __restrict__ pos, const
   }
 }
 
-// In-place inverse of an m x m block (row-major, leading dimension ld) by a blocked Gauss-Jordan without pivoting, one
-// workgroup per block: per panel of nb columns the pivot block is inverted by one thread in LDS while the others stage the
-// row and the column panel, then every thread updates its share of the matrix from LDS (four rows of a column per trip:
-// the column panel's entries are wave-uniform reads).  LDS: (2 m nb + 128) doubles.
-__global__ __launch_bounds__(512) void k_bcr_invert(const BcrInv* __restrict__ tasks, int nb, double* __restrict__ arena,
-                                                    float* __restrict__ arena32, int32_t* __restrict__ flag) {
-  extern __shared__ double lds[];
+// In-place inverse of m x m blocks (row-major, leading dimension ld) by a blocked Gauss-Jordan without pivoting, 32 columns per
+// panel, TWO launches per panel for all blocks of a reduction level at once:
+//   k_bcr_panel  (one workgroup per block): invert the 32 x 32 pivot block in LDS; R = Pinv * (row panel), Pinv itself on the
+//                panel's own columns; rows of the panel <- R; column panel -> Cb (rows of the panel zeroed), then zeroed in A;
+//   k_bcr_gemm   (64 x 64 tiles, matrix pipe):  A += -Cb * R,   i.e.  A_ij <- A_ij - A_ik Pinv A_kj  and  A_ik <- -A_ik Pinv.
+// (Round 5's first version did the whole inversion in ONE workgroup per block: 12.6 ms per launch at 432 unknowns, 113 ms per
+// refresh at 1.12 M tets - the update of the block was a latency-bound read-modify-write loop of a single compute unit.)
+__global__ __launch_bounds__(256) void k_bcr_panel(const BcrInv* __restrict__ tasks, int k0, double* __restrict__ arena,
+                                                   int32_t* __restrict__ flag) {
+  __shared__ double Ps[BCR_PANEL][BCR_PANEL + 1], Qs[BCR_PANEL][BCR_PANEL + 1];
   const BcrInv T = tasks[blockIdx.x];
-  const int m = T.m, ld = T.ld, tid = threadIdx.x, nt = blockDim.x;
+  const int m = T.m, ld = T.ld, tid = threadIdx.x;
   double* A = arena + T.a;
-  double* Cc = lds;                       // [m][nb]  column panel (old values)
-  double* R = lds + (size_t)m * nb;       // [nb][m]  row panel, then Pinv * row panel
-  double* P = R + (size_t)m * nb;         // [8][8]   pivot block -> its inverse
-  double* Q = P + 64;
-  for (int k0 = 0; k0 < m; k0 += nb) {
-    const int nbk = min(nb, m - k0);
-    if (tid < 64) {
-      const int r = tid >> 3, s = tid & 7;
-      P[tid] = (r < nbk && s < nbk) ? A[(size_t)(k0 + r) * ld + k0 + s] : (r == s ? 1.0 : 0.0);
-      Q[tid] = r == s ? 1.0 : 0.0;
-    }
-    for (int idx = tid; idx < m * nbk; idx += nt) {
-      const int i = idx / nbk, s = idx - i * nbk;
-      Cc[(size_t)i * nb + s] = A[(size_t)i * ld + k0 + s];
-    }
-    for (int idx = tid; idx < nbk * m; idx += nt) {
-      const int s = idx / m, j = idx - s * m;
-      R[(size_t)s * m + j] = A[(size_t)(k0 + s) * ld + j];
-    }
-    __syncthreads();
-    if (tid == 0) {                        // 8 x 8 Gauss-Jordan on [P | Q], serial: ~1 us, hidden behind nothing but short
-      bool bad = false;
-      for (int p = 0; p < nbk; ++p) {
-        const double piv = P[8 * p + p];
-        if (!(fabs(piv) > 1e-290) || !isfinite(piv)) { bad = true; break; }
-        const double ip = 1.0 / piv;
-        for (int s = 0; s < 8; ++s) { P[8 * p + s] *= ip; Q[8 * p + s] *= ip; }
-        for (int r = 0; r < nbk; ++r) {
-          if (r == p) continue;
-          const double f = P[8 * r + p];
-          for (int s = 0; s < 8; ++s) { P[8 * r + s] -= f * P[8 * p + s]; Q[8 * r + s] -= f * Q[8 * p + s]; }
-        }
-      }
-      if (bad) atomicOr(flag, 1);
+  double* Cb = arena + T.cb;
+  double* Rb = arena + T.rb;
+  if (k0 >= m) {                                   // a smaller block of the batch: nothing left to eliminate, the update adds zero
+    for (int idx = tid; idx < m * BCR_PANEL; idx += 256) Cb[idx] = 0.0;
+    return;
+  }
+  const int nbk = min(BCR_PANEL, m - k0);
+  for (int idx = tid; idx < BCR_PANEL * BCR_PANEL; idx += 256) {
+    const int r = idx / BCR_PANEL, c = idx - r * BCR_PANEL;
+    Ps[r][c] = (r < nbk && c < nbk) ? A[(size_t)(k0 + r) * ld + k0 + c] : (r == c ? 1.0 : 0.0);
+    Qs[r][c] = r == c ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  // Gauss-Jordan on [P | Q]: after pivot p the columns <= p of P are unit vectors and are not touched again, so the factors
+  // P[r][p] are read from a column nobody writes - two barriers per pivot
+  for (int p = 0; p < nbk; ++p) {
+    const double piv = Ps[p][p];
+    const bool bad = !(fabs(piv) > 1e-290) || !isfinite(piv);
+    if (bad && tid == 0) atomicOr(flag, 1);
+    const double ip = bad ? 1.0 : 1.0 / piv;
+    if (tid < 2 * BCR_PANEL) {
+      const int c = tid & (BCR_PANEL - 1);
+      if (tid < BCR_PANEL) { if (c > p) Ps[p][c] *= ip; }
+      else Qs[p][c] *= ip;
     }
     __syncthreads();
-    // R <- Pinv * R on the columns outside the panel, Pinv itself on the panel's columns (the in-place Gauss-Jordan form)
-    for (int j = tid; j < m; j += nt) {
-      double col[8];
-      for (int s = 0; s < nbk; ++s) col[s] = R[(size_t)s * m + j];
-      const bool inpanel = j >= k0 && j < k0 + nbk;
-      for (int r = 0; r < nbk; ++r) {
-        double v = 0.0;
-        if (inpanel) v = Q[8 * r + (j - k0)];
-        else for (int s = 0; s < nbk; ++s) v += Q[8 * r + s] * col[s];
-        R[(size_t)r * m + j] = v;
-      }
-    }
-    __syncthreads();
-    // A_ij <- A_ij - C_i . R_j (the panel's columns start from zero: A_ik <- -C_i Pinv), rows of the panel <- R
-    const int m4 = (m + 3) >> 2;
-    for (int idx = tid; idx < m4 * m; idx += nt) {
-      const int i4 = idx / m, j = idx - i4 * m;
-      const bool jin = j >= k0 && j < k0 + nbk;
-      double rj[8];
-      for (int s = 0; s < nbk; ++s) rj[s] = R[(size_t)s * m + j];
-      for (int r = 0; r < 4; ++r) {
-        const int i = 4 * i4 + r;
-        if (i >= m) break;
-        double v;
-        if (i >= k0 && i < k0 + nbk) v = R[(size_t)(i - k0) * m + j];
-        else {
-          v = jin ? 0.0 : A[(size_t)i * ld + j];
-          for (int s = 0; s < nbk; ++s) v -= Cc[(size_t)i * nb + s] * rj[s];
-        }
-        A[(size_t)i * ld + j] = v;
-      }
+    for (int idx = tid; idx < BCR_PANEL * 2 * BCR_PANEL; idx += 256) {
+      const int r = idx / (2 * BCR_PANEL), cc = idx - r * 2 * BCR_PANEL;
+      if (r == p || r >= nbk) continue;
+      const double f = Ps[r][p];
+      if (cc < BCR_PANEL) { if (cc > p) Ps[r][cc] -= f * Ps[p][cc]; }
+      else Qs[r][cc - BCR_PANEL] -= f * Qs[p][cc - BCR_PANEL];
     }
     __syncthreads();
   }
-  if (T.o32 >= 0) {
-    float* O = arena32 + T.o32;
-    for (int idx = tid; idx < m * m; idx += nt) {
-      const int i = idx / m, j = idx - i * m;
-      const double v = A[(size_t)i * ld + j];
-      if (!isfinite(v)) atomicOr(flag, 1);
-      O[(size_t)i * T.ld32 + j] = (float)v;
+  // R = Pinv * A[panel rows, :]  (Pinv on the panel's own columns) -> Rb; Cb = A[:, panel columns] with the panel's rows zeroed
+  for (int j = tid; j < m; j += 256) {
+    double col[BCR_PANEL];
+    for (int s = 0; s < BCR_PANEL; ++s) col[s] = s < nbk ? A[(size_t)(k0 + s) * ld + j] : 0.0;
+    const bool inpanel = j >= k0 && j < k0 + nbk;
+    for (int r = 0; r < BCR_PANEL; ++r) {
+      double v = 0.0;
+      if (r < nbk) {
+        if (inpanel) v = Qs[r][j - k0];
+        else for (int s = 0; s < BCR_PANEL; ++s) v += Qs[r][s] * col[s];
+      }
+      Rb[(size_t)r * m + j] = v;
     }
   }
+  for (int idx = tid; idx < m * BCR_PANEL; idx += 256) {
+    const int i = idx / BCR_PANEL, s = idx - i * BCR_PANEL;
+    Cb[idx] = (s < nbk && !(i >= k0 && i < k0 + nbk)) ? A[(size_t)i * ld + k0 + s] : 0.0;
+  }
+  __syncthreads();                                 // every read of the old panels is done
+  for (int idx = tid; idx < m * nbk; idx += 256) {
+    const int i = idx / nbk, s = idx - i * nbk;
+    if (!(i >= k0 && i < k0 + nbk)) A[(size_t)i * ld + k0 + s] = 0.0;
+  }
+  for (int j = tid; j < m; j += 256)
+    for (int r = 0; r < nbk; ++r) A[(size_t)(k0 + r) * ld + j] = Rb[(size_t)r * m + j];
+}
+// the finished inverses as FP32 operators of the solve (and the finiteness check of the whole set-up)
+__global__ __launch_bounds__(256) void k_bcr_copy32(const BcrInv* __restrict__ tasks, const double* __restrict__ arena,
+                                                    float* __restrict__ arena32, int32_t* __restrict__ flag) {
+  const BcrInv T = tasks[blockIdx.x];
+  if (T.o32 < 0) return;
+  const double* A = arena + T.a;
+  float* O = arena32 + T.o32;
+  bool bad = false;
+  for (int idx = threadIdx.x; idx < T.m * T.m; idx += 256) {
+    const int i = idx / T.m, j = idx - i * T.m;
+    const double v = A[(size_t)i * T.ld + j];
+    bad = bad || !isfinite(v);
+    O[(size_t)i * T.ld32 + j] = (float)v;
+  }
+  if (bad) atomicOr(flag, 1);
 }
 
 // Batched C = beta C + alpha (A1 B1 + A2 B2) on the FP64 matrix pipe.  One workgroup (four waves, 2 x 2) per 64 x 64 tile of
@@ -255,20 +259,25 @@ __global__ __launch_bounds__(256) void k_bcr_apply(const BcrTile* __restrict__ t
   }
   for (int i = c0 + threadIdx.x; i < T.ldw; i += 256) in[i] = 0.0;
   __syncthreads();
+  // a wave takes four consecutive rows and keeps their loads in flight together (one row at a time was a chain of four
+  // memory latencies per workgroup: 21 us per launch at 1.12 M tets for 5 us of bytes)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int rr = wave; rr < 16; rr += 4) {
-    const int row = tl.row0 + rr;
-    if (row >= T.rows) break;
-    const float* wr = W + T.w + (size_t)row * T.ldw;
-    double acc = 0.0;
-    for (int c = 4 * lane; c < T.ldw; c += 256) {
-      const float4 w = *reinterpret_cast<const float4*>(wr + c);
-      acc += (double)w.x * in[c] + (double)w.y * in[c + 1] + (double)w.z * in[c + 2] + (double)w.w * in[c + 3];
-    }
-    acc = wave_sum_dpp(acc);
-    if (lane == 0) {
-      if (FORWARD) b[T.out + row] += acc;
-      else x[T.out + row] = acc;
+  const int r0 = tl.row0 + 4 * wave;
+  if (r0 >= T.rows) return;
+  const float* wr[4];
+  for (int k = 0; k < 4; ++k) wr[k] = W + T.w + (size_t)min(r0 + k, T.rows - 1) * T.ldw;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int c = 4 * lane; c < T.ldw; c += 256) {
+    float4 w[4];
+    for (int k = 0; k < 4; ++k) w[k] = *reinterpret_cast<const float4*>(wr[k] + c);
+    const double i0 = in[c], i1 = in[c + 1], i2 = in[c + 2], i3 = in[c + 3];
+    for (int k = 0; k < 4; ++k) acc[k] += (double)w[k].x * i0 + (double)w[k].y * i1 + (double)w[k].z * i2 + (double)w[k].w * i3;
+  }
+  for (int k = 0; k < 4; ++k) {
+    const double v = wave_sum_dpp(acc[k]);
+    if (lane == 0 && r0 + k < T.rows) {
+      if (FORWARD) b[T.out + r0 + k] += v;
+      else x[T.out + r0 + k] = v;
     }
   }
 }
@@ -390,6 +399,13 @@ int bcr_plan(FsiCtx* ctx, int64_t nc, const std::vector<int64_t>& cptr, const st
       for (int tj = 0; tj < (g.N + 63) / 64; ++tj) gtiles.push_back(BcrGemmTile{id, ti, tj});
     d->setup_flops += 2LL * g.M * g.N * ((int64_t)g.K1 + g.K2);
   };
+  // an in-place inverse: its panel scratch and the tiles of its rank-32 updates A += -Cb Rb (one k_bcr_gemm launch per panel)
+  auto add_inverse = [&](int64_t D, int64_t o32, int m, int ld32) {
+    const int64_t cb = alloc64(m, BCR_PANEL), rb = alloc64(BCR_PANEL, m);
+    invs.push_back(BcrInv{D, o32, cb, rb, m, m, ld32});
+    add_gemm(BcrGemm{cb, rb, -1, -1, D, -1, m, m, BCR_PANEL, 0, BCR_PANEL, m, 0, 0, m, 0, -1.0, 1.0});
+    d->setup_flops += 2LL * m * m * (int64_t)(m - BCR_PANEL);       // (add_gemm counted one panel; the update runs once per panel)
+  };
   auto add_task = [&](const BcrTask& t) {
     const int32_t id = (int32_t)tasks.size();
     tasks.push_back(t);
@@ -402,6 +418,7 @@ int bcr_plan(FsiCtx* ctx, int64_t nc, const std::vector<int64_t>& cptr, const st
     const size_t na = active.size();
     // (1) inverses of the eliminated blocks, FP32 copy straight into the backward operator
     lv.inv.first = (int64_t)invs.size();
+    lv.invupd.first = (int64_t)gtiles.size();
     std::vector<int64_t> wb(na, -1);            // backward operator of the eliminated block at position i
     std::vector<int> wb_ld(na, 0);
     for (size_t i = 1; i < na; i += 2) {
@@ -409,11 +426,11 @@ int bcr_plan(FsiCtx* ctx, int64_t nc, const std::vector<int64_t>& cptr, const st
       const int cols = msz[e] + msz[a] + (c >= 0 ? msz[c] : 0);
       wb_ld[i] = ld4(cols);
       wb[i] = alloc32(msz[e], wb_ld[i]);
-      invs.push_back(BcrInv{blk[e].D, wb[i], msz[e], msz[e], wb_ld[i]});
+      add_inverse(blk[e].D, wb[i], msz[e], wb_ld[i]);
       lv.inv_maxm = std::max(lv.inv_maxm, (int)msz[e]);
-      d->setup_flops += 2LL * msz[e] * msz[e] * msz[e];
     }
     lv.inv.count = (int64_t)invs.size() - lv.inv.first;
+    lv.invupd.count = (int64_t)gtiles.size() - lv.invupd.first;
     // (2) first batch of products: H_ea = -Dinv_e L_e, H_ec = -Dinv_e U_e (FP32 only), G_jl = -L_j Dinv_l, G_jr = -U_j Dinv_r
     lv.gemm1.first = (int64_t)gtiles.size();
     for (size_t i = 1; i < na; i += 2) {
@@ -499,15 +516,16 @@ int bcr_plan(FsiCtx* ctx, int64_t nc, const std::vector<int64_t>& cptr, const st
     d->top_m = msz[t]; d->top_ld = ld4(msz[t]);
     const int64_t w = alloc32(msz[t], d->top_ld);
     d->top_inv = BcrRange{(int64_t)invs.size(), 1};
-    invs.push_back(BcrInv{blk[t].D, w, msz[t], msz[t], d->top_ld});
-    d->setup_flops += 2LL * msz[t] * msz[t] * msz[t];
+    d->top_invupd.first = (int64_t)gtiles.size();
+    add_inverse(blk[t].D, w, msz[t], d->top_ld);
+    d->top_invupd.count = (int64_t)gtiles.size() - d->top_invupd.first;
     d->top_task = BcrRange{(int64_t)tiles.size(), 0};
     BcrTask tk{w, msz[t], d->top_ld, moff[t], 1, {{moff[t], msz[t], 0}, {0, 0, 0}, {0, 0, 0}}};
     add_task(tk);
     d->top_task.count = (int64_t)tiles.size() - d->top_task.first;
   }
   d->bytes32 = a32 * 4; d->bytes64 = a64 * 8;
-  d->launches_per_solve = 2 * (int)d->levels.size() + 3;
+  d->launches_per_solve = 2 * (int)d->levels.size() + 1;      // (+ 2 when the vectors are not handed over in the solve's own order)
   if (stats) {
     stats->levels = (int64_t)d->levels.size(); stats->bytes32 = d->bytes32; stats->bytes64 = d->bytes64; stats->setup_flops = d->setup_flops;
     stats->launches = d->launches_per_solve;
@@ -543,12 +561,6 @@ int bcr_plan(FsiCtx* ctx, int64_t nc, const std::vector<int64_t>& cptr, const st
   return FSI_OK;
 }
 
-static int inv_nb(int m) {                     // panel width of k_bcr_invert that fits the default 64 KB of dynamic LDS
-  for (int nb = 8; nb >= 1; nb >>= 1)
-    if ((size_t)(2 * (size_t)m * nb + 128) * sizeof(double) <= 65536) return nb;
-  return 0;
-}
-
 // New Jacobian: dense blocks from the coarse level's values (ctx->sbmg_cvals after k_sbmg_coarse_finish), then the operators.
 int bcr_refresh(FsiCtx* ctx) {
   BcrData* d = ctx->bcr;
@@ -564,22 +576,23 @@ int bcr_refresh(FsiCtx* ctx) {
   // solved exactly, modes below it are damped as before (FsiTuning.bcr_shift; 0 = the exact level).
   hipLaunchKernelGGL(k_bcr_fill, dim3((unsigned)grid1(d->nfill)), dim3(256), 0, st, d->nfill, ctx->sbmg_cvals.p, d->fill_dst.p, d->fill_ld.p,
                      ctx->tune.bcr_shift, d->arena64.p);
-  auto invert = [&](const BcrRange& r, int maxm) -> int {
+  auto invert = [&](const BcrRange& r, const BcrRange& upd, int maxm) -> int {
     if (r.count == 0) return FSI_OK;
-    const int nb = inv_nb(maxm);
-    if (nb == 0) { ctx->err = "block cyclic reduction: a block does not fit the inversion kernel's LDS"; return FSI_ERR_INVALID; }
-    const size_t lds = (2 * (size_t)maxm * nb + 128) * sizeof(double);
-    hipLaunchKernelGGL(k_bcr_invert, dim3((unsigned)r.count), dim3(512), lds, st, d->invs.p + r.first, nb, d->arena64.p, d->arena32.p, d->flag.p);
+    for (int k0 = 0; k0 < maxm; k0 += BCR_PANEL) {
+      hipLaunchKernelGGL(k_bcr_panel, dim3((unsigned)r.count), dim3(256), 0, st, d->invs.p + r.first, k0, d->arena64.p, d->flag.p);
+      hipLaunchKernelGGL(k_bcr_gemm, dim3((unsigned)upd.count), dim3(256), 0, st, d->gtiles.p + upd.first, d->gemms.p, d->arena64.p, d->arena32.p);
+    }
+    hipLaunchKernelGGL(k_bcr_copy32, dim3((unsigned)r.count), dim3(256), 0, st, d->invs.p + r.first, d->arena64.p, d->arena32.p, d->flag.p);
     return FSI_OK;
   };
   for (const BcrLevelHost& lv : d->levels) {
-    FSICHK(invert(lv.inv, lv.inv_maxm));
+    FSICHK(invert(lv.inv, lv.invupd, lv.inv_maxm));
     if (lv.gemm1.count)
       hipLaunchKernelGGL(k_bcr_gemm, dim3((unsigned)lv.gemm1.count), dim3(256), 0, st, d->gtiles.p + lv.gemm1.first, d->gemms.p, d->arena64.p, d->arena32.p);
     if (lv.gemm2.count)
       hipLaunchKernelGGL(k_bcr_gemm, dim3((unsigned)lv.gemm2.count), dim3(256), 0, st, d->gtiles.p + lv.gemm2.first, d->gemms.p, d->arena64.p, d->arena32.p);
   }
-  FSICHK(invert(d->top_inv, d->top_m));
+  FSICHK(invert(d->top_inv, d->top_invupd, d->top_m));
   HIPCHK(hipGetLastError());
   int32_t flag[4] = {0, 0, 0, 0};
   HIPCHK(hipMemcpyAsync(flag, d->flag.p, sizeof flag, hipMemcpyDeviceToHost, st));
@@ -592,7 +605,7 @@ int bcr_refresh(FsiCtx* ctx) {
 // x_c = A_c^-1 r_c on the float4-padded coarse vectors of the solid cycle (rc4 in, xc4 out), queued on `st`.
 int bcr_solve(FsiCtx* ctx, const float* rc4, float* xc4, hipStream_t st) {
   BcrData* d = ctx->bcr;
-  hipLaunchKernelGGL(k_bcr_gather, dim3((unsigned)grid1(d->nc)), dim3(256), 0, st, d->nc, d->pos.p, rc4, d->b.p);
+  if (rc4) hipLaunchKernelGGL(k_bcr_gather, dim3((unsigned)grid1(d->nc)), dim3(256), 0, st, d->nc, d->pos.p, rc4, d->b.p);
   for (const BcrLevelHost& lv : d->levels)
     if (lv.fwd.count)
       hipLaunchKernelGGL(k_bcr_apply<true>, dim3((unsigned)lv.fwd.count), dim3(256), (size_t)lv.fwd_maxld * sizeof(double), st,
@@ -603,9 +616,12 @@ int bcr_solve(FsiCtx* ctx, const float* rc4, float* xc4, hipStream_t st) {
     if (it->bwd.count)
       hipLaunchKernelGGL(k_bcr_apply<false>, dim3((unsigned)it->bwd.count), dim3(256), (size_t)it->bwd_maxld * sizeof(double), st,
                          d->tiles.p + it->bwd.first, d->tasks.p, d->arena32.p, d->b.p, d->x.p);
-  hipLaunchKernelGGL(k_bcr_scatter, dim3((unsigned)grid1(d->nc)), dim3(256), 0, st, d->nc, d->pos.p, d->x.p, xc4);
+  if (xc4) hipLaunchKernelGGL(k_bcr_scatter, dim3((unsigned)grid1(d->nc)), dim3(256), 0, st, d->nc, d->pos.p, d->x.p, xc4);
   return FSI_OK;
 }
+const int32_t* bcr_pos(const FsiCtx* ctx) { return ctx->bcr->pos.p; }
+double* bcr_rhs(FsiCtx* ctx) { return ctx->bcr->b.p; }
+const double* bcr_sol(const FsiCtx* ctx) { return ctx->bcr->x.p; }
 
 bool bcr_ready(const FsiCtx* ctx) { return ctx->bcr && ctx->bcr->planned && ctx->bcr->ready; }
 

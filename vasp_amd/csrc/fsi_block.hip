@@ -1518,7 +1518,8 @@ __global__ void k_sbmg_coarse_finish(int64_t nc, const int64_t* __restrict__ cpt
 __global__ void k_sbmg_restrict(int64_t nc, const int64_t* __restrict__ chptr, const int32_t* __restrict__ child,
                                 const float* __restrict__ chw, const int32_t* __restrict__ snode,
                                 const double* __restrict__ rowscale, const uint8_t* __restrict__ flag,
-                                const uint8_t* __restrict__ cflag, const float* __restrict__ r4, float* __restrict__ rc4) {
+                                const uint8_t* __restrict__ cflag, const float* __restrict__ r4, float* __restrict__ rc4,
+                                const int32_t* __restrict__ bpos, double* __restrict__ bd) {
   // 8 lanes per coarse node (round 4; one thread walking its ~20 children through three dependent loads each took 50 us per
   // application at 1.12 M tets): the children's terms are added in a fixed tree order, so the sum stays reproducible
   const int sub = threadIdx.x & 7;
@@ -1536,15 +1537,30 @@ __global__ void k_sbmg_restrict(int64_t nc, const int64_t* __restrict__ chptr, c
         s0 += w * rv.x / (float)rowscale[6 * r + 3]; s1 += w * rv.y / (float)rowscale[6 * r + 4]; s2 += w * rv.z / (float)rowscale[6 * r + 5];
       }
     s0 = group_sum<8>(s0); s1 = group_sum<8>(s1); s2 = group_sum<8>(s2);
-    if (sub == 0) reinterpret_cast<float4*>(rc4)[i] = make_float4(s0, s1, s2, 0.f);
+    if (sub == 0) {
+      reinterpret_cast<float4*>(rc4)[i] = make_float4(s0, s1, s2, 0.f);
+      if (bd) {                                     // exact coarse solve (fsi_bcr.hip): the right-hand side in its own order, FP64
+        const int64_t p = 3 * (int64_t)bpos[i];
+        bd[p] = s0; bd[p + 1] = s1; bd[p + 2] = s2;
+      }
+    }
   }
 }
 __global__ void k_sbmg_prolong(int64_t nS, const int32_t* __restrict__ par, const float* __restrict__ pw,
-                               const uint8_t* __restrict__ flag, const float* __restrict__ xc4, float* __restrict__ e4) {
+                               const uint8_t* __restrict__ flag, const float* __restrict__ xc4, float* __restrict__ e4,
+                               const int32_t* __restrict__ bpos, const double* __restrict__ xd) {
   GS(a, nS) {
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!flag[a]) {
-      const float4 u = reinterpret_cast<const float4*>(xc4)[par[2 * a]], v = reinterpret_cast<const float4*>(xc4)[par[2 * a + 1]];
+      float4 u, v;
+      if (xd) {                                     // the exact coarse solve's answer, read where it lies (FP64, its own order)
+        const int64_t pu = 3 * (int64_t)bpos[par[2 * a]], pv = 3 * (int64_t)bpos[par[2 * a + 1]];
+        u = make_float4((float)xd[pu], (float)xd[pu + 1], (float)xd[pu + 2], 0.f);
+        v = make_float4((float)xd[pv], (float)xd[pv + 1], (float)xd[pv + 2], 0.f);
+      } else {
+        u = reinterpret_cast<const float4*>(xc4)[par[2 * a]];
+        v = reinterpret_cast<const float4*>(xc4)[par[2 * a + 1]];
+      }
       const float wu = pw[2 * a], wv = pw[2 * a + 1];
       out = make_float4(wu * u.x + wv * v.x, wu * u.y + wv * v.y, wu * u.z + wv * v.z, 0.f);
     }
@@ -1570,12 +1586,12 @@ void launch_sbmg_coarse_finish(hipStream_t st, int64_t nc, const int64_t* cptr, 
 }
 void launch_sbmg_restrict(hipStream_t st, int64_t nc, const int64_t* chptr, const int32_t* child, const float* chw,
                           const int32_t* snode, const double* rowscale, const uint8_t* flag, const uint8_t* cflag,
-                          const float* r4, float* rc4) {
-  hipLaunchKernelGGL(k_sbmg_restrict, dim3(gridn(8 * nc)), dim3(256), 0, st, nc, chptr, child, chw, snode, rowscale, flag, cflag, r4, rc4);
+                          const float* r4, float* rc4, const int32_t* bpos, double* bd) {
+  hipLaunchKernelGGL(k_sbmg_restrict, dim3(gridn(8 * nc)), dim3(256), 0, st, nc, chptr, child, chw, snode, rowscale, flag, cflag, r4, rc4, bpos, bd);
 }
 void launch_sbmg_prolong(hipStream_t st, int64_t nS, const int32_t* par, const float* pw, const uint8_t* flag, const float* xc4,
-                         float* e4) {
-  hipLaunchKernelGGL(k_sbmg_prolong, dim3(gridn(nS)), dim3(256), 0, st, nS, par, pw, flag, xc4, e4);
+                         float* e4, const int32_t* bpos, const double* xd) {
+  hipLaunchKernelGGL(k_sbmg_prolong, dim3(gridn(nS)), dim3(256), 0, st, nS, par, pw, flag, xc4, e4, bpos, xd);
 }
 
 // The same sweep with only the matrix VALUES in FP32 and every vector in FP64.  A rounded matrix is still one fixed linear

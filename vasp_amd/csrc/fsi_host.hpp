@@ -93,7 +93,10 @@ struct BcrPlanStats {
 };
 int bcr_plan(FsiCtx* ctx, int64_t nc, const std::vector<int64_t>& cptr, const std::vector<int32_t>& ccol, BcrPlanStats* stats);
 int bcr_refresh(FsiCtx* ctx);
-int bcr_solve(FsiCtx* ctx, const float* rc4, float* xc4, hipStream_t st);
+int bcr_solve(FsiCtx* ctx, const float* rc4, float* xc4, hipStream_t st);       // rc4 / xc4 == nullptr: the caller filled bcr_rhs / reads bcr_sol
+const int32_t* bcr_pos(const FsiCtx* ctx);      // coarse node -> position in the solve's own (breadth-first) order
+double* bcr_rhs(FsiCtx* ctx);                   // [3 nc] right-hand side / solution in that order (restriction writes, prolongation reads)
+const double* bcr_sol(const FsiCtx* ctx);
 bool bcr_ready(const FsiCtx* ctx);
 void bcr_free(FsiCtx* ctx);
 // fsi_krylov.hip

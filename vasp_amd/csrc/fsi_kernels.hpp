@@ -290,9 +290,9 @@ void launch_sbmg_coarse_finish(hipStream_t st, int64_t nc, const int64_t* cptr, 
                                const int32_t* cfine, const uint8_t* flag, float* cbinv12, uint8_t* cflag, int32_t* rowmax_bits);
 void launch_sbmg_restrict(hipStream_t st, int64_t nc, const int64_t* chptr, const int32_t* child, const float* chw,
                           const int32_t* snode, const double* rowscale, const uint8_t* flag, const uint8_t* cflag,
-                          const float* r4, float* rc4);
+                          const float* r4, float* rc4, const int32_t* bpos = nullptr, double* bd = nullptr);
 void launch_sbmg_prolong(hipStream_t st, int64_t nS, const int32_t* par, const float* pw, const uint8_t* flag, const float* xc4,
-                         float* e4);
+                         float* e4, const int32_t* bpos = nullptr, const double* xd = nullptr);
 void launch_sweep_sb_b3(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
                         const float* binv12, float c1, float c2, const float* din, float* dout, float* x, float* r,
                         int level = 0);

@@ -189,12 +189,14 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         }
         const int64_t nc = ctx->sbmg_nc, n4c = 4 * nc;
         float *cr = ctx->sbmg_work.p, *cd = cr + n4c, *cd2 = cr + 2 * n4c, *cx = cr + 3 * n4c, *crhs = cr + 4 * n4c;
+        const bool exact = bcr_ready(ctx);
         launch_sbmg_restrict(st, nc, ctx->sbmg_chptr.p, ctx->sbmg_child.p, ctx->sbmg_chw.p, ctx->snode.p, ctx->rowscale.p,
-                             ctx->sbmg_flag.p, ctx->sbmg_cflag.p, fr, crhs);
-        if (bcr_ready(ctx)) {
+                             ctx->sbmg_flag.p, ctx->sbmg_cflag.p, fr, crhs, exact ? bcr_pos(ctx) : nullptr, exact ? bcr_rhs(ctx) : nullptr);
+        if (exact) {
           // the coarse level solved exactly: block cyclic reduction over the breadth-first levels of the solid vertices, operators
-          // precomputed at the Jacobian refresh (fsi_bcr.hip) - 2 log2(blocks) + 3 launches instead of sbmg_cits dependent sweeps
-          FSICHK(bcr_solve(ctx, crhs, cx, st));
+          // precomputed at the Jacobian refresh (fsi_bcr.hip) - 2 log2(blocks) + 1 launches instead of sbmg_cits dependent sweeps;
+          // the restriction wrote the right-hand side in the solve's own order and the prolongation reads the answer there
+          FSICHK(bcr_solve(ctx, nullptr, nullptr, st));
           ctx->bcr_solves += 1;
         } else {
           const double cl = ctx->sbmg_clmax, clmin = cl / ctx->sbmg_ckappa, cth = 0.5 * (cl + clmin), cde = 0.5 * (cl - clmin), csig = cth / cde;
@@ -210,7 +212,8 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
             crho = rn;
           }
         }
-        launch_sbmg_prolong(st, ctx->nS, ctx->sbmg_par.p, ctx->sbmg_pw.p, ctx->sbmg_flag.p, cx, dcur);   // correction as the next direction
+        launch_sbmg_prolong(st, ctx->nS, ctx->sbmg_par.p, ctx->sbmg_pw.p, ctx->sbmg_flag.p, cx, dcur,     // correction as the next direction
+                            exact ? bcr_pos(ctx) : nullptr, exact ? bcr_sol(ctx) : nullptr);
         sweep(0.f, (float)sinit, -1);                          // x += P x_c, r -= A P x_c, restart the recurrence
         srho = 1.0 / ssig;
         for (int k = 0; k < ctx->sbmg_post; ++k) {
