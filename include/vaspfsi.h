@@ -149,6 +149,8 @@ typedef struct FsiTuning {
                                 * the solid vertices, operators refreshed with the Jacobian (csrc/fsi_bcr.hip) - instead of sbmg_cits sweeps */
   int32_t reserved0;
   double bcr_shift;            /* ... of A_c + bcr_shift * blockdiag(A_c): the floor below which the level's modes are damped, not inverted */
+  double newton_adaptive;      /* linear tolerance >= this x the contraction the Newton iteration of the same index reached one time
+                                * step ago under the same Jacobian (net of its own linear tolerance); 0: off.  fsi_newton_solve */
 } FsiTuning;
 void fsi_tuning_defaults(FsiTuning* t);
 /* (internal helper of fsi_get_tuning, exported so that the ABI test can exercise the size rule without a device) */

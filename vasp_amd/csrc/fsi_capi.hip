@@ -244,6 +244,7 @@ static void apply_tuning(FsiCtx* ctx, const FsiTuning& t) {
   ctx->cheb_its_s = t.its_solid; ctx->cheb_its_f = t.its_fluid; ctx->cheb_its_p = t.its_schur; ctx->cheb_its_d = t.its_disp;
   ctx->cheb_kappa_s = t.kappa_solid; ctx->cheb_kappa_f = t.kappa_fluid; ctx->cheb_kappa_p = t.kappa_schur; ctx->cheb_kappa_d = t.kappa_disp;
   ctx->solid_coarse_exact = t.solid_coarse_exact;
+  ctx->newton_adaptive = t.newton_adaptive;
   ctx->sbmg_pre = t.sbmg_pre; ctx->sbmg_post = t.sbmg_post; ctx->sbmg_cits = t.sbmg_cits; ctx->sbmg_alpha = t.sbmg_alpha; ctx->sbmg_ckappa = t.sbmg_ckappa;
   ctx->mg_pre = t.mg_pre; ctx->mg_post = t.mg_post; ctx->mg_cits = t.mg_cits; ctx->mg_alpha = t.mg_alpha; ctx->mg_ckappa = t.mg_ckappa;
 }

@@ -324,6 +324,14 @@ struct FsiCtx {
   double newton_forcing_late = 3e-3;         // forcing term of late Newton iterations (see fsi_newton_solve); >= newton_forcing or 0: off.
                                              // Round 4 scan (profiles/r04_forcing_scan.txt): distance of the known-answer run to the exact-solve
                                              // trajectory 4.7e-6 -> 1.4e-6 in v for +3 % of the bench's time step (2e-3: 1.0e-6 / +7 %; 1e-3: 5.6e-7 / +8 %)
+  double newton_adaptive = 0.1;              // forcing term from the contraction the Newton iteration of the same index reached one time step ago (see fsi_newton_solve); 0: off
+  double nw_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // that contraction, net of the linear residual that was allowed; 0 = not known (reset with the Jacobian)
+  int64_t newton_adaptive_solves = 0;
+  // adaptive solves only (set by fsi_newton_solve around its fsi_solve, zero otherwise): the answer must also leave an UNSCALED
+  // residual below utol * b_unscaled - Newton's policy reads the unscaled |b|, the Krylov method minimises the row-equilibrated
+  // one, and the rows differ by twelve decades - or the tolerance is tightened towards utol_rtol_floor (the non-adaptive value)
+  double utol = 0.0, utol_rtol_floor = 0.0, b_unscaled = 0.0;
+  int64_t utol_tightened = 0;
   double newton_late_factor = 10.0;          // "late": the previous update norm (or |b|) is within this factor of its tolerance
   int64_t newton_late_solves = 0;
   // Two chains of one preconditioner application side by side (FSI_PREC_STREAMS=1; precondition_block): stream A = solver

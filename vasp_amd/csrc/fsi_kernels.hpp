@@ -128,6 +128,7 @@ void launch_axpy(hipStream_t st, double* y, double a, const double* x, int64_t n
 void launch_axpby(hipStream_t st, double* z, double a, const double* x, double b, const double* y, int64_t n);
 void launch_scale(hipStream_t st, double* y, double a, int64_t n);
 void launch_mul(hipStream_t st, double* z, const double* x, const double* y, int64_t n);     // z = x .* y
+void launch_div(hipStream_t st, double* z, const double* x, const double* y, int64_t n);     // z = x ./ y
 void launch_gather(hipStream_t st, double* dst, const double* src, const int32_t* idx, int64_t n);   // dst[i]=src[idx[i]]
 void launch_scatter(hipStream_t st, double* dst, const double* src, const int32_t* idx, int64_t n);  // dst[idx[i]]=src[i]
 void launch_add_indexed(hipStream_t st, double* y, const int32_t* idx, const double* coef, double a, int64_t n);

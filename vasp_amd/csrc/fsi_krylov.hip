@@ -467,7 +467,8 @@ int gcr_cycle(FsiCtx* ctx, double* r, double* x, double target, double rtol_floo
 namespace fsi {
 namespace host {
 
-int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it, int* iters, double* relres) {
+int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol_in, int max_it, int* iters, double* relres) {
+  double rtol = rtol_in;           // tightened below when an adaptive solve (ctx->utol) leaves too much in the unscaled norm
   const int64_t n = ctx->ndof;
   hipStream_t st = ctx->stream;
   double* r = ctx->tmp1.p;
@@ -503,6 +504,7 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
   int stalls = 0;
   bool near_ok = false;
   const int64_t cap_now = ctx->kry_cap;
+  for (int tighten = 0; tighten < 8; ++tighten) {
   for (int cyc = 0; cyc < 8 && *iters < max_it; ++cyc) {
     // FP32 storage of Q: the residual recurrence of one cycle is good to about 1e-6 of the residual the cycle started from;
     // a tighter request is met by restarting the cycle from the true residual b - A x (iterative refinement).  With the FP32
@@ -602,6 +604,17 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol, int max_it
       }
     }
     rstart = rnorm;
+  }
+  // adaptive Newton solves: the unscaled residual D_r^-1 r against utol |b| (r: the residual the cycles ended on)
+  if (!(ctx->utol > 0.0) || !(rnorm <= rtol * bnorm) || rtol <= ctx->utol_rtol_floor * (1.0 + 1e-12) || *iters >= max_it) break;
+  double ru = 0.0;
+  launch_div(st, ctx->tmp3.p, r, ctx->rowscale.p, n);
+  FSICHK(gnorm2(ctx, ctx->tmp3.p, &ru));
+  if (!(ru > ctx->utol * ctx->b_unscaled)) break;
+  const double want = 0.5 * ctx->utol * ctx->b_unscaled / ru;              // aim a factor two below
+  rtol = std::max(ctx->utol_rtol_floor, rtol * std::min(0.5, std::max(0.02, want)));
+  ctx->utol_tightened += 1;
+  rstart = rnorm;
   }
   *relres = rnorm / bnorm;
   if (getenv("FSI_DEBUG_TRUERES")) {

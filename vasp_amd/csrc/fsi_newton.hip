@@ -63,6 +63,7 @@ int fsi_assemble_jacobian(FsiCtx* ctx) {
     ctx->op32_ok = true;
   }
   gcr_reset(ctx);          // the recycled directions belong to the previous matrix
+  for (double& h : ctx->nw_hist) h = 0.0;      // ... and so does what was learnt about the Newton iteration's contraction
   // what decides the storage precision of the basis belongs to the Jacobian that has just been replaced: the largest
   // right-hand side seen (one large early |b|, e.g. the first step from rest, must not keep tol_hint low for the whole run)
   // and a fall-back to FP64 after a failed cycle (a system that lost FP32 once may not lose it with the next matrix; after
@@ -112,6 +113,7 @@ int fsi_newton_solve(FsiCtx* ctx, const FsiNewtonOpts* o, FsiNewtonIter* iters, 
   HIPCHK(hipSetDevice(ctx->device));
   int it = 0;
   double residual = 1e8, rel_res = 1e8, last_residual = 1e8;
+  double prev_eta = 0.0;           // tolerance of the previous iteration's solve (adaptive forcing term below)
   *n_iters = 0;
   while (rel_res > o->rtol && residual > o->atol && it < o->max_it) {
     const bool rec = (it == 0 && o->recompute_tstep > 0 && o->counter % o->recompute_tstep == 0) ||
@@ -127,6 +129,31 @@ int fsi_newton_solve(FsiCtx* ctx, const FsiNewtonOpts* o, FsiNewtonIter* iters, 
     // than lin_rtol; without this the last iteration of every step solves a 1e-10-sized system to 1e-20
     double eta = o->lin_rtol;
     if (bnorm > 0.0 && o->atol > 0.0) eta = std::max(eta, std::min(1e-2, ctx->newton_forcing * o->atol / bnorm));
+    // What a quasi-Newton iteration can gain is bounded by its (stale) Jacobian, not by its linear solve: on the bench the first
+    // iteration of a time step was solved to 2e-6 and contracted the residual by 3e-3, step after step (and the aneurysm file at
+    // its own tolerances: solved to 1e-9, contracted by 1e-3).  The contraction the iteration of the SAME INDEX reached one time
+    // step ago, under the same Jacobian, is known; a linear residual a tenth of that (`newton_adaptive`) cannot show in the next
+    // nonlinear residual.  What is remembered is the contraction net of the linear tolerance that was allowed (rho_obs - eta: the
+    // two add at worst), so a looser solve cannot feed back into a looser solve.  Never looser than 1e-2, never applied to an
+    // iteration that refreshes the Jacobian (nothing is known about the new one), and the late rule below still tightens what is
+    // likely the last solve of the step.
+    if (it > 0 && it <= 8 && bnorm > 0.0 && residual > 0.0 && residual < 1e7) {
+      const double rho_obs = bnorm / residual;                      // |b_it| / |b_{it-1}| of THIS step
+      ctx->nw_hist[it - 1] = std::max(rho_obs - prev_eta, 0.5 * rho_obs);
+    }
+    // (newton_forcing = 0 means every system to lin_rtol, the direct-LU policy: nothing is loosened then)
+    if (ctx->newton_adaptive > 0.0 && ctx->newton_forcing > 0.0 && !rec && it < 8 && ctx->nw_hist[it] > 0.0 && ctx->nw_hist[it] < 1.0) {
+      const double eta_a = std::min(1e-2, ctx->newton_adaptive * ctx->nw_hist[it]);
+      if (eta_a > eta) {
+        // the contraction was observed on the UNSCALED |b| (the norm the policy's decisions hang on); the Krylov method stops on
+        // the row-equilibrated norm.  solve_gcr holds the answer to both: eta_a in its own norm, and an unscaled residual below
+        // eta_a |b| - tightening towards the non-adaptive tolerance while that fails (known-answer case, dt = 0.01: a scaled 1e-3
+        // left 0.4 |b| in the penalty rows, the residual rose and the policy refreshed a Jacobian the reference keeps)
+        ctx->utol = eta_a; ctx->utol_rtol_floor = eta; ctx->b_unscaled = bnorm;
+        eta = eta_a;
+        ctx->newton_adaptive_solves += 1;
+      }
+    }
     // Late iterations - the previous update was already within `late_factor` of the stopping tolerance, so this one is
     // likely the last of the step - are solved with the tighter forcing term: what an inexact LAST solve leaves in the state is
     // what separates the run from the reference's direct-LU trajectory (production defaults against
@@ -148,8 +175,9 @@ int fsi_newton_solve(FsiCtx* ctx, const FsiNewtonOpts* o, FsiNewtonIter* iters, 
     // in_newton / tol_hint hold for the two solves below and for nothing else: the guard clears them on EVERY way out of this
     // iteration (the early return of the refresh-and-retry path included), so that a later direct fsi_solve on this context is
     // never taken for a solve inside Newton - it would skip the FP64 verdict and choose the basis precision from a stale hint
-    struct NewtonScope { FsiCtx* c; ~NewtonScope() { c->tol_hint = 0.0; c->in_newton = false; } } newton_scope{ctx};
+    struct NewtonScope { FsiCtx* c; ~NewtonScope() { c->tol_hint = 0.0; c->in_newton = false; c->utol = 0.0; } } newton_scope{ctx};
     ctx->in_newton = true;
+    prev_eta = eta;
     int src = fsi_solve(ctx, eta, o->lin_max_it, o->lin_solver, &lit, &lrr);
     bool rec_retry = false;
     if (src == FSI_ERR_LINEAR && !rec && !ctx->prec_bad) {

@@ -75,6 +75,7 @@ __global__ void k_axpby(double* z, double a, const double* x, double b, const do
 }
 __global__ void k_scale(double* y, double a, int64_t n) { GRID_STRIDE(i, n) y[i] *= a; }
 __global__ void k_mul(double* z, const double* x, const double* y, int64_t n) { GRID_STRIDE(i, n) z[i] = x[i] * y[i]; }
+__global__ void k_div(double* z, const double* x, const double* y, int64_t n) { GRID_STRIDE(i, n) z[i] = x[i] / y[i]; }
 __global__ void k_gather(double* d, const double* s, const int32_t* idx, int64_t n) { GRID_STRIDE(i, n) d[i] = s[idx[i]]; }
 __global__ void k_scatter(double* d, const double* s, const int32_t* idx, int64_t n) { GRID_STRIDE(i, n) d[idx[i]] = s[i]; }
 // the targets are distinct (merged on the host): plain adds
@@ -124,6 +125,7 @@ void launch_axpby(hipStream_t st, double* z, double a, const double* x, double b
 }
 void launch_scale(hipStream_t st, double* y, double a, int64_t n) { LAUNCH1D(k_scale, st, n, y, a, n); }
 void launch_mul(hipStream_t st, double* z, const double* x, const double* y, int64_t n) { LAUNCH1D(k_mul, st, n, z, x, y, n); }
+void launch_div(hipStream_t st, double* z, const double* x, const double* y, int64_t n) { LAUNCH1D(k_div, st, n, z, x, y, n); }
 void launch_gather(hipStream_t st, double* d, const double* s, const int32_t* idx, int64_t n) { LAUNCH1D(k_gather, st, n, d, s, idx, n); }
 void launch_scatter(hipStream_t st, double* d, const double* s, const int32_t* idx, int64_t n) { LAUNCH1D(k_scatter, st, n, d, s, idx, n); }
 void launch_add_indexed(hipStream_t st, double* y, const int32_t* idx, const double* coef, double a, int64_t n) {
