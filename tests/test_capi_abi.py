@@ -88,7 +88,7 @@ def test_tuning_struct_size_is_honoured_in_both_directions():
         for bad in (0, -5, full + 64):                                        # "this header's size"
             t.contents.struct_size = bad
             fill(t)
-            assert t.contents.struct_size == full and t.contents.mg_cits == 24
+            assert t.contents.struct_size == full and t.contents.mg_cits == 16
 
 
 def test_error_codes_match_header():

@@ -311,3 +311,56 @@ def test_a_rank_local_failure_is_raised_on_every_rank_instead_of_hanging():
         p.join(120)
         assert p.exitcode == 0
     assert got == {0: "FsiError 4", 1: "FsiError 4"}, got
+
+
+def _transport_failure_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if rank == 1:
+        os.environ["VASPFSI_TEST_FAIL_HALO_AT"] = "7"          # this rank's 7th halo exchange raises before it communicates
+    import tempfile
+    import time
+    import torch.distributed as dist
+    from conftest import prepare_case
+    from vasp_amd.capi import FsiError
+    from vasp_amd.partition import DistBackend
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ns, desc, bc_values, pressure, hook = prepare_case("cylinder", GOLDEN / "cylinder" / "cylinder.h5", tempfile.mkdtemp(),
+                                                        T="0.003")
+    db = DistBackend(desc, dist, device=0, lin_rtol=1e-10)
+    t0 = time.time()
+    outcome = "no error"
+    try:
+        _time_steps(db, ns, bc_values, pressure, hook)
+    except FsiError as e:
+        outcome = f"FsiError {e.code}"
+    except Exception as e:                   # the stored Python exception of the callback is re-raised in its place
+        outcome = f"{type(e).__name__}"
+    q.put((rank, outcome, time.time() - t0))
+    db.hb.close()
+
+
+@pytest.mark.gpu
+def test_a_failed_exchange_inside_a_solve_ends_the_solve_on_every_rank():
+    """VERDICT r4 item 8c, callback path: one rank's halo exchange fails inside a Krylov iteration.  That rank leaves the solve
+    with FSI_ERR_DEVICE (its Python exception re-raised); the OTHER rank, already inside the matching all_to_all, must leave its
+    solve with an error too - promptly - instead of waiting for a peer that is gone: the failing rank tears the process group down
+    (``DistBackend._abort_transport``), as the library-side RCCL path aborts its communicator."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_transport_failure_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, outcome, seconds = q.get(timeout=300)
+        got[rank] = (outcome, seconds)
+    for p in procs:
+        p.join(120)
+    assert got[1][0] == "RuntimeError", got                   # the injected failure itself
+    assert got[0][0] != "no error", got                       # the peer did not sail on, and did not hang:
+    assert got[0][0] in ("FsiError 2", "RuntimeError", "DistBackendError", "DistNetworkError") or "Error" in got[0][0], got
+    assert got[0][1] < 120 and got[1][1] < 120, got

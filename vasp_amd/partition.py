@@ -337,6 +337,8 @@ class DistBackend:
         self._pending_bc = self._pending_P = None
         self._flow_stats = None
         self._flow_stats_valid = False           # DistBackend's own: cleared by newton_solve / set_state / shift, set by flow_stats
+        self._inject_counts: Dict[str, int] = {}
+        self._aborted = False
         # Overlap of the restricted Schwarz preconditioner, in node layers.  Measured on the 1.12 M-tet bench mesh (5 steps from
         # rest, Krylov iterations; one context: 114): 2 ranks 138 / 124 / 118 with 2 / 3 / 4 layers (3.8 / 5.1 / 6.4 % ghost
         # cells), 4 ranks 140 / 127 / 120 / 115 with 2 / 3 / 4 / 6 layers (11 / 14 / 18 / 27 %): four layers keep the count within
@@ -420,8 +422,38 @@ class DistBackend:
         return True, ""
 
     # ---- transport (called back from inside fsi_solve / fsi_newton_solve) ------------------------------------------
+    def _abort_transport(self, e: BaseException) -> None:
+        """A collective failed on THIS rank inside a solve: the library returns FSI_ERR_DEVICE here at once, but the other ranks
+        sit in the matching all_to_all / all_reduce.  Tear the job's transport down so that their pending collective fails too and
+        they leave the solve with FSI_ERR_DEVICE (their callbacks' except branch) instead of waiting for a rank that has left -
+        the callback path's counterpart of ncclCommAbort in csrc/fsi_rccl.hip."""
+        if getattr(self, "_aborted", False):
+            return
+        self._aborted = True
+        import sys
+        print(f"vasp_amd.partition: rank {self.rank}: a collective failed inside a solve ({type(e).__name__}: {e}); "
+              f"aborting the process group so that no rank waits for this one", file=sys.stderr, flush=True)
+        try:
+            if self.on_gpu_wire:
+                from torch.distributed.distributed_c10d import _abort_process_group
+                _abort_process_group()
+            else:
+                self.dist.destroy_process_group()          # gloo: closes the pairs' sockets; the peers' pending operation raises
+        except Exception as e2:                            # noqa: BLE001 - nothing more can be done from inside a callback
+            print(f"vasp_amd.partition: rank {self.rank}: aborting the process group failed too ({e2})", file=sys.stderr, flush=True)
+
+    def _inject(self, what: str) -> None:
+        """Test hook: VASPFSI_TEST_FAIL_<WHAT>_AT=k makes the k-th <what> callback of this process raise before it communicates."""
+        at = os.environ.get(f"VASPFSI_TEST_FAIL_{what}_AT")
+        if at is None:
+            return
+        n = self._inject_counts[what] = self._inject_counts.get(what, 0) + 1
+        if n == int(at):
+            raise RuntimeError(f"injected {what.lower()} failure (callback {n})")
+
     def _allreduce(self, _user, vals, n):
         try:
+            self._inject("ALLREDUCE")
             torch, a = self.torch, np.ctypeslib.as_array(vals, shape=(n,))
             if self.on_gpu_wire:
                 t = self._red[:n] if n <= len(self._red) else torch.empty(n, dtype=torch.float64, device=self.dev)
@@ -432,11 +464,13 @@ class DistBackend:
                 self.dist.all_reduce(torch.from_numpy(a))
             return 0
         except BaseException as e:          # never unwind through the C frames
-            self._error = e
+            self._error = self._error or e
+            self._abort_transport(e)
             return 1
 
     def _halo(self, _user):
         try:
+            self._inject("HALO")
             torch, p = self.torch, self.part
             ns, nr = len(p.send_dofs), len(p.ghost_dofs)
             if self.on_gpu_wire:
@@ -448,7 +482,8 @@ class DistBackend:
             torch.cuda.synchronize(self.dev)
             return 0
         except BaseException as e:
-            self._error = e
+            self._error = self._error or e
+            self._abort_transport(e)
             return 1
 
     def _check(self, rc):
