@@ -377,11 +377,12 @@ int fsi_solid_coarse_matrix(FsiCtx* ctx, int64_t* cptr, int32_t* ccol, float* cv
 int fsi_solid_coarse_solve(FsiCtx* ctx, const double* rhs, double* x);
 
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
-/* Run totals of the linear solver's events since fsi_create - out[0] newton_retries, out[1] fp32_fallbacks, out[2] gcr_restarts
- * (the FsiTimers fields of the same names count since the last reset) - without resolving the phase timers: no device
- * synchronisation, safe to call every time step, unaffected by fsi_get_timers(reset = 1).  What the product driver prints as
- * "Linear solver events so far". */
-int fsi_get_solver_events(const FsiCtx* ctx, int64_t out[3]);
+/* Run totals since fsi_create, without resolving the phase timers (no device synchronisation, safe to call every time step,
+ * unaffected by fsi_get_timers(reset = 1)): out[0] newton_retries, out[1] fp32_fallbacks, out[2] gcr_restarts - what the product
+ * driver prints as "Linear solver events so far" (the FsiTimers fields of the same names count since the last reset) -, out[3]
+ * Newton solves whose tolerance came from the adaptive forcing term, out[4] times such a solve was tightened because its UNSCALED
+ * residual was above the tolerance, out[5] exact coarse solves of the solid cycle, out[6], out[7] reserved (0). */
+int fsi_get_solver_events(const FsiCtx* ctx, int64_t out[8]);
 /* Measurement aid: streams `bytes` of the (idle) Krylov store once per kernel with 4-, 8-, 16- and 32-byte loads and
  * 4-, 8-, 16-byte stores per lane (kernels k_cal_read<...> / k_cal_write<...>), so that a rocprofv3 --pmc FETCH_SIZE /
  * WRITE_SIZE pass can be calibrated against known byte counts at the access widths the solver kernels use.  Discards

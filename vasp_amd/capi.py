@@ -474,9 +474,10 @@ class HipBackend:
     def solver_events(self) -> dict:
         """Run totals (since the context was created; timer resets do not touch them) of what the linear solver had to do beyond
         iterating - a cheap read: no device synchronisation, unlike ``timers()``."""
-        out = np.zeros(3, dtype=np.int64)
+        out = np.zeros(8, dtype=np.int64)
         self._check(self.lib.fsi_get_solver_events(self.ctx, _ptr(out)))
-        return {"newton_retries": int(out[0]), "fp32_fallbacks": int(out[1]), "gcr_restarts": int(out[2])}
+        return {"newton_retries": int(out[0]), "fp32_fallbacks": int(out[1]), "gcr_restarts": int(out[2]),
+                "adaptive_solves": int(out[3]), "adaptive_tightened": int(out[4]), "exact_coarse_solves": int(out[5])}
 
     def timers(self, reset=False) -> dict:
         t = FsiTimers()

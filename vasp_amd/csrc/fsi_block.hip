@@ -1173,7 +1173,8 @@ __global__ void k_mg_coarse_finish(int64_t nc, const int64_t* __restrict__ cptr,
 // coarse right-hand side: D_c^-1 P^T (D0 r), the fine residual r being that of the Jacobi-scaled system
 __global__ void k_mg_restrict(int64_t nc, const int64_t* __restrict__ chptr, const int32_t* __restrict__ child,
                               const float* __restrict__ chw, const float* __restrict__ d0, const float* __restrict__ r4,
-                              const float* __restrict__ dcinv4, float* __restrict__ rc4) {
+                              const float* __restrict__ dcinv4, float* __restrict__ rc4, float inv_theta,
+                              float* __restrict__ cx, float* __restrict__ cr, float* __restrict__ cd) {
   // four lanes per coarse vertex (a vertex has ~14 children: itself and its edge midpoints): each child is a dependent
   // index -> (weight, residual) gather, and one lane per vertex left 14 of them in a row (96 us per launch at 190 k vertices)
   const int sub = threadIdx.x & 3;
@@ -1190,7 +1191,13 @@ __global__ void k_mg_restrict(int64_t nc, const int64_t* __restrict__ chptr, con
     s0 = group_sum<4>(s0); s1 = group_sum<4>(s1); s2 = group_sum<4>(s2);
     if (sub == 0) {
       const float di = dcinv4[4 * i];
-      reinterpret_cast<float4*>(rc4)[i] = make_float4(di * s0, di * s1, di * s2, 0.f);
+      const float4 rc = make_float4(di * s0, di * s1, di * s2, 0.f);
+      reinterpret_cast<float4*>(rc4)[i] = rc;
+      if (cx) {                                       // + the coarse level's Chebyshev start (was its own launch): x = 0, r = rhs, d = rhs / theta
+        reinterpret_cast<float4*>(cx)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(cr)[i] = rc;
+        reinterpret_cast<float4*>(cd)[i] = make_float4(rc.x * inv_theta, rc.y * inv_theta, rc.z * inv_theta, 0.f);
+      }
     }
   }
 }
@@ -1226,8 +1233,9 @@ void launch_mg_coarse_finish(hipStream_t st, int64_t nc, const int64_t* cptr, co
                      dcinv4, rowmax_bits);
 }
 void launch_mg_restrict(hipStream_t st, int64_t nc, const int64_t* chptr, const int32_t* child, const float* chw,
-                        const float* d0, const float* r4, const float* dcinv4, float* rc4) {
-  hipLaunchKernelGGL(k_mg_restrict, dim3(gridn(4 * nc)), dim3(256), 0, st, nc, chptr, child, chw, d0, r4, dcinv4, rc4);
+                        const float* d0, const float* r4, const float* dcinv4, float* rc4, float inv_theta, float* cx, float* cr,
+                        float* cd) {
+  hipLaunchKernelGGL(k_mg_restrict, dim3(gridn(4 * nc)), dim3(256), 0, st, nc, chptr, child, chw, d0, r4, dcinv4, rc4, inv_theta, cx, cr, cd);
 }
 void launch_mg_prolong(hipStream_t st, int64_t N2, const int32_t* par, const float* pw, const float* d0, const float* xc4,
                        float* e4) {
@@ -1393,6 +1401,22 @@ __global__ void k_cheb_init_b3(int64_t nS, const float* __restrict__ rhs, const 
     reinterpret_cast<float4*>(x)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     reinterpret_cast<float4*>(r)[i] = ri;
     reinterpret_cast<float4*>(d)[i] = make_float4(z.x * inv_theta, z.y * inv_theta, z.z * inv_theta, 0.f);
+  }
+}
+// start of the solid two-level cycle in ONE launch (round 5; was gather + memset + init): r = the solid rows of the velocity
+// residual, x = 0, d = scale B^-1 r, the second direction buffer zeroed
+__global__ void k_solid_cycle_init(int64_t nS, const int32_t* __restrict__ snode, const double* __restrict__ full,
+                                   const float* __restrict__ binv12, float scale, float* __restrict__ x, float* __restrict__ r,
+                                   float* __restrict__ d, float* __restrict__ d2) {
+  GS(i, nS) {
+    const int64_t row = 3 * (int64_t)snode[i];
+    const float4 ri = make_float4((float)full[row], (float)full[row + 1], (float)full[row + 2], 0.f);
+    const float4 z = bmul(binv12 + 12 * i, ri);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(x)[i] = zero;
+    reinterpret_cast<float4*>(d2)[i] = zero;
+    reinterpret_cast<float4*>(r)[i] = ri;
+    reinterpret_cast<float4*>(d)[i] = make_float4(z.x * scale, z.y * scale, z.z * scale, 0.f);
   }
 }
 __global__ void k_cheb_step_b3(int64_t nS, const float* __restrict__ t, const float* __restrict__ binv12, float c1, float c2,
@@ -1845,6 +1869,10 @@ void launch_gather3_f32(hipStream_t st, int64_t nS, const int32_t* snode, const 
 }
 void launch_scatter3_f32(hipStream_t st, int64_t nS, const int32_t* snode, const float* comp, double* full) {
   hipLaunchKernelGGL(k_scatter3_f32, dim3(gridn(3 * nS)), dim3(256), 0, st, nS, snode, comp, full);
+}
+void launch_solid_cycle_init(hipStream_t st, int64_t nS, const int32_t* snode, const double* full, const float* binv12, float scale,
+                             float* x, float* r, float* d, float* d2) {
+  hipLaunchKernelGGL(k_solid_cycle_init, dim3(gridn(nS)), dim3(256), 0, st, nS, snode, full, binv12, scale, x, r, d, d2);
 }
 
 // x = mask .* (pseudo-random +-1 ripple): start vector of the power iteration, rich in element-scale modes

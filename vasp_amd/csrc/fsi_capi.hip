@@ -1493,11 +1493,13 @@ int fsi_wall_shear_stress(FsiCtx* ctx, int64_t nf, const int32_t* facet_cells, c
   return FSI_OK;
 }
 
-int fsi_get_solver_events(const FsiCtx* ctx, int64_t out[3]) {
+int fsi_get_solver_events(const FsiCtx* ctx, int64_t out[8]) {
   if (!ctx || !out) return FSI_ERR_INVALID;
   out[0] = ctx->ev_base[0] + ctx->newton_retries;
   out[1] = ctx->ev_base[1] + ctx->kry_fp32_failures_total;
   out[2] = ctx->ev_base[2] + ctx->gcr_restarts;
+  out[3] = ctx->newton_adaptive_solves; out[4] = ctx->utol_tightened; out[5] = ctx->bcr_solves;
+  out[6] = out[7] = 0;
   return FSI_OK;
 }
 

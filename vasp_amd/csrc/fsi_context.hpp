@@ -240,6 +240,7 @@ struct FsiCtx {
   fsi::BcrData* bcr = nullptr;               // exact coarse solve (block cyclic reduction over BFS levels of the solid vertices), or null
   int solid_coarse_exact = 1;                // FSI_SOLID_COARSE_EXACT=0: the coarse level keeps its sbmg_cits Chebyshev sweeps
   int64_t bcr_solves = 0;
+  const double* xs_zeroed = nullptr;         // the solid predictor's full-length vector whose non-solid entries are known to be zero (precondition_block)
   int sbmg_pre = 16, sbmg_post = 16, sbmg_cits = 90;      // round 2: 200 coarse sweeps on an interval that ended at 2.2x the largest eigenvalue
   double sbmg_alpha = 200.0, sbmg_ckappa = 4000.0, sbmg_clmax = 2.0;
   int64_t nfs = 0;                           // fluid-interior velocity rows with solid columns (coupling of the predictor)

@@ -269,7 +269,8 @@ void launch_mg_coarse_finish(hipStream_t st, int64_t nc, const int64_t* cptr, co
                              const int32_t* cfine, const uint8_t* rowflag, float* cc, uint8_t* cflag, float* dcinv4,
                              int32_t* rowmax_bits);
 void launch_mg_restrict(hipStream_t st, int64_t nc, const int64_t* chptr, const int32_t* child, const float* chw,
-                        const float* d0, const float* r4, const float* dcinv4, float* rc4);
+                        const float* d0, const float* r4, const float* dcinv4, float* rc4, float inv_theta = 0.f, float* cx = nullptr, float* cr = nullptr,
+                        float* cd = nullptr);
 void launch_mg_prolong(hipStream_t st, int64_t N2, const int32_t* par, const float* pw, const float* d0, const float* xc4,
                        float* e4);
 void launch_residual_rows(hipStream_t st, int64_t nrows, const int32_t* rows, const int64_t* ptr, const int32_t* col,
@@ -306,6 +307,8 @@ void launch_spmv_sb(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int
 void launch_cheb_init_f32(hipStream_t st, int64_t n, const float* rhs, const float* dinv, float inv_theta, float* x, float* r, float* d);
 void launch_cheb_step_f32(hipStream_t st, int64_t n, const float* t, const float* dinv, float c1, float c2, float* x, float* r, float* d);
 void launch_gather3_f32(hipStream_t st, int64_t nS, const int32_t* snode, const double* full, float* comp);
+void launch_solid_cycle_init(hipStream_t st, int64_t nS, const int32_t* snode, const double* full, const float* binv12, float scale,
+                             float* x, float* r, float* d, float* d2);
 void launch_scatter3_f32(hipStream_t st, int64_t nS, const int32_t* snode, const float* comp, double* full);
 void launch_gather_vals(hipStream_t st, int64_t n, const int64_t* pos, const double* src, double* dst);
 void launch_gather3(hipStream_t st, int64_t nS, const int32_t* snode, const double* full, double* comp);

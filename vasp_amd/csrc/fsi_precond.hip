@@ -150,15 +150,16 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
       const int64_t n = 4 * ctx->nS;               // float4 per solid node
       float* F = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(IW) + 15) & ~uintptr_t(15));   // float4 loads
       float *fr = F, *fd = F + n, *ft = F + 2 * n, *fx = F + 3 * n, *frhs = F + 4 * n;
-      launch_gather3_f32(st, ctx->nS, ctx->snode.p, rv, frhs);
       const double lmax = ctx->lmax_s, lmin = lmax / ctx->cheb_kappa_s, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
       double rho = 1.0 / sig;
       const bool bj = ctx->solid_block_jacobi != 0;
       const bool fused = bj && ctx->solid_fused;
-      if (fused && ctx->sbmg_ready) {}      // the two-level cycle below starts its own recurrence
+      const bool cycle = fused && ctx->sbmg_ready;      // the two-level cycle: gather, x = 0, first direction and the zeroed second buffer in ONE launch below
+      if (!cycle) launch_gather3_f32(st, ctx->nS, ctx->snode.p, rv, frhs);
+      if (cycle) {}
       else if (bj) launch_cheb_init_b3(st, ctx->nS, frhs, ctx->sb_binv12.p, (float)(1.0 / th), fx, fr, fd);
       else launch_cheb_init_f32(st, n, frhs, ctx->sb_dinv.p, (float)(1.0 / th), fx, fr, fd);
-      if (fused) HIPCHK(hipMemsetAsync(ft, 0, n * sizeof(float), st));     // second d buffer (ping-pong), pads stay zero
+      if (fused && !cycle) HIPCHK(hipMemsetAsync(ft, 0, n * sizeof(float), st));     // second d buffer (ping-pong), pads stay zero
       float *dcur = fd, *dnext = ft;
       if (fused && ctx->sbmg_ready) {
         // two-level cycle (see the displacement block): smoothing on [lmax/alpha, lmax], coarse solve on the solid vertices
@@ -170,7 +171,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         const bool s4 = (ctx->cheb4 & 1) != 0;
         const double sinit = s4 ? 4.0 / (3.0 * lmax) : 1.0 / sth;
         auto s4c = [&](int i, float* c1, float* c2) { *c1 = (float)((2.0 * i - 1.0) / (2.0 * i + 3.0)); *c2 = (float)((8.0 * i + 4.0) / ((2.0 * i + 3.0) * lmax)); };
-        launch_cheb_init_b3(st, ctx->nS, frhs, ctx->sb_binv12.p, (float)sinit, fx, fr, fd);
+        launch_solid_cycle_init(st, ctx->nS, ctx->snode.p, rv, ctx->sb_binv12.p, (float)sinit, fx, fr, fd, ft);
         auto sweep = [&](float c1, float c2, int sample) {
           const bool timed = ctx->sample_budget > 0 && sample >= 0 && sample < 8 && ctx->ss_ev0[0];
           if (timed) (void)hipEventRecord(ctx->ss_ev0[sample], st);
@@ -243,9 +244,12 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         rho = rn;
       }
       if (!(fused && ctx->sbmg_ready)) ctx->ss_samples_pending = (ctx->sample_budget > 0 && ctx->ss_ev0[0]) ? std::min(8, ctx->cheb_its_s) : 0;
-      launch_fill(st, xs, n3, 0.0);
+      // xs is written by this scatter alone (the sweeps' work areas end below it): its non-solid entries stay zero from one
+      // application to the next, so the 3 N2-entry fill runs once per context instead of once per application
+      if (ctx->xs_zeroed != xs) { launch_fill(st, xs, n3, 0.0); ctx->xs_zeroed = xs; }
       launch_scatter3_f32(st, ctx->nS, ctx->snode.p, fx, xs);
     } else {
+    ctx->xs_zeroed = nullptr;
     launch_gather3(st, ctx->nS, ctx->snode.p, rv, cs_rhs);
     {
       const CsrRef M = ss_ref(ctx);
@@ -429,11 +433,13 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
         }
         const int64_t nc = ctx->mg_nc, n4c = 4 * nc;
         float *cr = ctx->mg_work.p, *cd = cr + n4c, *ct = cr + 2 * n4c, *cx = cr + 3 * n4c, *crhs = cr + 4 * n4c;
-        launch_mg_restrict(st, nc, ctx->mg_chptr.p, ctx->mg_child.p, ctx->mg_chw.p, ctx->mg_d0.p, fr, ctx->mg_dcinv4.p, crhs);
         {
           const double cl = ctx->mg_clmax, clmin = cl / ctx->mg_ckappa, cth = 0.5 * (cl + clmin), cde = 0.5 * (cl - clmin), csig = cth / cde;
           double crho = 1.0 / csig;
-          launch_cheb_init_f32(st, n4c, crhs, ctx->mg_cones.p, (float)(1.0 / cth), cx, cr, cd);
+          // restriction and the coarse recurrence's start (x = 0, r = rhs, d = rhs / theta) in one launch
+          launch_mg_restrict(st, nc, ctx->mg_chptr.p, ctx->mg_child.p, ctx->mg_chw.p, ctx->mg_d0.p, fr, ctx->mg_dcinv4.p, crhs,
+                             (float)(1.0 / cth), cx, cr, cd);
+          (void)n4c;
           float *ca = cd, *cb = ct;
           for (int k = 0; k < ctx->mg_cits; ++k) {
             const double rn = 1.0 / (2.0 * csig - crho);
@@ -574,6 +580,7 @@ namespace host {
 
 int refresh_preconditioner(FsiCtx* ctx) {
   Phase ph(ctx, &ctx->t_fac);
+  ctx->xs_zeroed = nullptr;          // (the refresh uses ctx->blk as scratch: the next application zeroes its solid-predictor vector again)
   hipStream_t st = ctx->stream;
   int32_t flags[4] = {0, 0, 0, 0};
   if (!ctx->coloured && ctx->precond != 0) {
