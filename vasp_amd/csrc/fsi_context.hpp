@@ -332,6 +332,7 @@ struct FsiCtx {
   // residual below utol * b_unscaled - Newton's policy reads the unscaled |b|, the Krylov method minimises the row-equilibrated
   // one, and the rows differ by twelve decades - or the tolerance is tightened towards utol_rtol_floor (the non-adaptive value)
   double utol = 0.0, utol_rtol_floor = 0.0, b_unscaled = 0.0;
+  double utol_ratio = 0.0;                   // (unscaled / scaled) relative residual at the last check under this Jacobian: where the next adaptive solve starts
   int64_t utol_tightened = 0;
   double newton_late_factor = 10.0;          // "late": the previous update norm (or |b|) is within this factor of its tolerance
   int64_t newton_late_solves = 0;

@@ -489,6 +489,10 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol_in, int max
     const double lowest = ctx->tol_hint > 0.0 ? std::min(ctx->tol_hint, rtol) : rtol;
     ctx->kry_fp32 = lowest > ctx->tune.krylov_fp32_floor;
   }
+  // adaptive solve: start where the last check under this Jacobian says the unscaled criterion will be met (a re-entered cycle
+  // costs a projection on the kept space and a flush - three passes over the store - so guessing right the first time matters)
+  if (ctx->utol > 0.0 && ctx->utol_ratio > 0.0 && rtol > ctx->utol_rtol_floor)
+    rtol = std::max(ctx->utol_rtol_floor, std::min(rtol, 0.7 * ctx->utol / ctx->utol_ratio));
   // the kept directions serve every later solve with this matrix, so the tightest tolerance asked for since the refresh
   // decides the re-orthogonalisation criterion, not this solve's
   ctx->gs_rtol = ctx->gs_rtol > 0.0 ? std::min(ctx->gs_rtol, rtol) : rtol;
@@ -610,6 +614,7 @@ int solve_gcr(FsiCtx* ctx, const double* rhs, double* x, double rtol_in, int max
   double ru = 0.0;
   launch_div(st, ctx->tmp3.p, r, ctx->rowscale.p, n);
   FSICHK(gnorm2(ctx, ctx->tmp3.p, &ru));
+  if (rnorm > 0.0 && ctx->b_unscaled > 0.0) ctx->utol_ratio = (ru / ctx->b_unscaled) / (rnorm / bnorm);
   if (!(ru > ctx->utol * ctx->b_unscaled)) break;
   const double want = 0.5 * ctx->utol * ctx->b_unscaled / ru;              // aim a factor two below
   rtol = std::max(ctx->utol_rtol_floor, rtol * std::min(0.5, std::max(0.02, want)));

@@ -64,6 +64,7 @@ int fsi_assemble_jacobian(FsiCtx* ctx) {
   }
   gcr_reset(ctx);          // the recycled directions belong to the previous matrix
   for (double& h : ctx->nw_hist) h = 0.0;      // ... and so does what was learnt about the Newton iteration's contraction
+  ctx->utol_ratio = 0.0;                       // ... and about the row scaling's effect on its residuals
   // what decides the storage precision of the basis belongs to the Jacobian that has just been replaced: the largest
   // right-hand side seen (one large early |b|, e.g. the first step from rest, must not keep tol_hint low for the whole run)
   // and a fall-back to FP64 after a failed cycle (a system that lost FP32 once may not lose it with the next matrix; after
@@ -132,7 +133,7 @@ int fsi_newton_solve(FsiCtx* ctx, const FsiNewtonOpts* o, FsiNewtonIter* iters, 
     // What a quasi-Newton iteration can gain is bounded by its (stale) Jacobian, not by its linear solve: on the bench the first
     // iteration of a time step was solved to 2e-6 and contracted the residual by 3e-3, step after step (and the aneurysm file at
     // its own tolerances: solved to 1e-9, contracted by 1e-3).  The contraction the iteration of the SAME INDEX reached one time
-    // step ago, under the same Jacobian, is known; a linear residual a tenth of that (`newton_adaptive`) cannot show in the next
+    // step ago, under the same Jacobian, is known; a linear residual a fifth of that (`newton_adaptive` = 0.2) cannot show in the next
     // nonlinear residual.  What is remembered is the contraction net of the linear tolerance that was allowed (rho_obs - eta: the
     // two add at worst), so a looser solve cannot feed back into a looser solve.  Never looser than 1e-2, never applied to an
     // iteration that refreshes the Jacobian (nothing is known about the new one), and the late rule below still tightens what is
