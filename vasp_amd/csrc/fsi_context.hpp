@@ -325,7 +325,7 @@ struct FsiCtx {
   double newton_forcing_late = 3e-3;         // forcing term of late Newton iterations (see fsi_newton_solve); >= newton_forcing or 0: off.
                                              // Round 4 scan (profiles/r04_forcing_scan.txt): distance of the known-answer run to the exact-solve
                                              // trajectory 4.7e-6 -> 1.4e-6 in v for +3 % of the bench's time step (2e-3: 1.0e-6 / +7 %; 1e-3: 5.6e-7 / +8 %)
-  double newton_adaptive = 0.2;              // forcing term from the contraction the Newton iteration of the same index reached one time step ago (see fsi_newton_solve); 0: off
+  double newton_adaptive = 0.3;              // forcing term from the contraction the Newton iteration of the same index reached one time step ago (see fsi_newton_solve); 0: off
   double nw_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // that contraction, net of the linear residual that was allowed; 0 = not known (reset with the Jacobian)
   int64_t newton_adaptive_solves = 0;
   // adaptive solves only (set by fsi_newton_solve around its fsi_solve, zero otherwise): the answer must also leave an UNSCALED

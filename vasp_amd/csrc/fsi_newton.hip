@@ -133,7 +133,7 @@ int fsi_newton_solve(FsiCtx* ctx, const FsiNewtonOpts* o, FsiNewtonIter* iters, 
     // What a quasi-Newton iteration can gain is bounded by its (stale) Jacobian, not by its linear solve: on the bench the first
     // iteration of a time step was solved to 2e-6 and contracted the residual by 3e-3, step after step (and the aneurysm file at
     // its own tolerances: solved to 1e-9, contracted by 1e-3).  The contraction the iteration of the SAME INDEX reached one time
-    // step ago, under the same Jacobian, is known; a linear residual a fifth of that (`newton_adaptive` = 0.2) cannot show in the next
+    // step ago, under the same Jacobian, is known; a linear residual of 0.3 x that (`newton_adaptive`) cannot show in the next
     // nonlinear residual.  What is remembered is the contraction net of the linear tolerance that was allowed (rho_obs - eta: the
     // two add at worst), so a looser solve cannot feed back into a looser solve.  Never looser than 1e-2, never applied to an
     // iteration that refreshes the Jacobian (nothing is known about the new one), and the late rule below still tightens what is
