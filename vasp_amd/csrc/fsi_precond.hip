@@ -133,7 +133,8 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
   // velocity correction.  Work vectors of the two chains are disjoint: the solid and displacement sweeps use IW[0, 4 n3),
   // the fluid sweeps IW[6 n3, 10 n3), the Schur sweeps the unused tail of rp (V of its n3 entries carry r_p).
   const bool conc = ctx->prec_streams && ctx->stream2 && ctx->solid_fp32 && ctx->solid_block_jacobi && ctx->solid_fused && ctx->sbmg_ready &&
-                    ctx->sweeps_fp32 && ctx->tiled && ctx->fused_sweeps && ctx->cheb_its_p > 0 && ctx->schur_fp32 == 1 && ctx->s_vals32.p &&
+                    ctx->sweeps_fp32 && ctx->tiled && ctx->fused_sweeps && ctx->cheb_its_p > 0 &&
+                    ((ctx->schur_fp32 == 1 && ctx->s_vals32.p) || ctx->schur_fp32 == 0) &&      // (round 5: also with the all-FP64 Schur sweeps - the FP64-storage mode ran its ~5 ms application as ONE chain)
                     ctx->pv32_ok && ctx->adv_is_db && ctx->cheb_its_d > 0 && ctx->dd_is_scalar && 4 * V <= n3 && ctx->debug_prec_apply == 0;
   // (the applications whose sweep launches are timed by event pairs issue both chains on the solver stream - the same arithmetic in
   // the same order per chain, and a pair brackets its kernel alone)
@@ -330,7 +331,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
     // all-FP64 Schur sweeps, product fused with the Chebyshev update (one launch per sweep)
     const double lmax = ctx->lmax_p, lmin = lmax / ctx->cheb_kappa_p, th = 0.5 * (lmax + lmin), de = 0.5 * (lmax - lmin), sig = th / de;
     double rho = 1.0 / sig;
-    double *pr = IW, *pa = IW + V, *pb = IW + 2 * V;
+    double *pr = conc ? rp + V : IW, *pa = pr + V, *pb = pr + 2 * V;      // two chains: the Schur vectors live in the unused tail of rp, IW is stream A's
     launch_cheb_init(st, V, nullptr, tp, ctx->s_diagpos.p, ctx->s_vals.p, 1.0 / th, dp, pr, pa);
     for (int k = 0; k < ctx->cheb_its_p; ++k) {
       const double rn = 1.0 / (2.0 * sig - rho);
