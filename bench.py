@@ -54,7 +54,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # orthogonalisation group holds the FP32 column kernels AND the FP64-window kernels, the outer product both value types.
 KERNEL_GROUPS = {"k_gcr_dots": ["k_gcr_dots<", "k_gcr_axpy<"],
                  "k_gcr_flush": ["k_gcr_flush<"],
-                 "k_spmv_node6": ["k_spmv_node6<", "k_spmv_node6p<", "k_spmv_prow<", "k_spmv<0,"],
+                 "k_spmv_node6": ["k_spmv_node6<", "k_spmv_node6p<", "k_spmv_node6c<", "k_spmv_node6pc<", "k_spmv_prow<", "k_spmv<0,"],
                  "k_spmv_tiled_f32<1>": ["k_spmv_tiled_f32<1>"], "k_spmv_tiled_f32<3>": ["k_spmv_tiled_f32<3>"],
                  "k_sweep_tiled_f32<1>": ["k_sweep_tiled_f32<1>"], "k_sweep_tiled_f32<3>": ["k_sweep_tiled_f32<3>"],
                  "k_sweep_tiled_h<1>": ["k_sweep_tiled_h<1>"], "k_sweep_tiled_h<3>": ["k_sweep_tiled_h<3>"], "k_sweep_sb_h": ["k_sweep_sb_h"],
@@ -290,6 +290,11 @@ def main():
         z_bytes = (tm["ortho_z_cols"] * tm["ldz"] * 8.0) / z_launches + ndof_rank * 24.0
         generic = bool(os.environ.get("FSI_SPMV_GENERIC"))
         op32 = int(tm.get("spmv_fp32_calls", 0))
+        vbytes = 8.0 - 4.0 * op32 / max(tm["spmv_calls"], 1)                  # mean bytes per matrix value over the products of the region
+        # the d rows in pair form (sweep_flags bit 6: adopted by the last refresh's check): their 3 x (6 deg + pdeg) stored values per
+        # node are not read; 6 values + one neighbour rank per node pair are
+        drows = bool(flags & 64) and not generic
+        drows_skipped = 3.0 * (6.0 * tm["node_pairs"] + tm["node_vertex_pairs"]) if drows else 0.0
         kernels = {
             f"k_gcr_dots + k_gcr_axpy (Gram-Schmidt against the kept directions: Q in FP{8 * qb} streamed once per launch, "
             f"mean {tm['ortho_q_cols'] / q_launches:.0f} columns)":
@@ -317,11 +322,13 @@ def main():
                 (sch_avg * tm["inner_schur_iters"], int(tm["inner_schur_iters"]),
                  tm["schur_nnz"] * (tm["schur_elem_bytes"] + 4.0) + tm["schur_rows"] * 8.0 * 5),
             (f"k_spmv_node6 (monolithic Jacobian, one i32 column per six entries, {op32} of {int(tm['spmv_calls'])} products on the FP32 "
-             "copy of the values, the rest FP64; + k_spmv<0> on the pressure rows)"
+             "copy of the values, the rest FP64; "
+             + ("displacement rows from their pair form: six values per node pair instead of 18 + pressure columns; " if drows else "")
+             + "+ k_spmv_prow on the pressure rows)"
              if not generic else "k_spmv<0> (monolithic Jacobian, CSR f64 + i32)"):
                 (tm["spmv_ms"], tm["spmv_calls"],
-                 nnz * (8.0 - 4.0 * op32 / max(tm["spmv_calls"], 1) + (4.0 / 6.0 if not generic else 4.0))
-                 + ndof_rank * 16.0 + (ndof_rank + 1) * 8.0),
+                 (nnz - drows_skipped + 6.0 * tm["node_pairs"] * (1 if drows else 0)) * vbytes + nnz * (4.0 / 6.0 if not generic else 4.0)
+                 + (4.0 * tm["node_pairs"] if drows else 0.0) + ndof_rank * 16.0 + (ndof_rank + 1) * 8.0),
             # 1 676 B per tet (the scatter counted once; the element-vector round trip of the reproducible
             # gather form - 2 x 512 B per tet - is overhead, not algorithmic)
             "k_residual + k_residual_gather (element residual; per-dof sum of the element vectors in a fixed order)":
@@ -446,7 +453,8 @@ def main():
                                          "seconds_per_assembly": jac_k["avg_launch_ms"] * 1e-3,
                                          "note": "k_jacobian incl. the scatter into the CSR matrix and the matrix finish"},
                    "spmv": {"GBps_algorithmic": spmv_k["achieved_GBps"], "seconds_per_product": spmv_k["avg_launch_ms"] * 1e-3,
-                            "note": "k_spmv_node6: one i32 column per six entries (8.67 B per entry against the CPU port's 12)"}}
+                            "note": "k_spmv_node6: one i32 column per six entries (8.67 B per entry against the CPU port's 12)"
+                                    + ("; displacement rows in pair form (a third of the node rows' values not read)" if drows else "")}}
             out["cpu_baseline"] = cpu_baseline(desc, gpu)
         print(json.dumps(out))
     if dist is not None:

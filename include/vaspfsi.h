@@ -147,7 +147,10 @@ typedef struct FsiTuning {
   /* round 5 (fields are appended: struct_size tells an older caller's struct from this one) */
   int32_t solid_coarse_exact;  /* 1: the solid cycle's coarse level is solved exactly - block cyclic reduction over breadth-first levels of
                                 * the solid vertices, operators refreshed with the Jacobian (csrc/fsi_bcr.hip) - instead of sbmg_cits sweeps */
-  int32_t reserved0;
+  int32_t compact_drows;       /* 1: the outer product takes the three displacement rows of a node from a pair form - [dd_ii, dv_ii] per
+                                * node pair, six values instead of 18 + pressure columns - extracted at every Jacobian refresh together
+                                * with a check that those rows hold nothing else (they do not for the forms of SURVEY.md A.2: the mesh
+                                * extension and the solid's d - v relation act per component); 0: all six value rows are streamed */
   double bcr_shift;            /* ... of A_c + bcr_shift * blockdiag(A_c): the floor below which the level's modes are damped, not inverted */
   double newton_adaptive;      /* linear tolerance >= this x the contraction the Newton iteration of the same index reached one time
                                 * step ago under the same Jacobian (net of its own linear tolerance); 0: off.  fsi_newton_solve */
@@ -341,8 +344,9 @@ typedef struct FsiTimers {
                                                         state, not the environment's): bit 0 tiled sweeps fused with
                                                         the Chebyshev update, 1 FP16 packed records, 2 solid block in
                                                         FP32, 3 solid sweeps fused (block Jacobi), 4 solid two-level
-                                                        cycle ready, 5 displacement two-level cycle ready, 6 solid
-                                                        dense third level ready                                       */
+                                                        cycle ready, 5 displacement two-level cycle ready, 6 the
+                                                        outer products take the displacement rows from their pair
+                                                        form (FsiTuning.compact_drows, checked at the last refresh)   */
   int64_t part_allreduces;                           /* partitioned runs: all-reduces issued inside Krylov iterations
                                                         (FP64 basis: one per Gram-Schmidt pass; FP32 basis: two per pass
                                                         + one for its FP64 window; + one when an iteration looks

@@ -721,6 +721,58 @@ def test_mfma_jacobian_kernel_matches_the_complex_step_oracle(case_name, tmp_pat
     assert both.max() < 1e-13, (case_name, both.max())                     # two summation orders of the same contraction
 
 
+@pytest.mark.parametrize("case_name", ["cylinder", "mooney_rivlin", "robin"])
+def test_displacement_rows_in_pair_form_give_the_same_products(case_name, tmp_path):
+    """Round 5: the outer product takes the three displacement rows of a node from a pair form (``FsiTuning.compact_drows``: [dd_ii,
+    dv_ii] per node pair, extracted and CHECKED at every refresh).  Here: the library adopts the form on the StVK, the MooneyRivlin +
+    Robin and the Robin-wall cases (``sweep_flags`` bit 6), the assembled matrix really has nothing else in those rows (checked on the
+    host from ``fsi_get_matrix``, i.e. from the other side), and the product equals the one of a context that streams all six value
+    rows (to round-off: the sums run in another order) and the oracle's."""
+    from oracle.fsi_oracle import FsiOracle
+    from vasp_amd.capi import HipBackend
+    if case_name == "mooney_rivlin":
+        case = prepare_case("predeform", GOLDEN / "cylinder" / "cylinder.h5", tmp_path, dt="0.01", T="0.02", theta="1.0")
+    else:
+        case = prepare_case("cylinder", GOLDEN / "cylinder" / "cylinder.h5", tmp_path)
+    ns, desc = case[0], dict(case[1])
+    mesh = ns["mesh"]
+    if case_name == "robin":
+        fids = np.nonzero(ns["boundaries"] == 33)[0]
+        desc["robin_facets"] = mesh.facet_nodes[fids]
+        desc["robin_k"] = np.full(len(fids), 1e5)
+        desc["robin_c"] = np.full(len(fids), 10.0)
+    o = FsiOracle(desc)
+    U, U1 = random_state(mesh, o.ndof, seed=23)
+    g, P = boundary_data(case, 0.05)
+    o.solver_setup(np.zeros(o.ndof), np.zeros(o.ndof))
+    A_ref = o.jacobian(U, U1)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(o.ndof)
+    ys, A = {}, None
+    for compact in (1, 0):
+        hb = HipBackend(desc, tuning=dict(compact_drows=compact))
+        assert hb.tuning()["compact_drows"] == compact
+        hb.set_state("n", U); hb.set_state("n-1", U1); hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+        hb.assemble_residual()
+        hb.assemble_jacobian()
+        assert bool(int(hb.timers()["sweep_flags"]) & 64) == bool(compact)      # adopted by the refresh's own check / not asked for
+        ys[compact] = hb.spmv(x)
+        if compact:
+            A = hb.matrix().tocsr()
+        hb.close()
+    # the d rows of the assembled matrix from the host's side: row (node, i) has entries in the columns d_i and v_i of its neighbours only
+    nd = 3 * mesh.num_nodes
+    Ad = A[:nd].tocoo()
+    keep = Ad.data != 0.0
+    rows, cols = Ad.row[keep], Ad.col[keep]
+    assert cols.max() < 2 * nd                                                   # no pressure column
+    assert np.array_equal(rows % 3, cols % 3)                                    # [d | v | p] numbering, three components per node
+    ref = A_ref @ x
+    scale = np.abs(ref).max()
+    assert np.abs(ys[1] - ys[0]).max() <= 1e-13 * scale, np.abs(ys[1] - ys[0]).max() / scale
+    assert np.abs(ys[1] - ref).max() <= 1e-10 * scale
+
+
 def test_predeform_runs(tmp_path):
     """REF tests/test_simulations.py:60-77: the predeform problem runs a few steps; printed flow properties are sane."""
     import re

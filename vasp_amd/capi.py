@@ -58,7 +58,7 @@ class FsiTuning(C.Structure):
                 ("sbmg_pre", C.c_int32), ("sbmg_post", C.c_int32), ("sbmg_cits", C.c_int32), ("sbmg_alpha", C.c_double),
                 ("sbmg_ckappa", C.c_double),
                 ("mg_pre", C.c_int32), ("mg_post", C.c_int32), ("mg_cits", C.c_int32), ("mg_alpha", C.c_double), ("mg_ckappa", C.c_double),
-                ("solid_coarse_exact", C.c_int32), ("reserved0", C.c_int32), ("bcr_shift", C.c_double), ("newton_adaptive", C.c_double)]
+                ("solid_coarse_exact", C.c_int32), ("compact_drows", C.c_int32), ("bcr_shift", C.c_double), ("newton_adaptive", C.c_double)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

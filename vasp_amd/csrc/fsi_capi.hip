@@ -165,7 +165,7 @@ int fsi_destroy(FsiCtx* ctx) {
                            &ctx->tmp7, &ctx->scratch, &ctx->bc_vals, &ctx->pf_coef, &ctx->rb_val, &ctx->KZ, &ctx->hcoef,
                            &ctx->gcr_out, &ctx->gcr_y, &ctx->gcr_cn, &ctx->KQh, &ctx->hcoef_hot};
   for (auto* b : dbl) b->release();
-  ctx->KQ.release(); ctx->A32.release(); ctx->a32_ptr.release(); ctx->a32_cols.release();
+  ctx->KQ.release(); ctx->A32.release(); ctx->a32_ptr.release(); ctx->a32_cols.release(); ctx->Ad64.release(); ctx->Ad32.release();
   ctx->gcr_slots.release();
   ctx->gv_idx.release();
   if (ctx->gcr_host) { (void)hipHostFree(ctx->gcr_host); ctx->gcr_host = nullptr; }
@@ -1522,7 +1522,7 @@ int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset) {
                    ctx->op32_products,
                    (int64_t)((ctx->tiled && ctx->fused_sweeps ? 1 : 0) | (ctx->tiled && ctx->fused_sweeps && ctx->sweeps_fp16 ? 2 : 0) |
                              (ctx->solid_fp32 ? 4 : 0) | (ctx->solid_fp32 && ctx->solid_block_jacobi && ctx->solid_fused ? 8 : 0) |
-                             (ctx->sbmg_ready ? 16 : 0) | (ctx->mg_ready ? 32 : 0)),
+                             (ctx->sbmg_ready ? 16 : 0) | (ctx->mg_ready ? 32 : 0) | (ctx->drows_ok ? 64 : 0)),
                    ctx->part_allreduces, (int64_t)ctx->ncellcol, ctx->gcr_arnoldi_steps, ctx->gcr_restarts, ctx->newton_retries,
                    (int64_t)ctx->kry_fp32_failures_total, ctx->verdicts_skipped, ctx->gcr_reorth_forced, ctx->dd_cache_hits,
                    ctx->newton_late_solves};

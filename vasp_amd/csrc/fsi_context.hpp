@@ -287,6 +287,12 @@ struct FsiCtx {
   fsi::DevBuf<int64_t> a32_ptr;              // [N2 + 1] first entry of a node's padded block in A32 (k_spmv_node6p)
   fsi::DevBuf<int32_t> a32_cols;             // padded index rows
   int64_t a32_ptail = 0, a32_tail_src = 0, a32_tail_nnz = 0;     // pressure rows: behind the padded node blocks, unpadded
+  // d rows of the node blocks in pair form (k_drows_extract: six values per node pair instead of 18; FsiTuning.compact_drows):
+  // refreshed and CHECKED with every Jacobian - drows_ok only while nothing else was found in those rows
+  fsi::DevBuf<double> Ad64;                  // [6 x node pairs]
+  fsi::DevBuf<float> Ad32;                   // ... rounded, for the products on the FP32 copy
+  bool drows_ok = false;
+  int64_t drows_products = 0;
   bool gcr_stagnated = false;                // the last cycle ended on 40 iterations without a 10 % gain
   bool gcr_stalled = false;                  // ... on 80 iterations without a 10 % gain far from its target (truncated recurrence stuck)
   double f32_cycle_floor = 1e-6;             // FP32 basis: a cycle reduces the residual by at most this factor before the FP64 verdict

@@ -152,9 +152,14 @@ struct PRowGraph {
 };
 void launch_pad_cols32(hipStream_t st, int64_t N2, const int64_t* rowptr, const int32_t* cols, const int64_t* p32, int32_t* cols32);
 void launch_pad_vals32(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const double* A, const int64_t* p32,
-                       int64_t ptail, int64_t nnz_tail, int64_t tail_src, float* A32);
+                       int64_t ptail, int64_t nnz_tail, int64_t tail_src, float* A32, bool v_rows_only = false);
+// d rows of the node blocks in pair form [dd_0 dd_1 dd_2 dv_0 dv_1 dv_2] per node pair (fsi_solver.hip); flag bit 0: a d row holds
+// something else and the products must keep the full rows
+void launch_drows_extract(hipStream_t st, int64_t N2, const int64_t* rowptr, const double* A, const int64_t* nadj_ptr, double* ad64,
+                          float* ad32, int32_t* flag);
 void launch_spmv_node6p(hipStream_t st, int64_t N2, int64_t V, const int64_t* p32, const int32_t* cols32, const float* vals,
-                        const int64_t* rowptr, const int32_t* cols, int64_t tail_shift, const PRowGraph& g, const double* x, double* y);
+                        const int64_t* rowptr, const int32_t* cols, int64_t tail_shift, const PRowGraph& g, const double* x, double* y,
+                        const float* ad32 = nullptr);
 void launch_round_to_f32(hipStream_t st, int64_t n, const double* a, float* b);
 void launch_spmv(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const double* vals,
                  const double* x, double* y, int tag = SPMV_FIELD_BLOCK);
@@ -276,7 +281,7 @@ void launch_mg_prolong(hipStream_t st, int64_t N2, const int32_t* par, const flo
 void launch_residual_rows(hipStream_t st, int64_t nrows, const int32_t* rows, const int64_t* ptr, const int32_t* col,
                           const int64_t* src, const double* vals, const double* x, const double* b, double* y);
 void launch_spmv_node6(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const double* vals,
-                       const PRowGraph& g, const double* x, double* y);
+                       const PRowGraph& g, const double* x, double* y, const double* ad64 = nullptr);
 void launch_sweep_csr_mixed(hipStream_t st, int64_t n, const int64_t* rowptr, const int32_t* cols, const float* vals,
                             const int64_t* diagpos, const double* dvals, double c1, double c2, const double* din, double* dout,
                             double* x, double* r);

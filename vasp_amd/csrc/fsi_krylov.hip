@@ -17,10 +17,13 @@ int spmv(FsiCtx* ctx, const double* x, double* y, bool working) {
   if (working && ctx->op32_ok && ctx->kry_fp32) {
     ctx->op32_products += 1;
     launch_spmv_node6p(ctx->stream, ctx->N2, ctx->V, ctx->a32_ptr.p, ctx->a32_cols.p, ctx->A32.p, ctx->rowptr.p, ctx->cols.p,
-                       ctx->a32_ptail - ctx->a32_tail_src, g, x, y);
+                       ctx->a32_ptail - ctx->a32_tail_src, g, x, y, ctx->drows_ok ? ctx->Ad32.p : nullptr);
+    if (ctx->drows_ok) ctx->drows_products += 1;
     return FSI_OK;
   }
-  launch_spmv_node6(ctx->stream, ctx->N2, ctx->V, ctx->rowptr.p, ctx->cols.p, ctx->A.p, g, x, y);
+  // (drows_ok: the d rows from their pair form - six values per node pair, checked at the refresh - instead of 18 + pressure columns)
+  launch_spmv_node6(ctx->stream, ctx->N2, ctx->V, ctx->rowptr.p, ctx->cols.p, ctx->A.p, g, x, y, ctx->drows_ok ? ctx->Ad64.p : nullptr);
+  if (ctx->drows_ok) ctx->drows_products += 1;
   return FSI_OK;
 }
 

@@ -57,9 +57,25 @@ int fsi_assemble_jacobian(FsiCtx* ctx) {
     if (getenv("FSI_DEBUG")) { HIPCHK(hipStreamSynchronize(ctx->stream)); fprintf(stderr, "[fsi] matrix finish done\n"); fflush(stderr); }
   }
   ctx->op32_ok = false;
-  if (ctx->op32_policy && ctx->kry_fp32_policy != 0 && ctx->precond == 0 && ctx->A32.p) {
+  const bool copy32 = ctx->op32_policy && ctx->kry_fp32_policy != 0 && ctx->precond == 0 && ctx->A32.p;
+  // the d rows in pair form for the outer products (FsiTuning.compact_drows): extracted from THIS matrix, and adopted only if the
+  // kernel found nothing else in those rows (one flag read per refresh)
+  ctx->drows_ok = false;
+  if (ctx->tune.compact_drows && ctx->N2 > 0) {
+    const size_t npairs6 = 6 * (size_t)ctx->nadj.n;
+    if (!ctx->Ad64.p) HIPCHK(ctx->Ad64.alloc(npairs6));
+    if (copy32 && !ctx->Ad32.p) HIPCHK(ctx->Ad32.alloc(npairs6));
+    HIPCHK(hipMemsetAsync(ctx->iflags.p + 20, 0, sizeof(int32_t), ctx->stream));
+    launch_drows_extract(ctx->stream, ctx->N2, ctx->rowptr.p, ctx->A.p, ctx->nadj_ptr.p, ctx->Ad64.p, copy32 ? ctx->Ad32.p : nullptr, ctx->iflags.p + 20);
+    int32_t found = 1;
+    HIPCHK(hipMemcpyAsync(&found, ctx->iflags.p + 20, sizeof found, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->drows_ok = found == 0;
+    if (getenv("FSI_DEBUG")) fprintf(stderr, "[fsi] displacement rows of the outer product in pair form: %s\n", ctx->drows_ok ? "yes" : "no (other entries found)");
+  }
+  if (copy32) {
     launch_pad_vals32(ctx->stream, ctx->N2, ctx->V, ctx->rowptr.p, ctx->A.p, ctx->a32_ptr.p, ctx->a32_ptail, ctx->a32_tail_nnz,
-                      ctx->a32_tail_src, ctx->A32.p);       // rows are equilibrated: |entries| <= 1
+                      ctx->a32_tail_src, ctx->A32.p, ctx->drows_ok);       // rows are equilibrated: |entries| <= 1
     ctx->op32_ok = true;
   }
   gcr_reset(ctx);          // the recycled directions belong to the previous matrix

@@ -242,6 +242,106 @@ __global__ __launch_bounds__(256) void k_spmv_node6(int64_t N2, const int64_t* _
     if (lane == 0) { double* o = y + 6 * r; o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5; }
   }
 }
+// ---- displacement rows in pair form (round 5) -------------------------------------------------------------------------------
+// The three d rows of a node hold 6 deg + pdeg entries each, of which at most 2 deg are structurally non-zero for the forms VaSP
+// uses: the mesh-extension Laplacian and the solid's d - v relation act per component, so row (r, i) has dd_ii and dv_ii per
+// neighbour and no pressure entry - 18 of the 36 values of a node pair carry 6 numbers.  k_drows_extract copies those six per
+// pair [dd_0 dd_1 dd_2 dv_0 dv_1 dv_2] at every Jacobian refresh AND checks that every other entry of the d rows is exactly zero
+// (flag bit 0 otherwise: the full product stays).  The products then stream the three v rows as before and take the d rows
+// from the pair array with one lane per neighbour (48 contiguous bytes of values against the 48 contiguous bytes of x of that
+// neighbour): 24 deg + 3 pdeg values + 6 deg pair values per node instead of 36 deg + 6 pdeg.
+// (Round 2's "compact node rows" re-laid ALL 24 non-zeros as 24 short runs per node and was latency-bound: 3.46 against 3.20 ms.
+// Here the v rows keep their three long streams.)
+template <class DT>
+__global__ __launch_bounds__(256) void k_drows_extract(int64_t N2, const int64_t* __restrict__ rowptr, const double* __restrict__ A,
+                                                       const int64_t* __restrict__ nadj_ptr, double* __restrict__ ad64,
+                                                       DT* __restrict__ ad32, int32_t* __restrict__ flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  bool bad = false;
+  for (int64_t r = wave; r < N2; r += nwaves) {
+    const int64_t s0 = rowptr[6 * r], L = rowptr[6 * r + 1] - s0, a = nadj_ptr[r], deg6 = 6 * (nadj_ptr[r + 1] - a);
+    for (int i = 0; i < 3; ++i)
+      for (int64_t t = lane; t < L; t += 64) {
+        const double v = A[s0 + i * L + t];
+        const int c = (int)(t % 6);
+        if (t < deg6 && (c == i || c == i + 3)) {
+          const int64_t o = 6 * (a + t / 6) + (c == i ? i : 3 + i);
+          ad64[o] = v;
+          if (ad32) ad32[o] = (DT)v;
+        } else if (v != 0.0) bad = true;
+      }
+  }
+  if (bad) atomicOr(flag, 1);
+}
+void launch_drows_extract(hipStream_t st, int64_t N2, const int64_t* rowptr, const double* A, const int64_t* nadj_ptr, double* ad64,
+                          float* ad32, int32_t* flag) {
+  int64_t blocks = std::min<int64_t>((N2 + 3) / 4, 16384);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_drows_extract<float>, dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, A, nadj_ptr, ad64, ad32, flag);
+}
+// the d rows of node r from the pair array: lane k takes neighbour k (AT: double | float)
+template <class AT>
+__device__ inline void drows_pairs(const AT* __restrict__ ad, const int32_t* __restrict__ nadj, int64_t a, int64_t deg, int lane,
+                                   const double* __restrict__ x, double& a0, double& a1, double& a2) {
+  for (int64_t k = lane; k < deg; k += 64) {
+    const double2* xp = reinterpret_cast<const double2*>(x + 6 * (int64_t)nadj[a + k]);
+    double d0, d1, d2, v0, v1, v2;
+    if (sizeof(AT) == 8) {
+      const double2* p = reinterpret_cast<const double2*>(ad + 6 * (a + k));
+      const double2 p0 = p[0], p1 = p[1], p2 = p[2];
+      d0 = p0.x; d1 = p0.y; d2 = p1.x; v0 = p1.y; v1 = p2.x; v2 = p2.y;
+    } else {
+      const float2* p = reinterpret_cast<const float2*>(ad + 6 * (a + k));
+      const float2 p0 = p[0], p1 = p[1], p2 = p[2];
+      d0 = p0.x; d1 = p0.y; d2 = p1.x; v0 = p1.y; v1 = p2.x; v2 = p2.y;
+    }
+    const double2 x0 = xp[0], x1 = xp[1], x2 = xp[2];      // d_x d_y | d_z v_x | v_y v_z of the neighbour
+    a0 += d0 * x0.x + v0 * x1.y;
+    a1 += d1 * x0.y + v1 * x2.x;
+    a2 += d2 * x1.x + v2 * x2.y;
+  }
+}
+// k_spmv_node6 with the d rows in pair form: value rows 3 .. 5 of the node's block only.  The node index is made wave-uniform
+// for the compiler (readfirstlane), so the row and graph pointers come through the scalar cache.
+// (Also measured at 1.12 M tets, FP64 / FP32 copy, ms per product; this form 2.27 / 1.67, all six rows 2.56 - 2.72 / 1.73 - 1.82:
+// the v rows taken neighbour by neighbour like the d rows - no column indices, x gathered once per neighbour, 48 contiguous bytes
+// per lane and row - 2.27 / 1.93: 45 % of the lanes idle on a 29-neighbour node, 90 - 100 VGPRs; four strips of 64 entries issued
+// together, a 182-entry row in one round of index -> gather: 2.45, two strips: 2.14 (the same): the product wants many small waves,
+// not deep ones.  The scalar pointers took this form from 2.27 / 1.67 to 2.14 / 1.58.)
+template <bool XCD>
+__global__ __launch_bounds__(256) void k_spmv_node6c(int64_t N2, const int64_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ cols, const double* __restrict__ vals,
+                                                     const int64_t* __restrict__ nadj_ptr, const int32_t* __restrict__ nadj,
+                                                     const double* __restrict__ ad, const double* __restrict__ x, double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int64_t first, last, stride;
+  if (XCD) {
+    const int64_t chunk = (N2 + 7) >> 3, k = blockIdx.x & 7;
+    first = k * chunk + (blockIdx.x >> 3) * (int64_t)(blockDim.x >> 6) + wid;
+    last = (k + 1) * chunk < N2 ? (k + 1) * chunk : N2;
+    stride = (int64_t)(gridDim.x >> 3) * (blockDim.x >> 6);
+  } else {
+    first = blockIdx.x * (int64_t)(blockDim.x >> 6) + wid;
+    last = N2;
+    stride = (int64_t)gridDim.x * (blockDim.x >> 6);
+  }
+  for (int64_t r = first; r < last; r += stride) {
+    const int64_t s0 = rowptr[6 * r];
+    const int64_t L = rowptr[6 * r + 1] - s0;
+    const int64_t a = nadj_ptr[r], deg = nadj_ptr[r + 1] - a;
+    const double* v = vals + s0 + 3 * L;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
+    drows_pairs<double>(ad, nadj, a, deg, lane, x, a0, a1, a2);
+    for (int64_t t = lane; t < L; t += 64) {
+      const double xv = x[cols[s0 + t]];
+      a3 += v[t] * xv; a4 += v[L + t] * xv; a5 += v[2 * L + t] * xv;
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3); a4 = wave_sum(a4); a5 = wave_sum(a5);
+    if (lane == 0) { double* o = y + 6 * r; o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5; }
+  }
+}
 // Monolithic SpMV, pressure rows.  The row of vertex q (node rank r = vrank[q]) holds, for every neighbour node s of r in
 // ascending order, the six columns 6 s .. 6 s + 5, then the pressure columns (k_expand_cols): a lane takes a neighbour, reads
 // its rank from the node graph (4 bytes instead of six column indices), the six values and the six x entries - 48 contiguous,
@@ -253,8 +353,9 @@ __global__ __launch_bounds__(256) void k_spmv_prow(int64_t V, const int64_t* __r
                                                    const int64_t* __restrict__ nadj_ptr, const int32_t* __restrict__ nadj,
                                                    const double* __restrict__ x, double* __restrict__ y) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  // (wave-uniform for the compiler: the row's three levels of pointers - row, node rank, node graph - come through the scalar cache)
+  const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   for (int64_t q = wave; q < V; q += nwaves) {
     const int64_t s = prowptr[q], e = prowptr[q + 1];
     const int32_t r = vrank[q];
@@ -291,8 +392,16 @@ static void spmv_node6_any(hipStream_t st, int64_t N2, int64_t V, const int64_t*
   else hipLaunchKernelGGL((k_spmv_node6<VT, false>), dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, cols, vals, x, y);
   spmv_prows<VT>(st, N2, V, rowptr, cols, vals, g, x, y);      // pressure rows
 }
+// ad64 != nullptr: the d rows from their pair form (k_drows_extract found nothing else in them)
 void launch_spmv_node6(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const int32_t* cols, const double* vals,
-                       const PRowGraph& g, const double* x, double* y) {
+                       const PRowGraph& g, const double* x, double* y, const double* ad64) {
+  if (ad64 && g.nadj_ptr && g.nadj) {
+    int64_t blocks = (N2 + 3) / 4;
+    blocks = (blocks + 7) & ~(int64_t)7;
+    hipLaunchKernelGGL(k_spmv_node6c<true>, dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, cols, vals, g.nadj_ptr, g.nadj, ad64, x, y);
+    spmv_prows<double>(st, N2, V, rowptr, cols, vals, g, x, y);
+    return;
+  }
   spmv_node6_any<double>(st, N2, V, rowptr, cols, vals, g, x, y);
 }
 // ---- FP32 copy of the Jacobian in its own layout --------------------------------------------------------------------
@@ -312,12 +421,12 @@ __global__ __launch_bounds__(256) void k_pad_cols32(int64_t N2, const int64_t* _
   }
 }
 __global__ __launch_bounds__(256) void k_pad_vals32(int64_t N2, const int64_t* __restrict__ rowptr, const double* __restrict__ A,
-                                                    const int64_t* __restrict__ p32, float* __restrict__ A32) {
+                                                    const int64_t* __restrict__ p32, float* __restrict__ A32, int row0) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t r = wave; r < N2; r += nwaves) {
     const int64_t s0 = rowptr[6 * r], L = rowptr[6 * r + 1] - s0, Lp = (L + 3) & ~(int64_t)3, o = p32[r];
-    for (int k = 0; k < 6; ++k)
+    for (int k = row0; k < 6; ++k)
       for (int64_t t = lane; t < Lp; t += 64) A32[o + k * Lp + t] = t < L ? (float)A[s0 + k * L + t] : 0.f;
   }
 }
@@ -360,22 +469,71 @@ __global__ __launch_bounds__(256) void k_spmv_node6p(int64_t N2, const int64_t* 
     if (lane == 0) { double* o6 = y + 6 * r; o6[0] = a0; o6[1] = a1; o6[2] = a2; o6[3] = a3; o6[4] = a4; o6[5] = a5; }
   }
 }
+// k_spmv_node6p with the d rows in pair form (FP32 pair values): value rows 3 .. 5 of the padded block only
+template <bool XCD>
+__global__ __launch_bounds__(256) void k_spmv_node6pc(int64_t N2, const int64_t* __restrict__ p32, const int32_t* __restrict__ cols32,
+                                                      const float* __restrict__ vals, const int64_t* __restrict__ nadj_ptr,
+                                                      const int32_t* __restrict__ nadj, const float* __restrict__ ad,
+                                                      const double* __restrict__ x, double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int64_t first, last, stride;
+  if (XCD) {
+    const int64_t chunk = (N2 + 7) >> 3, k = blockIdx.x & 7;
+    first = k * chunk + (blockIdx.x >> 3) * (int64_t)(blockDim.x >> 6) + wid;
+    last = (k + 1) * chunk < N2 ? (k + 1) * chunk : N2;
+    stride = (int64_t)(gridDim.x >> 3) * (blockDim.x >> 6);
+  } else {
+    first = blockIdx.x * (int64_t)(blockDim.x >> 6) + wid;
+    last = N2;
+    stride = (int64_t)gridDim.x * (blockDim.x >> 6);
+  }
+  for (int64_t r = first; r < last; r += stride) {
+    const int64_t o = p32[r];
+    const int Lp = (int)((p32[r + 1] - o) / 6);
+    const int64_t a = nadj_ptr[r], deg = nadj_ptr[r + 1] - a;
+    const float* v = vals + o + 3 * (int64_t)Lp;
+    const int32_t* c = cols32 + o / 6;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
+    drows_pairs<float>(ad, nadj, a, deg, lane, x, a0, a1, a2);
+    for (int t = 4 * lane; t < Lp; t += 256) {
+      const int4 cc = *reinterpret_cast<const int4*>(c + t);
+      const float4 v3 = *reinterpret_cast<const float4*>(v + t), v4 = *reinterpret_cast<const float4*>(v + Lp + t),
+                   v5 = *reinterpret_cast<const float4*>(v + 2 * Lp + t);
+      const double x0 = x[cc.x], x1 = x[cc.y], x2 = x[cc.z], x3 = x[cc.w];
+      a3 += ((double)v3.x * x0 + (double)v3.y * x1) + ((double)v3.z * x2 + (double)v3.w * x3);
+      a4 += ((double)v4.x * x0 + (double)v4.y * x1) + ((double)v4.z * x2 + (double)v4.w * x3);
+      a5 += ((double)v5.x * x0 + (double)v5.y * x1) + ((double)v5.z * x2 + (double)v5.w * x3);
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3); a4 = wave_sum(a4); a5 = wave_sum(a5);
+    if (lane == 0) { double* o6 = y + 6 * r; o6[0] = a0; o6[1] = a1; o6[2] = a2; o6[3] = a3; o6[4] = a4; o6[5] = a5; }
+  }
+}
 void launch_pad_cols32(hipStream_t st, int64_t N2, const int64_t* rowptr, const int32_t* cols, const int64_t* p32, int32_t* cols32) {
   int64_t blocks = std::min<int64_t>((N2 + 3) / 4, 8192);
   hipLaunchKernelGGL(k_pad_cols32, dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, cols, p32, cols32);
 }
 // node rows padded (k_pad_vals32), pressure rows as they are behind them at entry offset ptail
+// (v_rows_only: the d rows are served from their pair form - k_spmv_node6pc never reads value rows 0 .. 2 of the copy)
 void launch_pad_vals32(hipStream_t st, int64_t N2, int64_t V, const int64_t* rowptr, const double* A, const int64_t* p32,
-                       int64_t ptail, int64_t nnz_tail, int64_t tail_src, float* A32) {
+                       int64_t ptail, int64_t nnz_tail, int64_t tail_src, float* A32, bool v_rows_only) {
   int64_t blocks = std::min<int64_t>((N2 + 3) / 4, 8192);
-  hipLaunchKernelGGL(k_pad_vals32, dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, A, p32, A32);
+  hipLaunchKernelGGL(k_pad_vals32, dim3((unsigned)blocks), dim3(256), 0, st, N2, rowptr, A, p32, A32, v_rows_only ? 3 : 0);
   if (V > 0 && nnz_tail > 0) launch_round_to_f32(st, nnz_tail, A + tail_src, A32 + ptail);
 }
 // y = A32 x: padded node rows, then the pressure rows (their values at vals + ptail, indexed by the rows' own pointers
 // shifted by tail_shift = ptail - rowptr[6 N2])
 void launch_spmv_node6p(hipStream_t st, int64_t N2, int64_t V, const int64_t* p32, const int32_t* cols32, const float* vals,
-                        const int64_t* rowptr, const int32_t* cols, int64_t tail_shift, const PRowGraph& g, const double* x, double* y) {
+                        const int64_t* rowptr, const int32_t* cols, int64_t tail_shift, const PRowGraph& g, const double* x, double* y,
+                        const float* ad32) {
   constexpr bool xcd = true;        // XCD-aware node mapping: -9 % HBM traffic (round 2)
+  if (ad32 && g.nadj_ptr && g.nadj) {      // d rows in pair form
+    int64_t blocks = (N2 + 3) / 4;
+    blocks = (blocks + 7) & ~(int64_t)7;
+    hipLaunchKernelGGL(k_spmv_node6pc<true>, dim3((unsigned)blocks), dim3(256), 0, st, N2, p32, cols32, vals, g.nadj_ptr, g.nadj, ad32, x, y);
+    spmv_prows<float>(st, N2, V, rowptr, cols, vals + tail_shift, g, x, y);
+    return;
+  }
   // one wave per node, no grid-stride loop: measured 1.87 ms per product against 2.23 ms with 8192 workgroups looping
   // (row lengths differ by 3x between edge and vertex nodes; the hardware scheduler balances what a static stride cannot)
   constexpr int64_t bmax = (int64_t)1 << 30;      // one wave per node, no grid-stride loop (round 2)

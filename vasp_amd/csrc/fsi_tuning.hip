@@ -72,7 +72,7 @@ void defaults(FsiTuning* t) {
   t->kappa_solid = 1e4; t->kappa_fluid = 5.0; t->kappa_schur = 100.0; t->kappa_disp = 1000.0;
   t->sbmg_pre = 16; t->sbmg_post = 16; t->sbmg_cits = 90; t->sbmg_alpha = 200.0; t->sbmg_ckappa = 4000.0;
   t->mg_pre = 3; t->mg_post = 5; t->mg_cits = 16; t->mg_alpha = 20.0; t->mg_ckappa = 250.0;
-  t->solid_coarse_exact = 1; t->bcr_shift = 2e-4; t->newton_adaptive = 0.3;
+  t->solid_coarse_exact = 1; t->bcr_shift = 2e-4; t->newton_adaptive = 0.3; t->compact_drows = 1;
 }
 
 void from_env(FsiTuning* t) {
@@ -102,6 +102,7 @@ void from_env(FsiTuning* t) {
   I("FSI_MG_PRE", &t->mg_pre); I("FSI_MG_POST", &t->mg_post); I("FSI_MG_CITS", &t->mg_cits);
   D("FSI_MG_ALPHA", &t->mg_alpha); D("FSI_MG_CKAPPA", &t->mg_ckappa);
   I("FSI_SOLID_COARSE_EXACT", &t->solid_coarse_exact); D("FSI_BCR_SHIFT", &t->bcr_shift); D("FSI_NEWTON_ADAPTIVE", &t->newton_adaptive);
+  I("FSI_COMPACT_DROWS", &t->compact_drows);
 }
 
 }  // namespace
