@@ -70,24 +70,26 @@ void schur_apply(FsiCtx* ctx, const double* in, double* out, double* w3) {
 // sweep direction are refreshed after every sweep runs, on its owned rows, the sweeps of the undivided block.  These helpers
 // route a field vector through the monolithic halo exchange (embedded in a scratch dof vector: wasteful, the whole send list
 // travels) so that the effect on the outer iteration can be counted before a field-wise exchange is built.
-__global__ void k_embed_f4(int64_t nn, const int32_t* __restrict__ map, const float* __restrict__ f, double* __restrict__ t, int off) {
+__global__ void k_embed_f4(int64_t nn, const int32_t* __restrict__ map, const int32_t* __restrict__ map2, const float* __restrict__ f, double* __restrict__ t, int off) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nn; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = map ? map[i] : i;
+    int64_t r = map ? map[i] : i;
+    if (map2) r = map2[r];
     for (int c = 0; c < 3; ++c) t[6 * r + off + c] = (double)f[4 * i + c];
   }
 }
-__global__ void k_extract_f4(int64_t nn, const int32_t* __restrict__ map, const double* __restrict__ t, float* __restrict__ f, int off) {
+__global__ void k_extract_f4(int64_t nn, const int32_t* __restrict__ map, const int32_t* __restrict__ map2, const double* __restrict__ t, float* __restrict__ f, int off) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nn; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = map ? map[i] : i;
+    int64_t r = map ? map[i] : i;
+    if (map2) r = map2[r];
     for (int c = 0; c < 3; ++c) f[4 * i + c] = (float)t[6 * r + off + c];
   }
 }
-int halo_field_f4(FsiCtx* ctx, int64_t nn, const int32_t* map, float* f, int off) {
+int halo_field_f4(FsiCtx* ctx, int64_t nn, const int32_t* map, float* f, int off, const int32_t* map2 = nullptr) {
   if (!ctx->part) return FSI_OK;
   const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nn + 255) / 256, 4096));
-  hipLaunchKernelGGL(k_embed_f4, dim3(g), dim3(256), 0, ctx->stream, nn, map, f, ctx->tmp6.p, off);
+  hipLaunchKernelGGL(k_embed_f4, dim3(g), dim3(256), 0, ctx->stream, nn, map, map2, f, ctx->tmp6.p, off);
   FSICHK(halo_update(ctx, ctx->tmp6.p));
-  hipLaunchKernelGGL(k_extract_f4, dim3(g), dim3(256), 0, ctx->stream, nn, map, ctx->tmp6.p, f, off);
+  hipLaunchKernelGGL(k_extract_f4, dim3(g), dim3(256), 0, ctx->stream, nn, map, map2, ctx->tmp6.p, f, off);
   return FSI_OK;
 }
 int halo_field_p(FsiCtx* ctx, double* pvec) {
@@ -247,6 +249,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
             launch_sweep_sb_b3(st, nc, ctx->sbmg_cptr.p, ctx->sbmg_ccol.p, ctx->sbmg_cvals.p, ctx->sbmg_cbinv12.p, (float)(rn * crho),
                                (float)(2.0 * rn / cde), ca, cb, cx, cr, 1);
             std::swap(ca, cb);
+            if (xch & 16) (void)halo_field_f4(ctx, nc, ctx->sbmg_cfine.p, ca, 3, ctx->snode.p);      // ... and of the solid cycle's coarse sweeps
             crho = rn;
           }
         }
