@@ -132,9 +132,7 @@ typedef struct FsiTuning {
   /* block preconditioner */
   int32_t prec_streams;        /* 1: two chains of an application side by side on two HIP streams                                  */
   int32_t experiment;          /* measurement switches of the block factorisation, 0 in production: bit 0       */
-                               /* pressure right-hand side from the fluid predictor only, bit 1 displacement block without velocity;  */
-                               /* partitioned runs: bits 2 / 3 / 4 refresh the ghost entries of the Schur / displacement / solid      */
-                               /* sweeps' direction after every sweep (through the monolithic halo exchange: counts, not speed)       */
+                               /* pressure right-hand side from the fluid predictor only, bit 1 displacement block without velocity   */
   int32_t cheb4;               /* bit 0 / 1 / 2: 4th-kind Chebyshev sweeps in the solid cycle / displacement cycle / Schur solve   */
   int32_t coarse_power;        /* 1: coarse-level Chebyshev intervals from a power iteration (0: Gershgorin bound)                 */
   int32_t solid_mg, dd_mg;     /* two-level (P2 -> P1) cycles of the solid velocity block / the displacement block                 */

@@ -773,6 +773,38 @@ def test_displacement_rows_in_pair_form_give_the_same_products(case_name, tmp_pa
     assert np.abs(ys[1] - ref).max() <= 1e-10 * scale
 
 
+def test_a_displacement_row_with_another_entry_keeps_the_full_product(tmp_path, monkeypatch):
+    """The other side of ``compact_drows``: the pair form is adopted only if the refresh's check finds nothing else in the d rows.
+    ``FSI_DEBUG_DROWS_INJECT`` (a test hook) puts a value where the forms leave a structural zero (a d_y column in a d_x row)
+    into the assembled matrix; the library must notice (``sweep_flags`` bit 6 off) and its product must be the product of THAT
+    matrix, entry included."""
+    from vasp_amd.capi import HipBackend
+    case = prepare_case("cylinder", GOLDEN / "cylinder" / "cylinder.h5", tmp_path)
+    ns, desc = case[0], dict(case[1])
+    mesh = ns["mesh"]
+    U, U1 = random_state(mesh, mesh.num_dofs, seed=3)
+    g, P = boundary_data(case, 0.05)
+    x = np.random.default_rng(8).standard_normal(mesh.num_dofs)
+    out = {}
+    for inject in (0, 1):
+        if inject:
+            monkeypatch.setenv("FSI_DEBUG_DROWS_INJECT", "1")
+        hb = HipBackend(desc)
+        hb.set_state("n", U); hb.set_state("n-1", U1); hb.set_dirichlet_values(g); hb.set_interface_pressure(P)
+        hb.assemble_residual()
+        hb.assemble_jacobian()
+        out[inject] = (bool(int(hb.timers()["sweep_flags"]) & 64), hb.spmv(x), hb.matrix().tocsr())
+        hb.close()
+    assert out[0][0] and not out[1][0]
+    dA = (out[1][2] - out[0][2]).tocoo()
+    dA.eliminate_zeros()
+    assert dA.nnz == 1 and dA.row[0] < 3 * mesh.num_nodes and dA.col[0] < 3 * mesh.num_nodes and dA.row[0] % 3 != dA.col[0] % 3
+    for inject in (0, 1):
+        ref = out[inject][2] @ x
+        assert np.abs(out[inject][1] - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.abs(out[1][1] - out[0][1]).max() > 0.0          # the entry is in the product
+
+
 def test_predeform_runs(tmp_path):
     """REF tests/test_simulations.py:60-77: the predeform problem runs a few steps; printed flow properties are sane."""
     import re

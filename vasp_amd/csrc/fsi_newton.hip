@@ -61,6 +61,17 @@ int fsi_assemble_jacobian(FsiCtx* ctx) {
   // the d rows in pair form for the outer products (FsiTuning.compact_drows): extracted from THIS matrix, and adopted only if the
   // kernel found nothing else in those rows (one flag read per refresh)
   ctx->drows_ok = false;
+  if (getenv("FSI_DEBUG_DROWS_INJECT") && ctx->nnz > 1) {
+    // test hook: a value where the forms leave a structural zero - entry 1 of the first d row (column d_y of node 0's first
+    // neighbour in a d_x row) - so that the check below has a matrix to refuse
+    const int64_t pos = 1;
+    const double val = 0.125;
+    int64_t* dpos = reinterpret_cast<int64_t*>(ctx->scratch.p + 4098);
+    HIPCHK(hipMemcpyAsync(dpos, &pos, sizeof pos, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->scratch.p + 4099, &val, sizeof val, hipMemcpyHostToDevice, ctx->stream));
+    launch_add_at(ctx->stream, ctx->A.p, dpos, ctx->scratch.p + 4099, 1.0, 1);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
   if (ctx->tune.compact_drows && ctx->N2 > 0) {
     const size_t npairs6 = 6 * (size_t)ctx->nadj.n;
     if (!ctx->Ad64.p) HIPCHK(ctx->Ad64.alloc(npairs6));

@@ -65,42 +65,6 @@ void schur_apply(FsiCtx* ctx, const double* in, double* out, double* w3) {
   launch_spmv(ctx->stream, ctx->V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->s_vals.p, in, out, SPMV_FIELD_BLOCK);
 }
 
-// ---- measurement aid (FsiTuning.experiment bits 2 - 4, partitioned runs only): owner -> ghost refresh of a sweep's direction --------
-// Restricted additive Schwarz cuts every inner solve at the overlap.  Owned rows are complete, so a rank whose ghost entries of the
-// sweep direction are refreshed after every sweep runs, on its owned rows, the sweeps of the undivided block.  These helpers
-// route a field vector through the monolithic halo exchange (embedded in a scratch dof vector: wasteful, the whole send list
-// travels) so that the effect on the outer iteration can be counted before a field-wise exchange is built.
-__global__ void k_embed_f4(int64_t nn, const int32_t* __restrict__ map, const int32_t* __restrict__ map2, const float* __restrict__ f, double* __restrict__ t, int off) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nn; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = map ? map[i] : i;
-    if (map2) r = map2[r];
-    for (int c = 0; c < 3; ++c) t[6 * r + off + c] = (double)f[4 * i + c];
-  }
-}
-__global__ void k_extract_f4(int64_t nn, const int32_t* __restrict__ map, const int32_t* __restrict__ map2, const double* __restrict__ t, float* __restrict__ f, int off) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nn; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = map ? map[i] : i;
-    if (map2) r = map2[r];
-    for (int c = 0; c < 3; ++c) f[4 * i + c] = (float)t[6 * r + off + c];
-  }
-}
-int halo_field_f4(FsiCtx* ctx, int64_t nn, const int32_t* map, float* f, int off, const int32_t* map2 = nullptr) {
-  if (!ctx->part) return FSI_OK;
-  const unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nn + 255) / 256, 4096));
-  hipLaunchKernelGGL(k_embed_f4, dim3(g), dim3(256), 0, ctx->stream, nn, map, map2, f, ctx->tmp6.p, off);
-  FSICHK(halo_update(ctx, ctx->tmp6.p));
-  hipLaunchKernelGGL(k_extract_f4, dim3(g), dim3(256), 0, ctx->stream, nn, map, map2, ctx->tmp6.p, f, off);
-  return FSI_OK;
-}
-int halo_field_p(FsiCtx* ctx, double* pvec) {
-  if (!ctx->part) return FSI_OK;
-  double* t = ctx->tmp6.p + 6 * ctx->N2;
-  launch_copy(ctx->stream, t, pvec, ctx->V);
-  FSICHK(halo_update(ctx, ctx->tmp6.p));
-  launch_copy(ctx->stream, pvec, t, ctx->V);
-  return FSI_OK;
-}
-
 // FP32 Chebyshev sweeps on a component-diagonal node-block matrix; dinv carries the Jacobi scaling and the mask
 void cheb_db_f32(FsiCtx* ctx, const float* db, const float* dinv, const double* rhs, double* x, double* W, int its,
                  double lmax, double kappa, hipStream_t st = nullptr) {
@@ -174,8 +138,7 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
                     ctx->pv32_ok && ctx->adv_is_db && ctx->cheb_its_d > 0 && ctx->dd_is_scalar && 4 * V <= n3 && ctx->debug_prec_apply == 0;
   // (the applications whose sweep launches are timed by event pairs issue both chains on the solver stream - the same arithmetic in
   // the same order per chain, and a pair brackets its kernel alone)
-  const int xch = ctx->part ? (ctx->tune.experiment & (4 | 8 | 16)) : 0;      // experiment bits 2 - 4: per-sweep halo refreshes (one stream then)
-  hipStream_t sA = ctx->stream, sB = (conc && ctx->sample_budget <= 0 && !xch) ? ctx->stream2 : ctx->stream;
+  hipStream_t sA = ctx->stream, sB = (conc && ctx->sample_budget <= 0) ? ctx->stream2 : ctx->stream;
   launch_split(st, N2, V, r, rd, rv, rp);
   if (conc) { HIPCHK(hipEventRecord(ctx->ev_split, sA)); HIPCHK(hipStreamWaitEvent(sB, ctx->ev_split, 0)); }
   // velocity predictor: block Gauss-Seidel solid (elasticity-dominated, many cheap sweeps) -> fluid interior (mass-dominated)
@@ -219,7 +182,6 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
             launch_sweep_sb_b3(st, ctx->nS, ctx->sb_ptr.p, ctx->sb_col.p, ctx->sb_vals.p, ctx->sb_binv12.p, c1, c2, dcur, dnext, fx, fr);
           if (timed) (void)hipEventRecord(ctx->ss_ev1[sample], st);
           std::swap(dcur, dnext);
-          if (xch & 16) (void)halo_field_f4(ctx, ctx->nS, ctx->snode.p, dcur, 3);      // experiment bit 4: the solid sweeps' direction (v part)
         };
         for (int k = 0; k < ctx->sbmg_pre; ++k) {
           if (s4) { float c1, c2; s4c(k + 1, &c1, &c2); sweep(c1, c2, k); continue; }
@@ -249,13 +211,11 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
             launch_sweep_sb_b3(st, nc, ctx->sbmg_cptr.p, ctx->sbmg_ccol.p, ctx->sbmg_cvals.p, ctx->sbmg_cbinv12.p, (float)(rn * crho),
                                (float)(2.0 * rn / cde), ca, cb, cx, cr, 1);
             std::swap(ca, cb);
-            if (xch & 16) (void)halo_field_f4(ctx, nc, ctx->sbmg_cfine.p, ca, 3, ctx->snode.p);      // ... and of the solid cycle's coarse sweeps
             crho = rn;
           }
         }
         launch_sbmg_prolong(st, ctx->nS, ctx->sbmg_par.p, ctx->sbmg_pw.p, ctx->sbmg_flag.p, cx, dcur,     // correction as the next direction
                             exact ? bcr_pos(ctx) : nullptr, exact ? bcr_sol(ctx) : nullptr);
-        if (xch & 16) (void)halo_field_f4(ctx, ctx->nS, ctx->snode.p, dcur, 3);      // (the owners' coarse correction on the ghost nodes)
         sweep(0.f, (float)sinit, -1);                          // x += P x_c, r -= A P x_c, restart the recurrence
         srho = 1.0 / ssig;
         for (int k = 0; k < ctx->sbmg_post; ++k) {
@@ -363,7 +323,6 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
                                c2, pa, pb, dp, pr);
         if (timed) { (void)hipEventRecord(ctx->sch_ev1[k], st); ctx->sch_samples_pending = k + 1; }
         std::swap(pa, pb);
-        if (xch & 4) FSICHK(halo_field_p(ctx, pa));      // experiment bit 2: the Schur sweeps' direction
         rho = rn;
       }
     }
@@ -381,7 +340,6 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
       launch_sweep_csr_f64(st, V, ctx->s_rowptr.p, ctx->s_cols.p, ctx->s_vals.p, ctx->s_diagpos.p, rn * rho, 2.0 * rn / de, pa, pb, dp, pr);
       if (timed) { (void)hipEventRecord(ctx->sch_ev1[k], st); ctx->sch_samples_pending = k + 1; }
       std::swap(pa, pb);
-      if (xch & 4) FSICHK(halo_field_p(ctx, pa));
       rho = rn;
     }
     ctx->inner_its[1] += ctx->cheb_its_p;
@@ -459,7 +417,6 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
                                  ctx->dd_rowflag.p, nullptr, c1, c2, dcur, dnext, fx, fr);
         if (timed) { (void)hipEventRecord(ctx->sc_ev1[k_sample], st); ctx->sc_samples_pending = k_sample + 1; }
         std::swap(dcur, dnext);
-        if (xch & 8) (void)halo_field_f4(ctx, N2, nullptr, dcur, 0);      // experiment bit 3: the displacement sweeps' direction (d part)
       };
       if (ctx->mg_ready) {
         // two-level cycle: Chebyshev smoothing on [lmax/alpha, lmax], coarse solve on the vertex graph, smoothing again
@@ -491,7 +448,6 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
               launch_sweep_sc_f32(st, nc, ctx->mg_cptr.p, ctx->mg_ccol.p, ctx->mg_cc.p, ctx->mg_cflag.p, (float)(rn * crho),
                                   (float)(2.0 * rn / cde), ca, cb, cx, cr);
               std::swap(ca, cb);
-              if (xch & 8) (void)halo_field_f4(ctx, nc, ctx->mg_cfine.p, ca, 0);      // ... and of its coarse level (vertices -> their fine ranks)
             } else {
               launch_spmv_sc_f32(st, nc, ctx->mg_cptr.p, ctx->mg_ccol.p, ctx->mg_cc.p, ctx->mg_cflag.p, cd, ct);
               launch_cheb_step_f32(st, n4c, ct, ctx->mg_cones.p, (float)(rn * crho), (float)(2.0 * rn / cde), cx, cr, cd);
@@ -500,7 +456,6 @@ int precondition_block(FsiCtx* ctx, const double* r, double* z) {
           }
         }
         launch_mg_prolong(st, N2, ctx->mg_par.p, ctx->mg_pw.p, ctx->mg_d0.p, cx, dcur);   // correction as the next direction
-        if (xch & 8) (void)halo_field_f4(ctx, N2, nullptr, dcur, 0);
         fine_sweep(0.f, (float)dinit, -1);                                             // x += P x_c, r -= C P x_c, restart
         srho = 1.0 / ssig;
         for (int k = 0; k < ctx->mg_post; ++k) {
@@ -820,9 +775,6 @@ int refresh_preconditioner(FsiCtx* ctx) {
     ctx->prec_bad = false;
     double prev_out = 0.0;
     const double l0[4] = {ctx->lmax_s, ctx->lmax_f, ctx->lmax_p, ctx->lmax_d};
-    const int32_t experiment = ctx->tune.experiment;
-    ctx->tune.experiment &= 3;      // the self-test is rank-local (its number of attempts may differ from rank to rank): no collectives inside
-    struct Restore { FsiCtx* c; int32_t v; ~Restore() { c->tune.experiment = v; } } restore{ctx, experiment};
     for (int attempt = 0; attempt < 8; ++attempt) {
       launch_mask_ripple(st, ctx->ndof, nullptr, ctx->tmp1.p);
       FSICHK(precondition_block(ctx, ctx->tmp1.p, ctx->tmp2.p));
@@ -846,15 +798,6 @@ int refresh_preconditioner(FsiCtx* ctx) {
       ctx->lmax_s *= 1.6; ctx->lmax_f *= 1.6; ctx->lmax_p *= 1.6; ctx->lmax_d *= 1.6;
       ctx->sbmg_clmax = std::min(ctx->sbmg_clmax * 1.6, std::max(ctx->sbmg_clmax, (double)ctx->sbmg_gersh));      // towards the row-sum bounds
       ctx->mg_clmax = std::min(ctx->mg_clmax * 1.6, std::max(ctx->mg_clmax, (double)ctx->mg_gersh));
-    }
-    if (ctx->part && (experiment & (4 | 8 | 16))) {
-      // sweeps whose directions cross the cut must be the SAME polynomial on every rank: one set of intervals for the job - the
-      // largest estimate of any rank, as a power mean of order 32 through the sum the transport offers (within 7 % above it at 8 ranks)
-      double* e[6] = {&ctx->lmax_s, &ctx->lmax_f, &ctx->lmax_p, &ctx->lmax_d, &ctx->sbmg_clmax, &ctx->mg_clmax};
-      double v[6];
-      for (int k = 0; k < 6; ++k) v[k] = std::pow(std::max(*e[k], 1e-30), 32.0);
-      FSICHK(allreduce(ctx, v, 6));
-      for (int k = 0; k < 6; ++k) *e[k] = std::pow(v[k], 1.0 / 32.0);
     }
     return FSI_OK;
   }
