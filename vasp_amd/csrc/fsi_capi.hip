@@ -305,6 +305,13 @@ int fsi_create_tuned(const FsiMeshDesc* mesh, const FsiParams* prm, int device, 
   HIPCHK(upload_tables());
 
   ctx->V = V; ctx->N2 = N2; ctx->C = C; ctx->ndof = 6 * N2 + V;
+  if (ctx->tune.mg_post <= 0) {
+    // "by size" (the default): what a fine displacement sweep costs is a launch's latency in a small context and its bytes in a large
+    // one, what it saves in outer iterations is the same - seven sweeps after the coarse correction win 2 - 15 % up to 630 k tets in
+    // both storage modes, five win 3 - 6 % from 1.12 M tets on in the mixed mode (profiles/r05_param_scan_final_tree.txt)
+    ctx->tune.mg_post = N2 < 1100000 ? 7 : 5;
+    ctx->mg_post = ctx->tune.mg_post;
+  }
   ctx->scheme = Scheme{prm->dt, prm->theta, 1.0 - prm->theta, prm->delta, prm->laplace_alpha};
   ctx->nfluid = prm->num_fluid_regions;
   ctx->nsolid = prm->num_solid_regions;

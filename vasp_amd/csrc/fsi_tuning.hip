@@ -71,7 +71,7 @@ void defaults(FsiTuning* t) {
   t->its_solid = 300; t->its_fluid = 4; t->its_schur = 30; t->its_disp = 60;
   t->kappa_solid = 1e4; t->kappa_fluid = 5.0; t->kappa_schur = 100.0; t->kappa_disp = 1000.0;
   t->sbmg_pre = 16; t->sbmg_post = 16; t->sbmg_cits = 90; t->sbmg_alpha = 200.0; t->sbmg_ckappa = 4000.0;
-  t->mg_pre = 3; t->mg_post = 5; t->mg_cits = 16; t->mg_alpha = 20.0; t->mg_ckappa = 250.0;
+  t->mg_pre = 3; t->mg_post = 0; t->mg_cits = 16; t->mg_alpha = 20.0; t->mg_ckappa = 250.0;
   t->solid_coarse_exact = 1; t->bcr_shift = 2e-4; t->newton_adaptive = 0.3; t->compact_drows = 1;
 }
 
