@@ -805,6 +805,24 @@ def test_a_displacement_row_with_another_entry_keeps_the_full_product(tmp_path, 
     assert np.abs(out[1][1] - out[0][1]).max() > 0.0          # the entry is in the product
 
 
+def test_displacement_smoothing_is_chosen_by_context_size(cylinder_case):
+    """``FsiTuning.mg_post = 0`` (the default) is resolved when the context is created - seven sweeps after the coarse correction of
+    the displacement cycle below 1.1 M P2 nodes, five above (profiles/r05_param_scan_final_tree.txt) - and ``fsi_get_tuning`` returns
+    what was taken; an explicit value is kept."""
+    from vasp_amd.capi import HipBackend, FsiTuning, load_library
+    import ctypes
+    t = FsiTuning()
+    load_library().fsi_tuning_defaults(ctypes.byref(t))
+    assert t.mg_post == 0
+    desc = cylinder_case[1]
+    hb = HipBackend(desc)
+    assert hb.tuning()["mg_post"] == 7
+    hb.close()
+    hb = HipBackend(desc, tuning=dict(mg_post=5))
+    assert hb.tuning()["mg_post"] == 5
+    hb.close()
+
+
 def test_predeform_runs(tmp_path):
     """REF tests/test_simulations.py:60-77: the predeform problem runs a few steps; printed flow properties are sane."""
     import re
