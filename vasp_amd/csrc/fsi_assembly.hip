@@ -185,7 +185,12 @@ __global__ __launch_bounds__(64, WAVES) void k_residual(ElemArrays ea, ElemParam
   if (lane < NQ) sW[lane] = c_qw[lane];
   const int64_t npairs = (C + 1) / 2;
   const int half = lane >> 5, q = lane & 31;
-  for (int64_t pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+  // cell pairs in the XCD-aware order of fsi_kernels.hpp: the state entries neighbouring cells share are fetched into ONE L2 instead
+  // of eight (gridDim.x is a multiple of 8: the XCD of a logical workgroup is that of its launch index)
+  const int64_t span = xcd_span(npairs);
+  for (int64_t lw = blockIdx.x; lw < span; lw += gridDim.x) {
+    const int64_t pair = xcd_unit(lw, npairs);
+    if (pair < 0) continue;
     const int64_t c0 = 2 * pair;
     const int ncell = c0 + 1 < C ? 2 : 1;
     int32_t dof[2] = {0, 0};
@@ -726,7 +731,7 @@ void launch_geometry(hipStream_t st, int64_t C, const double* coords, const int3
 // gather form (Re and the incidence lists given): every entry of F is written, no memset needed; otherwise F += with atomics
 void launch_residual(hipStream_t st, int64_t C, const ElemArrays& ea, const ElemParams& ep, const double* U,
                      const double* U1, double* F, const ResidualGather& rg) {
-  const int64_t grid = std::min<int64_t>((C + 1) / 2, 256 * 8 * 4);      // persistent: a few rounds of the resident workgroups
+  const int64_t grid = std::min<int64_t>(xcd_grid((C + 1) / 2), 256 * 8 * 4);      // persistent: a few rounds of the resident workgroups
   hipLaunchKernelGGL(k_residual<2>, dim3((unsigned)grid), dim3(64), 0, st, ea, ep, U, U1, F, C, rg.Re);
   if (rg.Re) {
     const int64_t n = 6 * rg.N2 + rg.V;

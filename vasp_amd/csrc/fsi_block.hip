@@ -644,6 +644,8 @@ __global__ __launch_bounds__(256) void k_spmv_sc_f32(int64_t N2, const int64_t* 
 // (a few thousand distinct nodes in mesh order) are gathered ONCE into LDS, the node-pair loop then reads 16-byte
 // entries from LDS through 2-byte local indices.  HBM per pair: value(s) + 2 B instead of value(s) + 4 B + a 16-B
 // gather that the L1/L2 have to serve.
+// The tile of a workgroup: in the XCD-aware order of fsi_kernels.hpp (grid = xcd_grid(tiles); -1: no tile)
+__device__ inline int64_t xcd_tile(int64_t ntiles) { return xcd_unit(blockIdx.x, ntiles); }
 static constexpr int TILE_LIMIT = 3584;          // distinct neighbour nodes per tile (56 KB of LDS as float4; + 6 KB static < 64 KB per workgroup)
 template <int NV, int TN>     // NV = 1: one ratio per pair (displacement block), NV = 3: component-diagonal values (fluid velocity block)
 __global__ __launch_bounds__(256) void k_spmv_tiled_f32(int64_t N2, const int64_t* __restrict__ nadj_ptr,
@@ -653,7 +655,8 @@ __global__ __launch_bounds__(256) void k_spmv_tiled_f32(int64_t N2, const int64_
                                                         float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) float4 sx[];   // max over the tiles of their distinct-neighbour count
   __shared__ __attribute__((aligned(16))) int64_t sptr[TN + 2];   // size a multiple of 16 B: keeps the dynamic base aligned
-  const int64_t tile = blockIdx.x;
+  const int64_t tile = xcd_tile((N2 + TN - 1) / TN);
+  if (tile < 0) return;
   const int64_t u0 = tile_uptr[tile], nu = tile_uptr[tile + 1] - u0;
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const int64_t r0 = tile * TN;
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(256) void k_spmv_tiled_f32(int64_t N2, const int64_
 void launch_spmv_tiled_f32(hipStream_t st, int nv, int tn, int64_t N2, int max_nu, const int64_t* nadj_ptr, const float* vals,
                            const uint16_t* ploc, const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag,
                            const float* x, float* y) {
-  const unsigned tiles = (unsigned)((N2 + tn - 1) / tn);
+  const unsigned tiles = xcd_grid((N2 + tn - 1) / tn);
   const size_t lds = (size_t)max_nu * sizeof(float4);
   TILED_DISPATCH(k_spmv_tiled_f32, 256, N2, nadj_ptr, vals, ploc, tile_uptr, ulist, rowflag, x, y);
 }
@@ -743,7 +746,8 @@ __global__ __launch_bounds__(1024) void k_sweep_tiled_f32(int64_t N2, const int6
   extern __shared__ __attribute__((aligned(16))) float4 sx[];
   __shared__ __attribute__((aligned(16))) int64_t sptr[TN + 2];
   __shared__ __attribute__((aligned(16))) float4 ssum[TN];   // the tile's products; the update below reads them coalesced
-  const int64_t tile = blockIdx.x;
+  const int64_t tile = xcd_tile((N2 + TN - 1) / TN);
+  if (tile < 0) return;
   const int64_t u0 = tile_uptr[tile], nu = tile_uptr[tile + 1] - u0;
   const float4* d4 = reinterpret_cast<const float4*>(din);
   const int64_t r0 = tile * TN;
@@ -833,7 +837,7 @@ void launch_sweep_tiled_f32(hipStream_t st, int nv, int tn, int64_t N2, int max_
                             const uint16_t* ploc, const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag,
                             const float* dinv, float c1, float c2, const float* din, float* dout, float* x, float* r) {
   const int th = tn == 128 ? 256 : 512;      // 16 lanes per node, 8 rounds per tile (measured at 256 nodes: 1024 threads no gain over 512)
-  const unsigned tiles = (unsigned)((N2 + tn - 1) / tn);
+  const unsigned tiles = xcd_grid((N2 + tn - 1) / tn);
   const size_t lds = (size_t)max_nu * sizeof(float4);
   TILED_DISPATCH(k_sweep_tiled_f32, th, N2, nadj_ptr, vals, ploc, tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
 }
@@ -885,7 +889,8 @@ __global__ __launch_bounds__(1024) void k_sweep_tiled_h(int64_t N2, const int64_
   extern __shared__ __attribute__((aligned(16))) float4 sx[];
   __shared__ __attribute__((aligned(16))) int64_t sptr[TN + 2];
   __shared__ __attribute__((aligned(16))) float4 ssum[TN];
-  const int64_t tile = blockIdx.x;
+  const int64_t tile = xcd_tile((N2 + TN - 1) / TN);
+  if (tile < 0) return;
   const int64_t u0 = tile_uptr[tile], nu = tile_uptr[tile + 1] - u0;
   const float4* d4 = reinterpret_cast<const float4*>(din);
   const int64_t r0 = tile * TN;
@@ -964,7 +969,7 @@ void launch_sweep_tiled_h(hipStream_t st, int nv, int tn, int64_t N2, int max_nu
                           const int64_t* tile_uptr, const int32_t* ulist, const uint8_t* rowflag, const float* dinv, float c1,
                           float c2, const float* din, float* dout, float* x, float* r) {
   const int th = tn == 128 ? 256 : 512;
-  const unsigned tiles = (unsigned)((N2 + tn - 1) / tn);
+  const unsigned tiles = xcd_grid((N2 + tn - 1) / tn);
   const size_t lds = (size_t)max_nu * sizeof(float4);
   if (nv == 1 && tn == 128)
     hipLaunchKernelGGL((k_sweep_tiled_h<1, 128>), dim3(tiles), dim3(th), lds, st, N2, nadj_ptr, static_cast<const uint32_t*>(rec), tile_uptr, ulist, rowflag, dinv, c1, c2, din, dout, x, r);
@@ -986,8 +991,11 @@ __global__ __launch_bounds__(256) void k_sweep_sb_h(int64_t nS, const int64_t* _
                                                     float* __restrict__ x, float* __restrict__ r) {
   constexpr int NB = 32 / LPR;                               // blocks in flight per lane
   const int sub = threadIdx.x & (LPR - 1);
-  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / LPR;
-  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) / LPR;
+  // rows in the workgroups' XCD-aware order (xcd_tile): a workgroup's 256 / LPR rows gather the d entries of rows a few workgroups away
+  const int64_t lb = xcd_tile((nS * LPR + 255) / 256);
+  if (lb < 0) return;
+  const int64_t grp = (lb * (int64_t)blockDim.x + threadIdx.x) / LPR;
+  const int64_t ngrp = nS;                                   // one row per group: the grid covers the rows
   const float4* d4 = reinterpret_cast<const float4*>(din);
   for (int64_t i = grp; i < nS; i += ngrp) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -1030,8 +1038,8 @@ __global__ __launch_bounds__(256) void k_sweep_sb_h(int64_t nS, const int64_t* _
 void launch_sweep_sb_h(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const void* rec, const float* binv12, float c1, float c2,
                        const float* din, float* dout, float* x, float* r) {
   constexpr int LPR = 8;
-  int64_t blocks = (nS * LPR + 255) / 256;
-  hipLaunchKernelGGL(k_sweep_sb_h<LPR>, dim3((unsigned)blocks), dim3(256), 0, st, nS, sb_ptr, static_cast<const uint2*>(rec), binv12, c1, c2, din, dout, x, r);
+  const int64_t blocks = (nS * LPR + 255) / 256;
+  hipLaunchKernelGGL(k_sweep_sb_h<LPR>, dim3(xcd_grid(blocks)), dim3(256), 0, st, nS, sb_ptr, static_cast<const uint2*>(rec), binv12, c1, c2, din, dout, x, r);
 }
 
 // The same fused sweep without tiles (coarse level of the displacement block: the vertex graph, L2-resident)
@@ -1711,7 +1719,9 @@ __global__ __launch_bounds__(256) void k_sweep_schur_tiled(int64_t n, const int6
   extern __shared__ __attribute__((aligned(16))) double sxd[];
   __shared__ int64_t sptr[SCHUR_TILE + 1];
   __shared__ double ssum[SCHUR_TILE];
-  const int64_t tile = blockIdx.x, r0 = tile * SCHUR_TILE;
+  const int64_t tile = xcd_tile((n + SCHUR_TILE - 1) / SCHUR_TILE);
+  if (tile < 0) return;
+  const int64_t r0 = tile * SCHUR_TILE;
   const int nrows = (int)((r0 + SCHUR_TILE < n ? r0 + SCHUR_TILE : n) - r0);
   const int64_t u0 = tile_uptr[tile], nu = tile_uptr[tile + 1] - u0;
   for (int64_t i = threadIdx.x; i < nu; i += 1024) {              // four dependent index -> entry pairs in flight
@@ -1751,7 +1761,7 @@ __global__ __launch_bounds__(256) void k_sweep_schur_tiled(int64_t n, const int6
 void launch_sweep_schur_tiled(hipStream_t st, int tile_rows, int64_t n, int max_nu, const int64_t* rowptr, const uint32_t* rec,
                               const int64_t* tile_uptr, const int32_t* ulist, const double* dinv, double c1, double c2,
                               const double* din, double* dout, double* x, double* r) {
-  const unsigned tiles = (unsigned)((n + tile_rows - 1) / tile_rows);
+  const unsigned tiles = xcd_grid((n + tile_rows - 1) / tile_rows);
   const size_t lds = (size_t)max_nu * sizeof(double);
   if (tile_rows == 32)
     hipLaunchKernelGGL(k_sweep_schur_tiled<32>, dim3(tiles), dim3(256), lds, st, n, rowptr, rec, tile_uptr, ulist, dinv, c1, c2, din, dout, x, r);
@@ -1772,9 +1782,12 @@ __global__ __launch_bounds__(256) void k_sweep_sb_b3(int64_t nS, const int64_t* 
                                                      const float* __restrict__ din, float* __restrict__ dout,
                                                      float* __restrict__ x, float* __restrict__ r) {
   const int sub = threadIdx.x & 15;
-  const int64_t grp = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
-  const int64_t ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
-  for (int64_t i = grp; i < nS; i += ngrp) {
+  // (workgroups in the XCD-aware order of xcd_tile; a grid-stride loop over the logical workgroups keeps the launch's cap)
+  const int64_t nlb = (nS + 15) / 16, nwg = gridDim.x, span = xcd_span(nlb);
+  for (int64_t lb0 = blockIdx.x; lb0 < span; lb0 += nwg) {
+  const int64_t lb = xcd_unit(lb0, nlb);
+  const int64_t i = lb * 16 + (threadIdx.x >> 4);
+  if (lb >= 0 && i < nS) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     const int64_t bend = sb_ptr[i + 1];
     if (LEVEL == 0) {
@@ -1820,11 +1833,12 @@ __global__ __launch_bounds__(256) void k_sweep_sb_b3(int64_t nS, const int64_t* 
       dout[4 * i + sub] = c1 * dc + c2 * (brow.x * r0 + brow.y * r1 + brow.z * r2);
     }
   }
+  }
 }
 void launch_sweep_sb_b3(hipStream_t st, int64_t nS, const int64_t* sb_ptr, const int32_t* sb_col, const float* vals,
                         const float* binv12, float c1, float c2, const float* din, float* dout, float* x, float* r, int level) {
-  int64_t blocks = (nS + 15) / 16;
-  if (blocks > 16384) blocks = 16384;
+  int64_t blocks = xcd_grid((nS + 15) / 16);
+  if (blocks > 16384) blocks = 16384;                   // (a multiple of 8: the XCD of a logical workgroup is that of its launch index)
   if (level == 0)
     hipLaunchKernelGGL(k_sweep_sb_b3<0>, dim3((unsigned)blocks), dim3(256), 0, st, nS, sb_ptr, sb_col, vals, binv12, c1, c2, din,
                        dout, x, r);

@@ -4,6 +4,20 @@
 
 namespace fsi {
 #if defined(__HIPCC__)
+// XCD-aware order of a launch's logical workgroups.  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2; a tile's
+// staged neighbour entries are mostly those of the tiles beside it along the (Morton) node order.  Logical workgroup L (XCD L & 7,
+// slot L >> 3 on that XCD) takes unit (L & 7) * ceil(n / 8) + (L >> 3): XCD k works through the k-th eighth of the units, as
+// k_spmv_node6 does, so that what neighbouring units share is fetched into ONE L2 instead of eight.  Measured on one box against the
+// launch order and against runs of 16 / 64 consecutive units dealt to the XCDs in turn (NOTEBOOK.md section 9): L2 -> fabric bytes of
+// k_residual 2.29 -> 1.65 x the algorithmic ones, Schur sweep 1.87 -> 1.69; step time unchanged at 1.12 M tets (the sweeps are paced
+// by dependent loads, not bytes), -4 % at 140 k; the three mappings equal.
+// xcd_span(n) logical workgroups cover n units (a multiple of 8); xcd_unit returns -1 for a logical workgroup without a unit.
+__host__ __device__ inline int64_t xcd_span(int64_t n) { return (n + 7) / 8 * 8; }
+__device__ inline int64_t xcd_unit(int64_t L, int64_t n) {
+  const int64_t chunk = (n + 7) >> 3, s = L >> 3, t = (L & 7) * chunk + s;
+  return s < chunk && t < n ? t : -1;
+}
+static inline unsigned xcd_grid(int64_t n) { return (unsigned)xcd_span(n); }
 // Sum over an aligned group of 4 / 8 / 16 lanes by DPP adds (quad permutes, then half-row and row mirrors): four VALU
 // instructions per value instead of four ds_bpermute round trips through the LDS crossbar, which is what __shfl_xor
 // compiles to and what paced the 16-lanes-per-row sweep kernels.  Every lane of the group ends up with the sum.
