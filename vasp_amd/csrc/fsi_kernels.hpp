@@ -9,7 +9,7 @@ namespace fsi {
 // slot L >> 3 on that XCD) takes unit (L & 7) * ceil(n / 8) + (L >> 3): XCD k works through the k-th eighth of the units, as
 // k_spmv_node6 does, so that what neighbouring units share is fetched into ONE L2 instead of eight.  Measured on one box against the
 // launch order and against runs of 16 / 64 consecutive units dealt to the XCDs in turn (NOTEBOOK.md section 9): L2 -> fabric bytes of
-// k_residual 2.29 -> 1.65 x the algorithmic ones, Schur sweep 1.87 -> 1.69; step time unchanged at 1.12 M tets (the sweeps are paced
+// k_residual 2.29 -> 1.65 x the algorithmic ones, Schur sweep 1.87 -> 1.55, solid fine sweep 1.12 -> 1.00; step time unchanged at 1.12 M tets (the sweeps are paced
 // by dependent loads, not bytes), -4 % at 140 k; the three mappings equal.
 // xcd_span(n) logical workgroups cover n units (a multiple of 8); xcd_unit returns -1 for a logical workgroup without a unit.
 __host__ __device__ inline int64_t xcd_span(int64_t n) { return (n + 7) / 8 * 8; }
