@@ -381,6 +381,11 @@ int fsi_solid_coarse_matrix(FsiCtx* ctx, int64_t* cptr, int32_t* ccol, float* cv
 /* x = A_c^-1 rhs by the production kernels (3 doubles per coarse node) */
 int fsi_solid_coarse_solve(FsiCtx* ctx, const double* rhs, double* x);
 
+/* Host-only test hook of the XCD-aware workgroup order (csrc/fsi_kernels.hpp: xcd_unit / xcd_span) that k_residual and the sweep
+ * kernels use: unit_out[span] = the unit (tile, cell pair, row block) logical workgroup L of a launch over n units works on, -1 for
+ * a workgroup without one; returns span = the number of logical workgroups launched (unit_out may be NULL), -1 for n < 0. */
+int64_t fsi_xcd_order(int64_t n, int64_t* unit_out);
+
 int fsi_get_timers(FsiCtx* ctx, FsiTimers* out, int reset);
 /* Run totals since fsi_create, without resolving the phase timers (no device synchronisation, safe to call every time step,
  * unaffected by fsi_get_timers(reset = 1)): out[0] newton_retries, out[1] fp32_fallbacks, out[2] gcr_restarts - what the product

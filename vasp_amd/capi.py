@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "fsi_set_pressure_facets", "fsi_set_interface_pressure", "fsi_set_robin_facets", "fsi_solver_setup",
     "fsi_assemble_residual", "fsi_assemble_jacobian", "fsi_solve", "fsi_newton_solve", "fsi_shift",
     "fsi_get_state", "fsi_set_state", "fsi_num_dofs", "fsi_matrix_nnz", "fsi_device_memory", "fsi_apply_preconditioner", "fsi_get_matrix", "fsi_spmv",
-    "fsi_get_timers", "fsi_get_solver_events", "fsi_bcr_plan_graph", "fsi_solid_coarse_info", "fsi_solid_coarse_matrix", "fsi_solid_coarse_solve", "fsi_get_values", "fsi_stress_strain", "fsi_wall_shear_stress", "fsi_calibration_streams", "fsi_set_newton_forcing", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
+    "fsi_get_timers", "fsi_get_solver_events", "fsi_xcd_order", "fsi_bcr_plan_graph", "fsi_solid_coarse_info", "fsi_solid_coarse_matrix", "fsi_solid_coarse_solve", "fsi_get_values", "fsi_stress_strain", "fsi_wall_shear_stress", "fsi_calibration_streams", "fsi_set_newton_forcing", "fsi_set_linear_solver", "fsi_set_chebyshev", "fsi_probe", "fsi_flow_stats", "fsi_set_partition",
     "fsi_rccl_unique_id", "fsi_set_rccl", "fsi_create_tuned", "fsi_get_tuning", "fsi_tuning_defaults", "fsi_tuning_from_env", "fsi_tuning_copy_out",
 )
 
@@ -159,6 +159,8 @@ def load_library(path: Optional[Path] = None):
     lib.fsi_get_timers.argtypes = [vp, C.POINTER(FsiTimers), C.c_int]
     lib.fsi_get_solver_events.argtypes = [vp, vp]
     lib.fsi_bcr_plan_graph.argtypes = [i64, vp, vp, vp, vp, vp]
+    lib.fsi_xcd_order.argtypes = [i64, vp]
+    lib.fsi_xcd_order.restype = i64
     lib.fsi_solid_coarse_info.argtypes = [vp, vp]
     lib.fsi_solid_coarse_matrix.argtypes = [vp, vp, vp, vp]
     lib.fsi_solid_coarse_solve.argtypes = [vp, vp, vp]

@@ -1500,6 +1500,14 @@ int fsi_wall_shear_stress(FsiCtx* ctx, int64_t nf, const int32_t* facet_cells, c
   return FSI_OK;
 }
 
+int64_t fsi_xcd_order(int64_t n, int64_t* unit_out) {
+  if (n < 0) return -1;
+  const int64_t span = fsi::xcd_span(n);
+  if (unit_out)
+    for (int64_t L = 0; L < span; ++L) unit_out[L] = fsi::xcd_unit(L, n);
+  return span;
+}
+
 int fsi_get_solver_events(const FsiCtx* ctx, int64_t out[8]) {
   if (!ctx || !out) return FSI_ERR_INVALID;
   out[0] = ctx->ev_base[0] + ctx->newton_retries;

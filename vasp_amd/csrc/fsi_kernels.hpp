@@ -13,7 +13,7 @@ namespace fsi {
 // by dependent loads, not bytes), -4 % at 140 k; the three mappings equal.
 // xcd_span(n) logical workgroups cover n units (a multiple of 8); xcd_unit returns -1 for a logical workgroup without a unit.
 __host__ __device__ inline int64_t xcd_span(int64_t n) { return (n + 7) / 8 * 8; }
-__device__ inline int64_t xcd_unit(int64_t L, int64_t n) {
+__host__ __device__ inline int64_t xcd_unit(int64_t L, int64_t n) {
   const int64_t chunk = (n + 7) >> 3, s = L >> 3, t = (L & 7) * chunk + s;
   return s < chunk && t < n ? t : -1;
 }
