@@ -201,8 +201,10 @@ int fsi_set_newton_forcing(FsiCtx* ctx, double forcing);
 int fsi_set_linear_solver(FsiCtx* ctx, int32_t precond);
 /* Sweep counts and assumed condition numbers of the Chebyshev solves inside the block preconditioner (solid and
  * fluid-interior part of the velocity block, pressure Schur complement).  Non-positive arguments keep the current value.
- * Defaults: solid 300 / 1e4 (one-level fallback; default: two-level cycle), fluid 4 / 5, Schur 40 / 1e2, displacement 60 / 1e3 (one-level fallback; the default
- * displacement solve is the two-level P2 -> P1 cycle: 4 + 8 smoothing sweeps around 40 coarse sweeps). */
+ * Defaults (csrc/fsi_tuning.hip is the one place that holds them): solid 300 / 1e4 (one-level fallback; default: the two-level cycle,
+ * 16 + 16 sweeps around the exact coarse solve), fluid 4 / 5, Schur 30 / 1e2, displacement 60 / 1e3 (one-level fallback; the default
+ * displacement solve is the two-level P2 -> P1 cycle: 3 + 5 smoothing sweeps - 3 + 7 in contexts below 1.1 M nodes - around 16 coarse
+ * sweeps). */
 int fsi_set_chebyshev(FsiCtx* ctx, int32_t its_solid, double kappa_solid, int32_t its_fluid, double kappa_fluid,
                       int32_t its_schur, double kappa_schur, int32_t its_disp, double kappa_disp);
 /* Finishes set-up: assembles A_pre = assemble(J_linear) at the current state (solver_setup()). */
